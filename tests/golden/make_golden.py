@@ -1,0 +1,161 @@
+"""Generate the golden fixtures by running the REFERENCE itself (PyTorch CPU, fp32).
+
+Run in the build container only (needs /root/reference):
+    python tests/golden/make_golden.py
+It imports the reference with the two shims of SURVEY.md §8c (stub `pulp`; force
+`pretrained=False` for the ResNets), loads the recipe weights of oracle/weights.py and writes
+small .pt/.npz fixtures next to this file.  Nothing here is imported by the product or the tests.
+"""
+import hashlib
+import json
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+REF = os.environ.get('DEVA_REFERENCE_ROOT', '/root/reference')
+sys.modules.setdefault('pulp', types.ModuleType('pulp'))
+sys.path.insert(0, REF)
+import deva.model.resnet as _R  # noqa: E402
+
+_r18, _r50 = _R.resnet18, _R.resnet50
+_R.resnet18 = lambda pretrained=True, extra_dim=0: _r18(pretrained=False, extra_dim=extra_dim)
+_R.resnet50 = lambda pretrained=True, extra_dim=0: _r50(pretrained=False, extra_dim=extra_dim)
+from deva.model.network import DEVA  # noqa: E402
+from deva.inference.inference_core import DEVAInferenceCore  # noqa: E402
+from deva.model import memory_utils as MU  # noqa: E402
+from deva.inference.memory_manager import MemoryManager  # noqa: E402
+from deva.utils.tensor_utils import pad_divide_by  # noqa: E402
+
+from oracle import synth, weights  # noqa: E402
+import scenarios  # noqa: E402
+
+warnings.filterwarnings('ignore')
+torch.set_grad_enabled(False)
+torch.set_num_threads(8)
+
+
+def build_reference(cfg):
+    net = DEVA(cfg).eval()
+    spec = [(k, tuple(v.shape), v.dtype) for k, v in net.state_dict().items()]
+    sd = weights.make_state_dict(spec, seed=0)
+    net.load_weights(sd)
+    return net, spec, sd
+
+
+def gen_spec(spec, sd):
+    h = hashlib.sha256()
+    for k, _, _ in spec:
+        h.update(k.encode())
+        h.update(sd[k].numpy().tobytes())
+    out = dict(sha256_seed0=h.hexdigest(),
+               tensors=[[k, list(s), str(d).replace('torch.', '')] for k, s, d in spec])
+    with open(os.path.join(HERE, 'state_dict_spec.json'), 'w') as f:
+        json.dump(out, f, indent=0)
+
+
+def gen_memory_ops():
+    """get_similarity / do_softmax(top_k, usage) / readout  (memory_utils.py:6-76,
+    memory_manager.py:64-75) plus the no-top-k softmax used by consolidation."""
+    cases = {}
+    for name, (n, hw, scale, seed) in {
+            'small_peaky': (300, 48, 1.0, 11),
+            'mid_flat': (1000, 100, 0.15, 12),     # flat similarities -> many near ties
+            'ragged': (77, 33, 0.5, 13),            # sizes that are not multiples of any tile
+    }.items():
+        mk, ms, qk, qe = synth.affinity_inputs(n, hw, seed=seed, key_scale=scale)
+        sim = MU.get_similarity(mk, ms, qk, qe, add_batch_dim=True)
+        vals, idx = torch.topk(sim, k=30, dim=1)
+        aff, usage = MU.do_softmax(sim.clone(), top_k=30, inplace=True, return_usage=True)
+        v = synth.value_inputs(2, 512, n, seed=seed)
+        mm = MemoryManager(synth.base_config())
+        ro = mm._readout(aff[0], v)
+        full = MU.do_softmax(sim)  # consolidation path
+        cases[name] = dict(n=n, hw=hw, scale=scale, seed=seed, sim=sim[0].clone(),
+                           topk_values=vals[0], topk_indices=idx[0].int(),
+                           usage=usage[0], readout=ro, full_softmax=full[0])
+    torch.save(cases, os.path.join(HERE, 'memory_ops.pt'))
+
+
+def gen_stages(net):
+    """Teacher-forced stage outputs at 96x128, 2 objects."""
+    H, W, no = 96, 128, 2
+    img = synth.FrameStream(H, W, seed=5).next().unsqueeze(0)
+    ms, feat = net.encode_image(img)
+    key, shr, sel = net.transform_key(feat)
+    masks, sensory, readout = synth.stage_inputs(H, W, no)
+    value, sens_deep = net.encode_mask(img, ms, sensory, masks, is_deep_update=True)
+    sens_seg, logits, prob = net.segment(ms, readout, sensory, masks)
+    out = dict(f16=ms[0], f8=ms[1], f4=ms[2], feat=feat, key=key, shrinkage=shr, selection=sel,
+               value=value, sensory_deep=sens_deep, sensory_seg=sens_seg, logits=logits, prob=prob)
+    torch.save({k: v.clone() for k, v in out.items()}, os.path.join(HERE, 'stages_96x128.pt'))
+
+
+def gen_e2e(net):
+    for name, sc in scenarios.E2E.items():
+        def make_core(cfg):
+            return DEVAInferenceCore(net, cfg)
+
+        outs, core = scenarios.run_scenario(make_core, sc)
+        mem = core.memory
+        sizes = dict(work={b: mem.work_mem.size(b) for b in mem.work_mem.buckets},
+                     long=({b: mem.long_mem.size(b) for b in mem.long_mem.buckets}
+                           if mem.use_long_term else {}))
+        # per-frame arrays: the channel count changes mid-clip when a second annotation arrives
+        np.savez_compressed(
+            os.path.join(HERE, f'e2e_{name}.npz'),
+            **{f'prob_sub_{t}': p[:, ::2, ::2].numpy() for t, p in enumerate(outs)},
+            argmax=np.stack([p.argmax(0).numpy().astype(np.uint8) for p in outs]),
+            nchan=np.array([p.shape[0] for p in outs]),
+            sizes=json.dumps(sizes))
+        print(name, 'frames', len(outs), 'sizes', sizes)
+
+
+def gen_vos_example(net):
+    """BASELINE config 1: example/vos bmx-trees, 4 frames 854x480, 2 objects, default flags.
+    Frames are stored decoded (uint8) so the GPU box needs neither the reference nor a JPEG codec
+    match; normalisation = ImageNet mean/std as deva/dataset/utils.py:8."""
+    from PIL import Image
+    base = os.path.join(REF, 'example', 'vos')
+    names = ['00000', '00001', '00002', '00003']
+    frames = np.stack([np.array(Image.open(os.path.join(base, 'JPEGImages', 'bmx-trees', n + '.jpg')).convert('RGB'))
+                       for n in names])
+    ann = np.array(Image.open(os.path.join(base, 'Annotations', 'bmx-trees', '00000.png')))
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+    cfg = synth.base_config(enable_long_term_count_usage=False)
+    core = DEVAInferenceCore(net, cfg)
+    labels = [int(x) for x in np.unique(ann) if x != 0]
+    outs = []
+    for t in range(len(names)):
+        img = (torch.from_numpy(frames[t]).permute(2, 0, 1).float() / 255 - mean) / std
+        if t == 0:
+            p = core.step(img, torch.from_numpy(ann.astype(np.int64)), labels, end=False)
+        else:
+            p = core.step(img, end=(t == len(names) - 1))
+        outs.append(p)
+    np.savez_compressed(os.path.join(HERE, 'e2e_vos_example.npz'), frames=frames, annotation=ann,
+                        labels=np.array(labels),
+                        prob_sub=np.stack([p[:, ::4, ::4].numpy() for p in outs]).astype(np.float32),
+                        argmax=np.stack([p.argmax(0).numpy().astype(np.uint8) for p in outs]))
+    print('vos example labels', labels, [tuple(p.shape) for p in outs])
+
+
+if __name__ == '__main__':
+    cfg = synth.base_config()
+    net, spec, sd = build_reference(cfg)
+    gen_spec(spec, sd)
+    gen_memory_ops()
+    gen_stages(net)
+    gen_e2e(net)
+    gen_vos_example(net)
+    for f in sorted(os.listdir(HERE)):
+        print(f, os.path.getsize(os.path.join(HERE, f)))
