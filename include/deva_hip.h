@@ -1,0 +1,211 @@
+/*
+ * deva_hip.h -- C ABI of libdeva_hip.so: the MI355X (gfx950) kernels behind DEVA's per-frame
+ * temporal-propagation path.
+ *
+ * The reference (hkchengrex/Tracking-Anything-with-DEVA) is pure Python/PyTorch and has no FFI;
+ * each entry point below states the reference code (file:line under the reference root) whose
+ * arithmetic it replaces.  The Python host side that mirrors the reference's module interface
+ * (tracking-anything-with-deva_amd/deva/...) binds these symbols with ctypes; INTEGRATION.md shows
+ * the binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 unless stated otherwise;
+ *   - activations are NCHW, exactly as the reference passes them;
+ *   - memory banks are TOKEN-MAJOR arenas: row n holds the C channels of memory token n
+ *     (the reference keeps [C, N] tensors and re-allocates them on every append,
+ *     kv_memory_store.py:97-116);
+ *   - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream);
+ *   - no entry point allocates, frees or synchronises; all work is stream-ordered;
+ *   - return value 0 = ok, non-zero = error, text via deva_hip_last_error().
+ */
+#ifndef DEVA_HIP_H
+#define DEVA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DEVA_HIP_ABI_VERSION 1
+
+int deva_hip_version(void);
+const char* deva_hip_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution as implicit GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32), fused prologue/epilogue.
+ * Replaces every nn.Conv2d / GConv2D call of the path (big_modules.py:42-51,103-113,164-201;
+ * modules.py:19-38,73-78,135-169; group_modules.py:41-67; resnet.py:46-114) with eval-mode
+ * BatchNorm folded into the packed weights.
+ *
+ * Input  = virtual channel-concat of up to two NCHW tensors (replaces torch.cat in
+ *          group_modules.py:119-121, modules.py:139,163, big_modules.py:180), each with its own
+ *          batch stride (0 = broadcast over the batch, replaces .expand()).
+ * Weight = packed [KH*KW][C0+C1][cout_pad] (tap-major, cout contiguous, cout_pad = cout rounded
+ *          up to 32, zero filled).
+ * out[b][m][oh][ow] = act( sum_k W[k][m] * in(k, b, oh, ow) + bias[m] + residual ) */
+enum {
+  DEVA_ACT_NONE = 0,
+  DEVA_ACT_RELU = 1,
+  DEVA_ACT_SIGMOID = 2,
+  DEVA_ACT_SQUARE_PLUS_ONE = 3 /* x*x+1: shrinkage head, modules.py:75 */
+};
+
+typedef struct deva_conv_desc {
+  const float* in0;
+  const float* in1; /* may be NULL when c1 == 0 */
+  int64_t in0_batch_stride; /* elements; 0 broadcasts in0 over the batch */
+  int64_t in1_batch_stride;
+  int32_t c0, c1;
+  int32_t batch, height, width; /* input spatial size */
+  const float* weight; /* packed, see above */
+  const float* bias;   /* [cout] or NULL */
+  int32_t cout, cout_pad;
+  int32_t kh, kw, stride, pad;
+  int32_t relu_in; /* apply max(x,0) to the inputs while loading (F.relu before the conv) */
+  const float* residual; /* [batch or 1][cout][OH][OW] or NULL, added before the activation */
+  int64_t residual_batch_stride; /* elements; 0 broadcasts */
+  int32_t act;
+  float* out; /* [batch][cout][OH][OW] */
+} deva_conv_desc;
+
+int deva_conv2d(const deva_conv_desc* desc, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Pooling / resampling / pointwise blocks */
+
+/* nn.MaxPool2d(3, stride 2, pad 1) (resnet.py:122), optional fused ReLU after the pool
+ * (MaskEncoder order, big_modules.py:107-110).  in [planes][H][W] -> out [planes][OH][OW]. */
+int deva_maxpool3x3s2(const float* in, float* out, int64_t planes, int height, int width,
+                      int relu_after, void* stream);
+
+/* F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) over [batch][C][h][w]
+ * (group_modules.py:26-30) fused with the broadcast skip add of MaskUpsampleBlock
+ * (modules.py:88-92): out = skip[c] + up(in[b][c]); skip is [C][2h][2w] or NULL. */
+int deva_upsample2x_add(const float* in, const float* skip, float* out, int batch, int channels,
+                        int height, int width, void* stream);
+
+/* F.interpolate(mode='area') for an integer shrink factor (network.py:117,
+ * group_modules.py:33-38): mean over factor x factor boxes.  in [planes][H][W]. */
+int deva_area_downsample(const float* in, float* out, int64_t planes, int height, int width,
+                         int factor, void* stream);
+
+/* DEVA.aggregate (network.py:33-40) over `num` object planes of `pixels` each:
+ * p = apply_sigmoid ? sigmoid(in) : in;  out[0] = logit(clamp(prod(1-p)));  out[i+1] = logit(clamp(p_i)).
+ * in may be fp32 or (in_is_u8 != 0) uint8/bool one-hot planes (inference_core.py:273-277). */
+int deva_aggregate(const void* in, int in_is_u8, int apply_sigmoid, float* out, int num,
+                   int64_t pixels, void* stream);
+
+/* softmax over the channel axis of [channels][pixels] (inference_core.py:279) */
+int deva_softmax_channels(const float* in, float* out, int channels, int64_t pixels, void* stream);
+
+/* network.py:167-168: x4 bilinear upsample (align_corners=False) of [channels][h][w] logits and
+ * the channel softmax, one pass.  Writes both logits_up and prob ([channels][4h][4w]). */
+int deva_upsample4x_softmax(const float* in, float* logits_up, float* prob, int channels,
+                            int height, int width, void* stream);
+
+/* CBAM (cbam.py:21-76) on x [batch][C][hw], three small kernels + the fused apply.
+ *  (1) global average and max per (b,c) plane;
+ *  (2) scale = sigmoid(mlp(avg) + mlp(max)), mlp = Linear(C,hidden) -> ReLU -> Linear(hidden,C);
+ *  (3) pooled[b][0] = max_c(x*scale), pooled[b][1] = mean_c(x*scale)   (ChannelPool)
+ *  (4) after the 7x7 gate conv (deva_conv2d):  out = x + (x*scale)*sigmoid(gate)
+ *      -- the "+ x" is the g + r of group_modules.py:149 fused in. */
+int deva_global_avgmax(const float* x, float* avg, float* mx, int64_t planes, int hw, void* stream);
+int deva_cbam_mlp(const float* avg, const float* mx, const float* w1, const float* b1,
+                  const float* w2, const float* b2, float* scale, int batch, int channels,
+                  int hidden, void* stream);
+int deva_cbam_channel_pool(const float* x, const float* scale, float* pooled, int batch,
+                           int channels, int hw, void* stream);
+int deva_cbam_apply(const float* x, const float* scale, const float* gate, float* out, int batch,
+                    int channels, int hw, void* stream);
+
+/* GRU-style sensory update (modules.py:141-149,162-169): values [batch][3C][hw], h [batch][C][hw]
+ * new_h = sig(v[:C]) * h * (1 - sig(v[C:2C])) + sig(v[C:2C]) * tanh(v[2C:]). */
+int deva_gru_update(const float* values, const float* h, float* new_h, int batch, int channels,
+                    int hw, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Memory read: anisotropic-L2 similarity -> top-k -> softmax (-> usage), nothing materialised.
+ * Replaces get_similarity + do_softmax(top_k, inplace, return_usage) (memory_utils.py:6-76) as
+ * called from MemoryManager.match_memory (memory_manager.py:106-152).
+ *
+ * The bank is the virtual concatenation of two token-major segments (long-term rows first, then
+ * working rows: memory_manager.py:110-113 without the torch.cat): keys [n][64], shrinkage [n].
+ * Queries are channel-major as produced by transform_key: qk, qe [64][hw].
+ *
+ * Step 1 (deva_affinity_topk): grid = query tiles x `splits` token ranges; every wave keeps the
+ *   exact top-k of its range for 32 queries and writes them as sorted 64-bit keys
+ *   (order-preserving score bits << 32 | ~token index) to part_keys [splits][hw][k].
+ * Step 2 (deva_affinity_finalize): merges the `splits` sorted lists per query, w = exp(v)/sum exp(v)
+ *   (NO max subtraction, memory_utils.py:59-60), writes idx/w [hw][k] sorted by descending score
+ *   and, if usage_fix != NULL, adds w * 2^40 to usage_fix[token] (uint64 fixed point: integer
+ *   atomics make the usage sum order-independent, hence deterministic).
+ * Total order used for ties: higher score first, then lower token index.
+ * Requires CK == 64, 1 <= k <= 32, n_long + n_work >= k, 1 <= splits <= 64. */
+int deva_affinity_topk(const float* key_long, const float* shr_long, int n_long,
+                       const float* key_work, const float* shr_work, int n_work,
+                       const float* qk, const float* qe, int hw, int k, int splits,
+                       uint64_t* part_keys, void* stream);
+int deva_affinity_finalize(const uint64_t* part_keys, int hw, int k, int splits, int32_t* idx,
+                           float* weight, uint64_t* usage_fix, void* stream);
+/* workspace query: number of uint64 elements part_keys must hold */
+int64_t deva_affinity_workspace(int hw, int k, int splits);
+/* splits the library would pick for a bank/query size (>= 1) */
+int deva_affinity_default_splits(int n_total, int hw);
+
+/* KeyValueMemoryStore.update_bucket_usage (kv_memory_store.py:118-125) for one segment:
+ * use[i] += usage_fix[offset+i] * 2^-40 (if use != NULL), life[i] += 1 (if life != NULL), and
+ * usage_fix[offset .. offset+n) is zeroed for the next frame. */
+int deva_usage_update(uint64_t* usage_fix, int64_t offset, float* use, float* life, int n,
+                      void* stream);
+
+/* MemoryManager._readout (memory_manager.py:64-75) in sparse form, one object per call:
+ * out[c][q] = sum_j weight[q][j] * value(idx[q][j])[c], value rows token-major [n][cv] in the
+ * same long-then-work index space.  out is [cv][hw] (an NCHW plane stack). */
+int deva_readout_sparse(const int32_t* idx, const float* weight, int hw, int k,
+                        const float* val_long, int n_long, const float* val_work, int cv,
+                        float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Bank maintenance (KeyValueMemoryStore.add / sieve_by_range / remove_obsolete_features,
+ * kv_memory_store.py:35-185; MemoryManager.consolidation, memory_manager.py:251-276). */
+
+/* append one frame: src channel-major [channels][count] -> rows dst_row0.. of a token-major arena */
+int deva_bank_append(const float* src, float* arena, int64_t dst_row0, int channels, int count,
+                     void* stream);
+/* dst[i][:] = src[rows[i]][:] (rows = int32 device array, NULL = identity/contiguous copy) */
+int deva_bank_gather_rows(const float* src, const int32_t* rows, float* dst, int count,
+                          int channels, void* stream);
+/* token-major rows -> channel-major [channels][count] (for API views of the bank) */
+int deva_bank_export(const float* arena, float* dst, int channels, int count, void* stream);
+
+/* rank[i] = position of x[i] in the order (descending ? larger first : smaller first), ties by
+ * lower index first; a permutation of 0..n-1.  If use/life given (life != NULL) x = use/life
+ * (KeyValueMemoryStore.get_usage, kv_memory_store.py:187-192) is computed on the fly and also
+ * written to x_out when non-NULL. */
+int deva_rank(const float* x, const float* life, float* x_out, int n, int descending,
+              int32_t* rank, void* stream);
+/* topk via ranks: out_idx[rank[i]] = i for rank[i] < k  (torch.topk(..., sorted=True)) */
+int deva_rank_select(const int32_t* rank, int n, int k, int32_t* out_idx, void* stream);
+/* eviction (kv_memory_store.py:170-174): with ascending ranks, thr = x at rank n_remove-1;
+ * survivors = x > thr.  Writes survivor row indices in order to out_idx and their number to
+ * out_count[0] (device int32). */
+int deva_evict_select(const float* x, const int32_t* rank_asc, int n, int n_remove,
+                      int32_t* out_idx, int32_t* out_count, void* stream);
+
+/* consolidation, potentiation step: dense similarity of all candidates against the prototypes
+ * (queries = prototype key + its stored selection, rows proto_idx of the candidate arrays):
+ * sim[n*ld + p], token-major candidates key/sel [n_cand][64], shr [n_cand]. */
+int deva_similarity_dense(const float* key, const float* shr, const float* sel,
+                          const int32_t* proto_idx, int n_cand, int n_proto, int ld, float* sim,
+                          void* stream);
+/* do_softmax without top-k (memory_utils.py:67-70): softmax over rows n of each column of
+ * x[n][ld] (first p columns), in place.  With ld = p rounded up to 32 and zero pad columns the
+ * result is directly the packed "weight" of a 1x1 deva_conv2d, which performs the prototype
+ * value / shrinkage readout (memory_manager.py:270-274) as a GEMM on the matrix cores. */
+int deva_softmax_columns(float* x, int n, int p, int ld, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEVA_HIP_H */

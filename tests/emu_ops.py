@@ -1,0 +1,217 @@
+"""TEST-ONLY stand-ins for `deva.hip.ops` written with plain PyTorch on the CPU.
+
+The build container has no GPU, so the host-side logic of the package (weight packing, BN folding,
+graph wiring, arena bookkeeping, the frame state machine) is exercised on the CPU by
+monkeypatching these functions over the ctypes wrappers.  They define, in executable form, the
+contract each HIP kernel must meet; the `-m gpu` tests then hold the real kernels to the same
+oracle.  Nothing here is reachable from the product package.
+"""
+import torch
+import torch.nn.functional as F
+
+from deva.hip import ops as real
+from deva.hip.ops import PackedConv
+
+TWO40 = float(2**40)
+_real_pack_conv = real.pack_conv
+
+
+def require_hip(device, what):  # the emulation runs on the CPU
+    return None
+
+
+def pack_conv(weight, bias=None, bn=None, device=None):
+    return _real_pack_conv(weight, bias, bn, None)
+
+
+def _unpack(pc: PackedConv):
+    return pc.weight[:, :pc.cout].reshape(pc.kh, pc.kw, pc.cin, pc.cout).permute(3, 2, 0, 1).contiguous()
+
+
+def _act(y, act):
+    if act == real.ACT_RELU:
+        return F.relu(y)
+    if act == real.ACT_SIGMOID:
+        return torch.sigmoid(y)
+    if act == real.ACT_SQUARE_PLUS_ONE:
+        return y * y + 1
+    return y
+
+
+def conv2d(pc, x0, x1=None, *, stride=1, pad=0, relu_in=False, residual=None, act=real.ACT_NONE, out=None):
+    batch = max(x0.shape[0], 1 if x1 is None else x1.shape[0], 1 if residual is None else residual.shape[0])
+    xs = [x0.expand(batch, -1, -1, -1)]
+    if x1 is not None:
+        xs.append(x1.expand(batch, -1, -1, -1))
+    x = torch.cat(xs, 1)
+    assert x.shape[1] == pc.cin
+    if relu_in:
+        x = F.relu(x)
+    y = F.conv2d(x, _unpack(pc), pc.bias, stride=stride, padding=pad)
+    if residual is not None:
+        y = y + residual
+    y = _act(y, act)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def maxpool3x3s2(x, relu_after=False):
+    y = F.max_pool2d(x, 3, 2, 1)
+    return F.relu(y) if relu_after else y
+
+
+def upsample2x_add(x, skip):
+    y = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
+    return y if skip is None else skip + y
+
+
+def area_downsample(x, factor):
+    lead = x.shape[:-2]
+    y = F.avg_pool2d(x.reshape(1, -1, *x.shape[-2:]), factor)
+    return y.reshape(*lead, *y.shape[-2:])
+
+
+def aggregate(prob, apply_sigmoid=False):
+    p = prob.float()
+    if apply_sigmoid:
+        p = torch.sigmoid(p)
+    full = torch.cat([torch.prod(1 - p, dim=0, keepdim=True), p], 0).clamp(1e-7, 1 - 1e-7)
+    return torch.log(full / (1 - full))
+
+
+def softmax_channels(x):
+    return torch.softmax(x, dim=0)
+
+
+def upsample4x_softmax(logits, need_logits=True):
+    up = F.interpolate(logits.unsqueeze(0), scale_factor=4, mode='bilinear', align_corners=False)[0]
+    return (up if need_logits else None), torch.softmax(up, dim=0)
+
+
+def cbam(x, w1, b1, w2, b2, spatial):
+    hw = x.shape[-2:]
+
+    def mlp(v):
+        return F.linear(F.relu(F.linear(v, w1, b1)), w2, b2)
+
+    att = mlp(F.avg_pool2d(x, hw).flatten(1)) + mlp(F.max_pool2d(x, hw).flatten(1))
+    xs = x * torch.sigmoid(att)[:, :, None, None]
+    pooled = torch.cat([xs.max(1, keepdim=True)[0], xs.mean(1, keepdim=True)], 1)
+    gate = conv2d(spatial, pooled, pad=spatial.kh // 2)
+    return x + xs * torch.sigmoid(gate)
+
+
+def gru_update(values, h):
+    c = h.shape[1]
+    f, u, n = torch.sigmoid(values[:, :c]), torch.sigmoid(values[:, c:2 * c]), torch.tanh(values[:, 2 * c:])
+    return f * h * (1 - u) + u * n
+
+
+def _bank(key_long, n_long, key_work, n_work):
+    parts = []
+    if n_long:
+        parts.append(key_long[:n_long])
+    if n_work:
+        parts.append(key_work[:n_work])
+    return torch.cat(parts, 0)
+
+
+def affinity_topk(key_long, shr_long, n_long, key_work, shr_work, n_work, qk, qe, k, usage_fix=None,
+                  splits=None):
+    mk = _bank(key_long, n_long, key_work, n_work)          # [N,64] token-major
+    ms = _bank(shr_long, n_long, shr_work, n_work)          # [N]
+    if mk.shape[0] < k:
+        raise real.DevaHipError('selected index k out of range')
+    a_sq = mk.pow(2) @ qe
+    two_ab = 2 * (mk @ (qk * qe))
+    b_sq = (qe * qk.pow(2)).sum(0, keepdim=True)
+    sim = (-a_sq + two_ab - b_sq) * ms[:, None] / 8.0
+    vals, idx = torch.topk(sim, k=k, dim=0)                  # [k,hw]
+    w = vals.exp()
+    w = w / w.sum(0, keepdim=True)
+    idx, w = idx.t().contiguous(), w.t().contiguous()
+    if usage_fix is not None:
+        usage_fix.index_add_(0, idx.reshape(-1), (w.reshape(-1).double() * TWO40).long())
+    return idx.int(), w
+
+
+def usage_update(usage_fix, offset, use, life, n):
+    seg = usage_fix[offset:offset + n]
+    if use is not None:
+        use[:n] += (seg.double() / TWO40).float()
+    if life is not None:
+        life[:n] += 1
+    seg.zero_()
+
+
+def readout_sparse(idx, weight, val_long, n_long, val_work, out):
+    hw, k = idx.shape
+    cv = out.shape[0]
+    n_work_needed = int(idx.max().item()) + 1 - n_long
+    vals = _bank(val_long, n_long, val_work, max(n_work_needed, 0))
+    g = vals[idx.long().reshape(-1)].reshape(hw, k, cv)
+    out.copy_((g * weight[:, :, None]).sum(1).t().reshape(out.shape))
+    return out
+
+
+def bank_append(src, arena, row0):
+    arena[row0:row0 + src.shape[1]] = src.t()
+
+
+def bank_gather_rows(src, rows, dst, count):
+    dst[:count] = src[:count] if rows is None else src[rows[:count].long()]
+
+
+def bank_export(arena, n):
+    return arena[:n].t().contiguous()
+
+
+def rank(x, n, descending, life=None):
+    v = x[:n] / life[:n] if life is not None else x[:n]
+    order = torch.sort(v, descending=descending, stable=True)[1]
+    r = torch.empty(n, dtype=torch.int32)
+    r[order] = torch.arange(n, dtype=torch.int32)
+    return r, (v.clone() if life is not None else None)
+
+
+def rank_select(rank_t, k):
+    out = torch.empty(k, dtype=torch.int32)
+    sel = rank_t < k
+    out[rank_t[sel].long()] = torch.nonzero(sel).flatten().int()
+    return out
+
+
+def evict_select(x, rank_asc, n_remove):
+    n = rank_asc.numel()
+    thr = x[:n][rank_asc == n_remove - 1][0]
+    keep = torch.nonzero(x[:n] > thr).flatten().int()
+    idx = torch.zeros(n, dtype=torch.int32)
+    idx[:keep.numel()] = keep
+    return idx, torch.tensor([keep.numel()], dtype=torch.int32)
+
+
+def similarity_dense(key, shr, sel, proto_idx, n_cand):
+    p = proto_idx.numel()
+    ld = (p + 31) // 32 * 32
+    mk = key[:n_cand]
+    qk, qe = key[proto_idx.long()].t(), sel[proto_idx.long()].t()   # [64,P]
+    a_sq = mk.pow(2) @ qe
+    two_ab = 2 * (mk @ (qk * qe))
+    b_sq = (qe * qk.pow(2)).sum(0, keepdim=True)
+    sim = torch.zeros(n_cand, ld)
+    sim[:, :p] = (-a_sq + two_ab - b_sq) * shr[:n_cand, None] / 8.0
+    return sim
+
+
+def softmax_columns(x, p):
+    x[:, :p] = torch.softmax(x[:, :p], dim=0)
+    return x
+
+
+def install(monkeypatch):
+    """patch every public op of deva.hip.ops with its emulation"""
+    for name in real.__all__ + ['require_hip']:
+        if name in globals() and callable(globals()[name]) and name not in ('PackedConv',):
+            monkeypatch.setattr(real, name, globals()[name])

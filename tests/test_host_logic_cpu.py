@@ -1,0 +1,119 @@
+"""Host-side logic of the package on the CPU: the HIP ops are replaced by the PyTorch emulation of
+tests/emu_ops.py, so these tests check weight packing / BN folding, graph wiring, the arena-based
+memory stores and the frame state machine against the oracle and the reference's golden vectors.
+The kernels themselves are tested on the GPU (tests/test_gpu_*.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import emu_ops
+import scenarios
+from oracle import deva_oracle as O
+from oracle import synth
+
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture()
+def emu(monkeypatch):
+    emu_ops.install(monkeypatch)
+
+
+def _network(recipe_state_dict):
+    from deva.model.network import DEVA
+    sd, _ = recipe_state_dict
+    net = DEVA(synth.base_config())
+    net.load_weights(sd)
+    return net
+
+
+def test_state_dict_is_checkpoint_compatible(recipe_state_dict):
+    from deva.model.network import DEVA
+    _, spec = recipe_state_dict
+    mine = {k: (list(v.shape), str(v.dtype).replace('torch.', '')) for k, v in DEVA(synth.base_config()).state_dict().items()}
+    ref = {k: (s, d) for k, s, d in spec['tensors']}
+    assert mine == ref
+
+
+def test_stages_match_reference(emu, golden_dir, recipe_state_dict):
+    net = _network(recipe_state_dict)
+    g = torch.load(os.path.join(golden_dir, 'stages_96x128.pt'))
+    H, W, no = 96, 128, 2
+    img = synth.FrameStream(H, W, seed=5).next().unsqueeze(0)
+    ms, feat = net.encode_image(img)
+    key, shr, sel = net.transform_key(feat)
+    masks, sensory, readout = synth.stage_inputs(H, W, no)
+    value, sens_deep = net.encode_mask(img, ms, sensory, masks)
+    sens_seg, logits, prob = net.segment(ms, readout, sensory, masks)
+    got = dict(f16=ms[0], f8=ms[1], f4=ms[2], feat=feat, key=key, shrinkage=shr, selection=sel,
+               value=value, sensory_deep=sens_deep, sensory_seg=sens_seg, logits=logits, prob=prob)
+    for k, v in got.items():
+        assert v.shape == g[k].shape, k
+        err = (v - g[k]).abs().max().item()
+        assert err <= 2e-4 * max(1.0, g[k].abs().max().item()), (k, err)
+
+
+def test_chunked_objects_equal_joint(emu, recipe_state_dict):
+    net = _network(recipe_state_dict)
+    H, W, no = 64, 96, 3
+    img = synth.FrameStream(H, W, seed=6).next().unsqueeze(0)
+    ms, feat = net.encode_image(img)
+    masks, sensory, readout = synth.stage_inputs(H, W, no)
+    a = net.segment(ms, readout, sensory, masks)
+    b = net.segment(ms, readout, sensory, masks, chunk_size=2)
+    for x, y in zip(a, b):
+        assert torch.allclose(x, y, atol=1e-5)
+    va, sa = net.encode_mask(img, ms, sensory, masks)
+    vb, sb = net.encode_mask(img, ms, sensory, masks, chunk_size=1)
+    assert torch.allclose(va, vb, atol=1e-5) and torch.allclose(sa, sb, atol=1e-5)
+
+
+@pytest.mark.parametrize('name', list(scenarios.E2E))
+def test_e2e_matches_reference(emu, golden_dir, recipe_state_dict, name):
+    from deva.inference.inference_core import DEVAInferenceCore
+    net = _network(recipe_state_dict)
+    sc = scenarios.E2E[name]
+    outs, core = scenarios.run_scenario(lambda cfg: DEVAInferenceCore(net, cfg), sc)
+    g = np.load(os.path.join(golden_dir, f'e2e_{name}.npz'))
+    assert [p.shape[0] for p in outs] == g['nchan'].tolist()
+    sizes = json.loads(str(g['sizes']))
+    mem = core.memory
+    assert {str(b): mem.work_mem.size(b) for b in mem.work_mem.buckets} == sizes['work']
+    if mem.use_long_term:
+        assert {str(b): mem.long_mem.size(b) for b in mem.long_mem.buckets} == sizes['long']
+    worst = max(np.abs(p[:, ::2, ::2].numpy() - g[f'prob_sub_{t}']).max() for t, p in enumerate(outs))
+    assert worst <= 2e-3, (name, worst)
+
+
+def test_store_views_follow_reference_layout(emu):
+    from deva.inference.kv_memory_store import KeyValueMemoryStore
+    st = KeyValueMemoryStore(save_selection=True, save_usage=True)
+    g = torch.Generator().manual_seed(0)
+    k1, s1, e1 = torch.randn(64, 10, generator=g), torch.rand(1, 10, generator=g), torch.rand(64, 10, generator=g)
+    v1 = {3: torch.randn(8, 10, generator=g), 7: torch.randn(8, 10, generator=g)}
+    st.add(k1, v1, s1, e1)
+    k2, s2, e2 = torch.randn(64, 6, generator=g), torch.rand(1, 6, generator=g), torch.rand(64, 6, generator=g)
+    v2 = {3: torch.randn(8, 6, generator=g), 7: torch.randn(8, 6, generator=g), 9: torch.randn(8, 6, generator=g)}
+    st.add(k2, v2, s2, e2)
+    assert st.buckets == {0: [3, 7], 1: [9]}
+    assert torch.equal(st.key[0], torch.cat([k1, k2], 1)) and torch.equal(st.key[1], k2)
+    assert torch.equal(st.value[7], torch.cat([v1[7], v2[7]], 1)) and torch.equal(st.value[9], v2[9])
+    assert torch.equal(st.shrinkage[0], torch.cat([s1, s2], 1))
+    assert torch.equal(st.selection[1], e2)
+    st.sieve_by_range(0, 2, -4, min_size=3)
+    keep = list(range(0, 2)) + list(range(12, 16))
+    assert torch.equal(st.key[0], torch.cat([k1, k2], 1)[:, keep])
+    assert torch.equal(st.value[3], torch.cat([v1[3], v2[3]], 1)[:, keep])
+    st.purge_except([9])
+    assert st.buckets == {1: [9]} and st.num_objects == 1 and not st.engaged(0)
+
+
+def test_no_cpu_fallback_in_product(recipe_state_dict):
+    """without the emulation the package must refuse to run on the CPU (no silent fallback)"""
+    from deva.hip import DevaHipError
+    net = _network(recipe_state_dict)
+    with pytest.raises(DevaHipError):
+        net.encode_image(torch.zeros(1, 3, 32, 32))

@@ -1,0 +1,405 @@
+// Memory read of DEVA on gfx950: anisotropic-L2 similarity -> exact top-k -> softmax (-> usage),
+// fused so that the N x HW similarity matrix is never written (the reference materialises it
+// ~12 times per frame, memory_utils.py:29-74).
+//
+// Similarity (memory_utils.py:29-43), per memory token n and query q:
+//     A = sum_c mk[n][c]^2 * qe[c][q]          B = sum_c mk[n][c] * (qk[c][q]*qe[c][q])
+//     sim = ((-A + 2B) - bsq[q]) * ms[n] / sqrt(64)
+// A and B run on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32 FMA chains) with the
+// channels in natural order, each in its own accumulator and combined in the reference's order, so
+// the scores agree with an fp32 FMA GEMM to the last bits -- top-k is discontinuous, a 1e-5
+// relative error flips memory tokens in and out of the softmax support.
+//
+// Work decomposition: one wave owns 32 queries (the MFMA N dimension) and streams a range of
+// memory tokens in tiles of 32 (the MFMA M dimension); the query operand lives in registers for
+// the whole kernel, the key rows are read straight from the token-major bank (a 32x64 fp32 tile
+// per 8192 matrix-pipe cycles -- operand traffic is irrelevant here, the kernel is bound by the
+// fp32 MFMA rate).  Per query the wave keeps a candidate list in LDS: scores >= the running k-th
+// best are appended (rare once the threshold has settled: ~k*ln(N/k) appends per query in total),
+// and when a list could overflow it is pruned back to the best k by rank counting.
+// grid.y splits the bank into token ranges so small frames still fill 256 CUs; a second kernel
+// merges the per-range lists, applies exp/normalise and accumulates the usage counters.
+#include <math.h>
+
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace deva {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int CK = 64;
+constexpr int QT = 32;            // queries per wave
+constexpr int CAP = 64;           // candidate slots per query
+constexpr int STRIDE = CAP + 1;   // padded row (uint64 entries) to spread LDS banks
+constexpr int WAVES = 4;
+constexpr int TOKT = 32;          // tokens per tile
+
+__device__ __forceinline__ uint32_t orderable(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float from_orderable(uint32_t o) {
+  const uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  return __uint_as_float(u);
+}
+// larger key = better candidate: higher score first, then lower token index
+__device__ __forceinline__ uint64_t make_key(float score, uint32_t token) {
+  return ((uint64_t)orderable(score) << 32) | (uint64_t)(~token);
+}
+
+#define DEVA_COMPILER_FENCE() asm volatile("" ::: "memory")
+
+struct AffArgs {
+  const float* key_long;
+  const float* shr_long;
+  int n_long;
+  const float* key_work;
+  const float* shr_work;
+  int n_total;
+  const float* qk;
+  const float* qe;
+  int hw;
+  int k;
+  int splits;
+  int tiles_per_split;
+  int total_tiles;
+  uint64_t* part;
+};
+
+__global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs p) {
+  __shared__ uint64_t s_cand[WAVES][QT][STRIDE];
+  __shared__ uint32_t s_cnt[WAVES][QT];
+  __shared__ float s_tau[WAVES][QT];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int l31 = lane & 31;
+  const int half = lane >> 5;
+  const int q0 = (blockIdx.x * WAVES + wave) * QT;
+  if (q0 >= p.hw) return;  // whole wave idle (no block-level barrier is used in this kernel)
+  const int split = blockIdx.y;
+
+  volatile uint64_t* cand = &s_cand[wave][0][0];
+  volatile uint32_t* cnt = &s_cnt[wave][0];
+  volatile float* tau = &s_tau[wave][0];
+
+  if (lane < QT) {
+    cnt[lane] = 0;
+    tau[lane] = -INFINITY;
+  }
+  DEVA_COMPILER_FENCE();
+
+  // ---- query operand (registers, whole kernel).  MFMA t consumes channels 2t (lanes 0-31) and
+  // 2t+1 (lanes 32-63): natural channel order in the accumulation chain.
+  const int q = min(q0 + l31, p.hw - 1);
+  float bqe[CK / 2], bqk[CK / 2];
+  // bsq = sum_c qe*qk^2 in the order ATen's CPU sum uses for this reduction (four 16-channel
+  // partial sums, then ((s0+s1)+s2)+s3) -- probed bit-equal on >99% of queries
+  float bs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int t = 0; t < CK / 2; ++t) {
+    const float e0 = p.qe[(int64_t)(2 * t) * p.hw + q], e1 = p.qe[(int64_t)(2 * t + 1) * p.hw + q];
+    const float k0 = p.qk[(int64_t)(2 * t) * p.hw + q], k1 = p.qk[(int64_t)(2 * t + 1) * p.hw + q];
+    bs[t >> 3] += e0 * (k0 * k0);
+    bs[t >> 3] += e1 * (k1 * k1);
+    bqe[t] = half ? e1 : e0;
+    bqk[t] = half ? (k1 * e1) : (k0 * e0);
+  }
+  const float bsq = ((bs[0] + bs[1]) + bs[2]) + bs[3];
+
+  const int t_begin = split * p.tiles_per_split;
+  const int t_end = min(p.total_tiles, t_begin + p.tiles_per_split);
+
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int n_base = tile * TOKT;
+
+    // ---- prune lists that could overflow during this tile (at most 32 appends per query per tile)
+    {
+      const uint32_t c_mine = cnt[l31];
+      uint64_t need = __ballot(c_mine > (uint32_t)(CAP - TOKT)) & 0xffffffffull;
+      while (need) {
+        const int qq = __ffsll((unsigned long long)need) - 1;
+        need &= need - 1;
+        const uint32_t c = cnt[qq];
+        volatile uint64_t* row = cand + qq * STRIDE;
+        const uint64_t mine = ((uint32_t)lane < c) ? row[lane] : 0ull;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < c; ++j) rank += (row[j] > mine) ? 1u : 0u;
+        DEVA_COMPILER_FENCE();
+        if ((uint32_t)lane < c && rank < (uint32_t)p.k) row[rank] = mine;
+        if ((uint32_t)lane < c && c >= (uint32_t)p.k && rank == (uint32_t)p.k - 1)
+          tau[qq] = from_orderable((uint32_t)(mine >> 32));
+        if (lane == 0) cnt[qq] = min(c, (uint32_t)p.k);
+        DEVA_COMPILER_FENCE();
+      }
+    }
+    const float tau_l = tau[l31];
+
+    // ---- key tile: lane (l31, half) reads the whole 256-B row of token n_base + l31
+    const int n_mine = min(n_base + l31, p.n_total - 1);
+    const float* krow = (n_mine < p.n_long) ? (p.key_long + (int64_t)n_mine * CK)
+                                            : (p.key_work + (int64_t)(n_mine - p.n_long) * CK);
+    const float ms_mine = (n_mine < p.n_long) ? p.shr_long[n_mine] : p.shr_work[n_mine - p.n_long];
+    float4 x[CK / 4];
+#pragma unroll
+    for (int j = 0; j < CK / 4; ++j) x[j] = reinterpret_cast<const float4*>(krow)[j];
+
+    f32x16 accA, accB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      accA[r] = 0.0f;
+      accB[r] = 0.0f;
+    }
+#pragma unroll
+    for (int t = 0; t < CK / 2; ++t) {
+      // channel 2t + half of this lane's token
+      const float4 v = x[t >> 1];
+      const float lo = (t & 1) ? v.z : v.x;
+      const float hi = (t & 1) ? v.w : v.y;
+      const float a = half ? hi : lo;
+      accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a * a, bqe[t], accA, 0, 0, 0);
+      accB = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bqk[t], accB, 0, 0, 0);
+    }
+
+    // ---- scores of this lane: query l31, tokens n_base + (r&3) + 8*(r>>2) + 4*half
+    uint32_t pass = 0;
+    float sc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float ms = __shfl(ms_mine, j);
+      float v = (-accA[r] + 2.0f * accB[r]) - bsq;
+      v = v * ms * 0.125f;
+      sc[r] = v;
+      const bool ok = (n_base + j < p.n_total) && (v >= tau_l);
+      pass |= ok ? (1u << r) : 0u;
+    }
+    const int np = __popc(pass);
+    if (np) {
+      uint32_t pos = __hip_atomic_fetch_add((uint32_t*)&s_cnt[wave][l31], (uint32_t)np, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_WORKGROUP);
+      volatile uint64_t* row = cand + l31 * STRIDE;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (pass & (1u << r)) {
+          const int j = (r & 3) + 8 * (r >> 2) + 4 * half;
+          row[pos++] = make_key(sc[r], (uint32_t)(n_base + j));
+        }
+      }
+    }
+    DEVA_COMPILER_FENCE();
+  }
+
+  // ---- final prune of every list, then the sorted best-k of this range go to global memory
+  for (int qq = 0; qq < QT; ++qq) {
+    const uint32_t c = cnt[qq];
+    volatile uint64_t* row = cand + qq * STRIDE;
+    const uint64_t mine = ((uint32_t)lane < c) ? row[lane] : 0ull;
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < c; ++j) rank += (row[j] > mine) ? 1u : 0u;
+    DEVA_COMPILER_FENCE();
+    if ((uint32_t)lane < c && rank < (uint32_t)p.k) row[rank] = mine;
+    if (lane == 0) cnt[qq] = min(c, (uint32_t)p.k);
+    DEVA_COMPILER_FENCE();
+  }
+  const int nq = min(QT, p.hw - q0);
+  uint64_t* dst = p.part + ((int64_t)split * p.hw + q0) * p.k;
+  for (int e = lane; e < nq * p.k; e += 64) {
+    const int ql = e / p.k;
+    const int r = e - ql * p.k;
+    dst[e] = ((uint32_t)r < cnt[ql]) ? cand[ql * STRIDE + r] : 0ull;
+  }
+}
+
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, off);
+    const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), off);
+    const uint64_t o = ((uint64_t)hi << 32) | lo;
+    v = (o > v) ? o : v;
+  }
+  return v;
+}
+
+// one wave per query: tournament merge of `splits` sorted lists (lane s owns list s)
+__global__ __launch_bounds__(256) void affinity_finalize_kernel(const uint64_t* __restrict__ part, int hw, int k,
+                                                                int splits, int32_t* __restrict__ idx,
+                                                                float* __restrict__ weight,
+                                                                unsigned long long* __restrict__ usage_fix) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (q >= hw) return;
+  const uint64_t* list = part + ((int64_t)lane * hw + q) * k;
+  int ptr = 0;
+  uint64_t head = (lane < splits) ? list[0] : 0ull;
+  uint64_t mine = 0ull;
+  for (int r = 0; r < k; ++r) {
+    const uint64_t best = wave_max_u64(head);
+    if (lane == r) mine = best;
+    if (head == best && best != 0ull) {
+      ++ptr;
+      head = (ptr < k) ? list[ptr] : 0ull;
+    }
+  }
+  // lanes 0..k-1 hold the winners in descending order
+  const bool live = lane < k;
+  const float score = from_orderable((uint32_t)(mine >> 32));
+  const uint32_t token = ~(uint32_t)mine;
+  const float e = live ? expf(score) : 0.0f;
+  float sum = 0.0f;
+  for (int r = 0; r < k; ++r) sum += __shfl(e, r);  // sequential, like torch.sum over the sorted top-k
+  const float w = e / sum;
+  if (live) {
+    idx[(int64_t)q * k + lane] = (int32_t)token;
+    weight[(int64_t)q * k + lane] = w;
+    if (usage_fix && mine != 0ull && w == w) {
+      atomicAdd(&usage_fix[token], (unsigned long long)(w * 1099511627776.0f));  // w * 2^40, exact scaling
+    }
+  }
+}
+
+__global__ void usage_update_kernel(unsigned long long* __restrict__ usage_fix, int64_t offset,
+                                    float* __restrict__ use, float* __restrict__ life, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long f = usage_fix[offset + i];
+  usage_fix[offset + i] = 0ull;
+  if (use) use[i] += (float)((double)f * (1.0 / 1099511627776.0));
+  if (life) life[i] += 1.0f;
+}
+
+// ------------------------------------------------------------------ sparse readout
+// block = 256 threads = 4 waves; tile = 32 queries x 256 channels.  A wave gathers the k value rows
+// of 8 queries (each lane a float4 of the 1-KiB row slab), accumulates in registers, and the tile
+// is transposed through LDS so the [cv][hw] output is written 128 B at a time.
+constexpr int RQ = 32;    // queries per block
+constexpr int RC = 256;   // channels per block
+
+__global__ __launch_bounds__(256) void readout_sparse_kernel(const int32_t* __restrict__ idx,
+                                                             const float* __restrict__ weight, int hw, int k,
+                                                             const float* __restrict__ val_long, int n_long,
+                                                             const float* __restrict__ val_work, int cv,
+                                                             float* __restrict__ out) {
+  __shared__ float tile[RC][RQ + 1];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int q0 = blockIdx.x * RQ;
+  const int c0 = blockIdx.y * RC;
+  const int cl = lane * 4;  // channel offset inside the slab
+  const bool c_ok = (c0 + cl) < cv;  // cv is a multiple of 4
+  for (int qi = 0; qi < RQ / 4; ++qi) {
+    const int ql = wave * (RQ / 4) + qi;
+    const int q = q0 + ql;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < hw && c_ok) {
+      for (int j = 0; j < k; ++j) {
+        const int t = idx[(int64_t)q * k + j];
+        const float w = weight[(int64_t)q * k + j];
+        const float* row = (t < n_long) ? (val_long + (int64_t)t * cv) : (val_work + (int64_t)(t - n_long) * cv);
+        const float4 v = *reinterpret_cast<const float4*>(row + c0 + cl);
+        acc.x += w * v.x;
+        acc.y += w * v.y;
+        acc.z += w * v.z;
+        acc.w += w * v.w;
+      }
+    }
+    tile[cl + 0][ql] = acc.x;
+    tile[cl + 1][ql] = acc.y;
+    tile[cl + 2][ql] = acc.z;
+    tile[cl + 3][ql] = acc.w;
+  }
+  __syncthreads();
+  const int tq = threadIdx.x & 31;
+  const int tc = threadIdx.x >> 5;  // 0..7
+  if (q0 + tq < hw) {
+    for (int c = tc; c < RC; c += 8) {
+      if (c0 + c < cv) out[(int64_t)(c0 + c) * hw + q0 + tq] = tile[c][tq];
+    }
+  }
+}
+
+}  // namespace
+}  // namespace deva
+
+using namespace deva;
+
+extern "C" int64_t deva_affinity_workspace(int hw, int k, int splits) { return (int64_t)splits * hw * k; }
+
+extern "C" int deva_affinity_default_splits(int n_total, int hw) {
+  const int qblocks = (int)ceil_div(hw, WAVES * QT);
+  const int tiles = (int)ceil_div(n_total, TOKT);
+  int s = (int)ceil_div(512, qblocks);
+  if (s > tiles / 4) s = tiles / 4;  // keep >= 4 tiles (128 tokens) per range
+  if (s > 64) s = 64;
+  if (s < 1) s = 1;
+  return s;
+}
+
+extern "C" int deva_affinity_topk(const float* key_long, const float* shr_long, int n_long, const float* key_work,
+                                  const float* shr_work, int n_work, const float* qk, const float* qe, int hw,
+                                  int k, int splits, uint64_t* part_keys, void* stream) {
+  DEVA_REQUIRE(qk && qe && part_keys && hw > 0, "deva_affinity_topk: bad query args");
+  DEVA_REQUIRE(n_long >= 0 && n_work >= 0, "deva_affinity_topk: negative bank size");
+  DEVA_REQUIRE(n_long == 0 || (key_long && shr_long), "deva_affinity_topk: null long-term segment");
+  DEVA_REQUIRE(n_work == 0 || (key_work && shr_work), "deva_affinity_topk: null working segment");
+  DEVA_REQUIRE(k >= 1 && k <= CAP - TOKT, "deva_affinity_topk: k=%d unsupported (1..%d)", k, CAP - TOKT);
+  const int64_t n_total = (int64_t)n_long + n_work;
+  DEVA_REQUIRE(n_total >= k, "deva_affinity_topk: selected index k out of range (bank has %lld tokens, k=%d)",
+               (long long)n_total, k);
+  DEVA_REQUIRE(n_total < (1ll << 31), "deva_affinity_topk: bank too large");
+  DEVA_REQUIRE(splits >= 1 && splits <= 64, "deva_affinity_topk: splits must be 1..64");
+  AffArgs a;
+  a.key_long = key_long ? key_long : key_work;
+  a.shr_long = shr_long ? shr_long : shr_work;
+  a.n_long = n_long;
+  a.key_work = key_work ? key_work : key_long;
+  a.shr_work = shr_work ? shr_work : shr_long;
+  a.n_total = (int)n_total;
+  a.qk = qk;
+  a.qe = qe;
+  a.hw = hw;
+  a.k = k;
+  a.splits = splits;
+  a.total_tiles = (int)ceil_div(n_total, TOKT);
+  a.tiles_per_split = (int)ceil_div(a.total_tiles, splits);
+  a.part = part_keys;
+  dim3 grid((unsigned)ceil_div(hw, WAVES * QT), (unsigned)splits);
+  hipLaunchKernelGGL(affinity_topk_kernel, grid, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
+  return check_launch("deva_affinity_topk");
+}
+
+extern "C" int deva_affinity_finalize(const uint64_t* part_keys, int hw, int k, int splits, int32_t* idx,
+                                      float* weight, uint64_t* usage_fix, void* stream) {
+  DEVA_REQUIRE(part_keys && idx && weight && hw > 0, "deva_affinity_finalize: bad args");
+  DEVA_REQUIRE(k >= 1 && k <= 64 && splits >= 1 && splits <= 64, "deva_affinity_finalize: k/splits out of range");
+  hipLaunchKernelGGL(affinity_finalize_kernel, dim3((unsigned)ceil_div(hw, 4)), dim3(256), 0, (hipStream_t)stream,
+                     part_keys, hw, k, splits, idx, weight, (unsigned long long*)usage_fix);
+  return check_launch("deva_affinity_finalize");
+}
+
+extern "C" int deva_usage_update(uint64_t* usage_fix, int64_t offset, float* use, float* life, int n,
+                                 void* stream) {
+  DEVA_REQUIRE(usage_fix && n >= 0 && offset >= 0, "deva_usage_update: bad args");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(usage_update_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (unsigned long long*)usage_fix, offset, use, life, n);
+  return check_launch("deva_usage_update");
+}
+
+extern "C" int deva_readout_sparse(const int32_t* idx, const float* weight, int hw, int k, const float* val_long,
+                                   int n_long, const float* val_work, int cv, float* out, void* stream) {
+  DEVA_REQUIRE(idx && weight && out && hw > 0 && k > 0 && cv > 0, "deva_readout_sparse: bad args");
+  DEVA_REQUIRE(cv % 4 == 0, "deva_readout_sparse: value dim must be a multiple of 4");
+  DEVA_REQUIRE(n_long == 0 || val_long, "deva_readout_sparse: null long-term values");
+  const float* vl = val_long ? val_long : val_work;
+  const float* vw = val_work ? val_work : val_long;
+  DEVA_REQUIRE(vl && vw, "deva_readout_sparse: no value segment");
+  dim3 grid((unsigned)ceil_div(hw, RQ), (unsigned)ceil_div(cv, RC));
+  hipLaunchKernelGGL(readout_sparse_kernel, grid, dim3(256), 0, (hipStream_t)stream, idx, weight, hw, k, vl, n_long,
+                     vw, cv, out);
+  return check_launch("deva_readout_sparse");
+}

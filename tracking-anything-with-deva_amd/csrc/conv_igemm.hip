@@ -1,0 +1,307 @@
+// Implicit-GEMM convolution on the fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32).
+//
+//   out[b][m][oh][ow] = act( sum_k Wp[k][m] * X(k; b,oh,ow) + bias[m] + residual[b][m][oh][ow] )
+//
+// GEMM view:  M = cout, N = batch*OH*OW (pixels, batch-major), K = KH*KW*(C0+C1), k = tap*Ctot + c.
+// A = packed weights, k-major [K][cout_pad]  (cout contiguous)  -> float4 global loads along M
+// B = im2col of the NCHW input, gathered on the fly; for a fixed k consecutive pixels are
+//     consecutive addresses (stride-1 convs), so the scalar gathers of a wave are coalesced.
+//
+// fp32-in MFMA runs at the fp32 vector rate (256 FLOP/clk/CU), i.e. a 128x128 block tile needs
+// only ~8 B/clk/CU of operand traffic: the kernel is matrix-pipe bound, so the staging path is
+// kept simple (register-staged, double-buffered LDS, one barrier per K step) and exact fp32.
+//
+// Each of the 4 waves owns a (WM x WN) sub-tile made of 32x32 MFMA tiles.  Operand fragments for
+// v_mfma_f32_32x32x2_f32:  A: lane l holds A[i = l&31][k = l>>5],  B: B[k = l>>5][j = l&31],
+// D: reg r of lane l is D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
+#include "common.h"
+
+namespace deva {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+  const float* in0;
+  const float* in1;
+  int64_t bs0, bs1;  // batch strides (elements)
+  int c0, c1, ctot;
+  int H, W, OH, OW, OHW;
+  int64_t HW;
+  const float* w;
+  const float* bias;
+  int cout, cout_pad;
+  int KH, KW, stride, pad;
+  int K;        // KH*KW*ctot
+  int n_total;  // batch*OH*OW
+  int relu_in;
+  const float* res;
+  int64_t res_bs;
+  int act;
+  float* out;
+  int tiles_n;
+};
+
+constexpr int BK = 16;
+constexpr int THREADS = 256;
+
+// MODE 0: 1x1 kernel (tap == 0);  MODE 1: both channel counts multiples of BK (tap and source are
+// uniform over a K step);  MODE 2: anything (per-element decode, used by the 3/4/2-channel stems).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE>
+__global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvArgs p) {
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  static_assert(TM >= 1 && TN >= 1, "wave tile");
+  constexpr int A_V4 = (BK * BM / 4 + THREADS - 1) / THREADS;  // float4 loads per thread
+  constexpr int KG = THREADS / BN;                              // k rows covered per pass
+  constexpr int B_PT = BK / KG;                                 // scalar gathers per thread
+
+  __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm0 = (wave / WAVES_N) * WM;
+  const int wn0 = (wave % WAVES_N) * WN;
+  const int l31 = lane & 31;
+  const int half = lane >> 5;
+
+  const int tile_m = blockIdx.x / p.tiles_n;
+  const int tile_n = blockIdx.x % p.tiles_n;
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  // ---- per-thread constants of the B gather: this thread always gathers pixel n0 + (tid % BN)
+  const int bn_local = tid % BN;
+  const int bk_group = tid / BN;
+  const int n_g = n0 + bn_local;
+  const bool n_ok = n_g < p.n_total;
+  int ih0, iw0;
+  const float* src0;
+  const float* src1;
+  {
+    const int nn = n_ok ? n_g : 0;
+    const int b = nn / p.OHW;
+    const int pix = nn - b * p.OHW;
+    const int oh = pix / p.OW;
+    const int ow = pix - oh * p.OW;
+    ih0 = oh * p.stride - p.pad;
+    iw0 = ow * p.stride - p.pad;
+    src0 = p.in0 + (int64_t)b * p.bs0;
+    src1 = p.in1 ? p.in1 + (int64_t)b * p.bs1 : p.in0;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  float4 ra[A_V4];
+  float rb[B_PT];
+
+  auto load_tiles = [&](int k0) {
+    // A: rows k0..k0+BK-1 of the packed weights, columns m0..m0+BM-1
+#pragma unroll
+    for (int i = 0; i < A_V4; ++i) {
+      const int e = tid + i * THREADS;
+      const int kr = e / (BM / 4);
+      const int mc = (e % (BM / 4)) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < BK * BM / 4) {
+        const int k = k0 + kr;
+        const int m = m0 + mc;
+        if (k < p.K && m < p.cout_pad) v = *reinterpret_cast<const float4*>(p.w + (int64_t)k * p.cout_pad + m);
+      }
+      ra[i] = v;
+    }
+    // B: im2col gather
+    int tap_u = 0, cbase_u = 0;
+    if (MODE == 1) {
+      tap_u = k0 / p.ctot;
+      cbase_u = k0 - tap_u * p.ctot;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PT; ++i) {
+      const int kl = bk_group + i * KG;
+      const int k = k0 + kl;
+      int tap, c;
+      if (MODE == 0) {
+        tap = 0;
+        c = k;
+      } else if (MODE == 1) {
+        tap = tap_u;
+        c = cbase_u + kl;
+      } else {
+        tap = k / p.ctot;
+        c = k - tap * p.ctot;
+      }
+      int ih = ih0, iw = iw0;
+      if (MODE != 0) {
+        const int dy = tap / p.KW;
+        ih += dy;
+        iw += tap - dy * p.KW;
+      }
+      const bool ok = n_ok && (k < p.K) && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+      float v = 0.0f;
+      if (ok) {
+        const float* s = (c < p.c0) ? (src0 + (int64_t)c * p.HW) : (src1 + (int64_t)(c - p.c0) * p.HW);
+        v = s[ih * p.W + iw];
+        if (p.relu_in) v = fmaxf(v, 0.0f);
+      }
+      rb[i] = v;
+    }
+  };
+
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_V4; ++i) {
+      const int e = tid + i * THREADS;
+      if (e < BK * BM / 4) {
+        const int kr = e / (BM / 4);
+        const int mc = (e % (BM / 4)) * 4;
+        *reinterpret_cast<float4*>(&As[buf][kr][mc]) = ra[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_PT; ++i) Bs[buf][bk_group + i * KG][bn_local] = rb[i];
+  };
+
+  const int ksteps = (p.K + BK - 1) / BK;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+
+  for (int s = 0; s < ksteps; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < ksteps) load_tiles((s + 1) * BK);  // global loads in flight during the MFMAs
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[buf][2 * kk + half][wm0 + i * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[buf][2 * kk + half][wn0 + j * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (s + 1 < ksteps) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias + residual + activation, NCHW store (32 consecutive pixels per half-wave)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn0 + j * 32 + l31;
+    if (n >= p.n_total) continue;
+    const int b = n / p.OHW;
+    const int pix = n - b * p.OHW;
+    const int64_t obase = (int64_t)b * p.cout * p.OHW + pix;
+    const int64_t rbase = (int64_t)b * p.res_bs + pix;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m >= p.cout) continue;
+        float v = acc[i][j][r];
+        if (p.bias) v += p.bias[m];
+        if (p.res) v += p.res[rbase + (int64_t)m * p.OHW];
+        if (p.act == DEVA_ACT_RELU) {
+          v = fmaxf(v, 0.0f);
+        } else if (p.act == DEVA_ACT_SIGMOID) {
+          v = sigmoidf_(v);
+        } else if (p.act == DEVA_ACT_SQUARE_PLUS_ONE) {
+          v = v * v + 1.0f;
+        }
+        p.out[obase + (int64_t)m * p.OHW] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+int launch_mode(const ConvArgs& a, int mode, hipStream_t st) {
+  ConvArgs p = a;
+  const int tiles_m = (int)ceil_div(a.cout, BM);
+  p.tiles_n = (int)ceil_div(a.n_total, BN);
+  dim3 grid((unsigned)(tiles_m * p.tiles_n));
+  if (mode == 0) {
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, 0>), grid, dim3(THREADS), 0, st, p);
+  } else if (mode == 1) {
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, 1>), grid, dim3(THREADS), 0, st, p);
+  } else {
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, 2>), grid, dim3(THREADS), 0, st, p);
+  }
+  return check_launch("deva_conv2d");
+}
+
+}  // namespace
+}  // namespace deva
+
+extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
+  using namespace deva;
+  DEVA_REQUIRE(d != nullptr, "deva_conv2d: null descriptor");
+  DEVA_REQUIRE(d->in0 && d->weight && d->out, "deva_conv2d: null tensor");
+  DEVA_REQUIRE(d->c0 > 0 && d->c1 >= 0 && (d->c1 == 0 || d->in1), "deva_conv2d: bad channel split");
+  DEVA_REQUIRE(d->batch > 0 && d->height > 0 && d->width > 0 && d->cout > 0, "deva_conv2d: bad shape");
+  DEVA_REQUIRE(d->cout_pad % 32 == 0 && d->cout_pad >= d->cout, "deva_conv2d: cout_pad must be cout rounded up to 32");
+  DEVA_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "deva_conv2d: bad kernel geometry");
+  ConvArgs a;
+  a.in0 = d->in0;
+  a.in1 = d->c1 ? d->in1 : nullptr;
+  a.bs0 = d->in0_batch_stride;
+  a.bs1 = d->in1_batch_stride;
+  a.c0 = d->c0;
+  a.c1 = d->c1;
+  a.ctot = d->c0 + d->c1;
+  a.H = d->height;
+  a.W = d->width;
+  a.OH = (d->height + 2 * d->pad - d->kh) / d->stride + 1;
+  a.OW = (d->width + 2 * d->pad - d->kw) / d->stride + 1;
+  DEVA_REQUIRE(a.OH > 0 && a.OW > 0, "deva_conv2d: empty output");
+  a.OHW = a.OH * a.OW;
+  a.HW = (int64_t)d->height * d->width;
+  a.w = d->weight;
+  a.bias = d->bias;
+  a.cout = d->cout;
+  a.cout_pad = d->cout_pad;
+  a.KH = d->kh;
+  a.KW = d->kw;
+  a.stride = d->stride;
+  a.pad = d->pad;
+  a.K = d->kh * d->kw * a.ctot;
+  const int64_t n_total = (int64_t)d->batch * a.OHW;
+  DEVA_REQUIRE(n_total < (1ll << 31) && a.HW < (1ll << 31), "deva_conv2d: tensor too large for 32-bit pixel index");
+  a.n_total = (int)n_total;
+  a.relu_in = d->relu_in;
+  a.res = d->residual;
+  a.res_bs = d->residual_batch_stride;
+  a.act = d->act;
+  a.out = d->out;
+  a.tiles_n = 0;
+
+  int mode;
+  if (d->kh == 1 && d->kw == 1) {
+    mode = 0;
+  } else if (a.ctot % BK == 0) {
+    mode = 1;
+  } else {
+    mode = 2;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  // Tile choice: the largest tile that still yields >= ~2 workgroups per CU (256 CUs).
+  const int64_t blocks128 = ceil_div(a.cout, 128) * ceil_div(a.n_total, 128);
+  const int64_t blocks64 = ceil_div(a.cout, 64) * ceil_div(a.n_total, 64);
+  if (a.cout <= 32) return launch_mode<32, 128, 1, 4>(a, mode, st);
+  if (a.cout >= 128 && blocks128 >= 512) return launch_mode<128, 128, 2, 2>(a, mode, st);
+  if (blocks64 >= 384 || a.cout <= 64) return launch_mode<64, 64, 2, 2>(a, mode, st);
+  return launch_mode<64, 64, 2, 2>(a, mode, st);
+}

@@ -1,0 +1,384 @@
+// Pooling, resampling and pointwise blocks of the DEVA decoder / encoders (all HBM-bound).
+// One thread per output element, consecutive threads on consecutive addresses (coalesced).
+#include <math.h>
+
+#include "common.h"
+
+namespace deva {
+namespace {
+
+constexpr int TPB = 256;
+
+inline dim3 grid_for(int64_t n) {
+  int64_t b = ceil_div(n, TPB);
+  if (b > 65535 * 16) b = 65535 * 16;  // grid-stride beyond this
+  return dim3((unsigned)b);
+}
+
+// ------------------------------------------------------------------ max pool 3x3 / s2 / p1
+__global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t total,
+                                    int H, int W, int OH, int OW, int relu_after) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ow = (int)(i % OW);
+    const int64_t t = i / OW;
+    const int oh = (int)(t % OH);
+    const int64_t plane = t / OH;
+    const float* src = in + plane * (int64_t)H * W;
+    float m = -INFINITY;
+    const int h0 = oh * 2 - 1, w0 = ow * 2 - 1;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int h = h0 + dy;
+      if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int w = w0 + dx;
+        if ((unsigned)w >= (unsigned)W) continue;
+        m = fmaxf(m, src[h * W + w]);
+      }
+    }
+    if (relu_after) m = fmaxf(m, 0.0f);
+    out[i] = m;
+  }
+}
+
+// ------------------------------------------------------------------ bilinear helpers
+// PyTorch area_pixel_compute_source_index(align_corners=False): src = scale*(dst+0.5)-0.5, clamped at 0
+struct Lerp {
+  int i0, i1;
+  float w0, w1;
+};
+__device__ __forceinline__ Lerp lerp_index(int dst, float scale, int in_size) {
+  float src = scale * (dst + 0.5f) - 0.5f;
+  if (src < 0.0f) src = 0.0f;
+  Lerp l;
+  l.i0 = (int)src;  // src >= 0 -> floor
+  l.i1 = l.i0 + ((l.i0 < in_size - 1) ? 1 : 0);
+  l.w1 = src - (float)l.i0;
+  l.w0 = 1.0f - l.w1;
+  return l;
+}
+__device__ __forceinline__ float bilerp(const float* __restrict__ src, int W, const Lerp& ly, const Lerp& lx) {
+  const float top = lx.w0 * src[ly.i0 * W + lx.i0] + lx.w1 * src[ly.i0 * W + lx.i1];
+  const float bot = lx.w0 * src[ly.i1 * W + lx.i0] + lx.w1 * src[ly.i1 * W + lx.i1];
+  return ly.w0 * top + ly.w1 * bot;
+}
+
+__global__ void upsample2x_add_kernel(const float* __restrict__ in, const float* __restrict__ skip,
+                                      float* __restrict__ out, int64_t total, int C, int h, int w) {
+  const int OH = 2 * h, OW = 2 * w;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW);
+    const int64_t t = i / OW;
+    const int oy = (int)(t % OH);
+    const int64_t plane = t / OH;  // b*C + c
+    const int c = (int)(plane % C);
+    const Lerp ly = lerp_index(oy, 0.5f, h), lx = lerp_index(ox, 0.5f, w);
+    float v = bilerp(in + plane * (int64_t)h * w, w, ly, lx);
+    if (skip) v = skip[((int64_t)c * OH + oy) * OW + ox] + v;
+    out[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------ area downsample (integer factor)
+__global__ void area_downsample_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t total,
+                                       int H, int W, int f) {
+  const int OH = H / f, OW = W / f;
+  const float denom = (float)(f * f);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW);
+    const int64_t t = i / OW;
+    const int oy = (int)(t % OH);
+    const int64_t plane = t / OH;
+    const float* src = in + plane * (int64_t)H * W + (int64_t)oy * f * W + ox * f;
+    float s = 0.0f;
+    for (int dy = 0; dy < f; ++dy)
+      for (int dx = 0; dx < f; ++dx) s += src[dy * W + dx];
+    out[i] = s / denom;
+  }
+}
+
+// ------------------------------------------------------------------ aggregate (network.py:33-40)
+__device__ __forceinline__ float logit_clamped(float p) {
+  p = fminf(fmaxf(p, 1e-7f), 1.0f - 1e-7f);
+  return logf(p / (1.0f - p));
+}
+
+template <bool U8>
+__global__ void aggregate_kernel(const void* __restrict__ in_, int apply_sigmoid, float* __restrict__ out,
+                                 int num, int64_t pixels) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < pixels; i += (int64_t)gridDim.x * blockDim.x) {
+    float bg = 1.0f;
+    for (int o = 0; o < num; ++o) {
+      float p;
+      if (U8) {
+        p = (float)reinterpret_cast<const unsigned char*>(in_)[(int64_t)o * pixels + i];
+      } else {
+        p = reinterpret_cast<const float*>(in_)[(int64_t)o * pixels + i];
+      }
+      if (apply_sigmoid) p = sigmoidf_(p);
+      bg *= (1.0f - p);
+      out[(int64_t)(o + 1) * pixels + i] = logit_clamped(p);
+    }
+    out[i] = logit_clamped(bg);
+  }
+}
+
+// ------------------------------------------------------------------ channel softmax
+__global__ void softmax_channels_kernel(const float* __restrict__ in, float* __restrict__ out, int C,
+                                        int64_t pixels) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < pixels; i += (int64_t)gridDim.x * blockDim.x) {
+    float m = -INFINITY;
+    for (int c = 0; c < C; ++c) m = fmaxf(m, in[(int64_t)c * pixels + i]);
+    float s = 0.0f;
+    for (int c = 0; c < C; ++c) s += expf(in[(int64_t)c * pixels + i] - m);
+    for (int c = 0; c < C; ++c) out[(int64_t)c * pixels + i] = expf(in[(int64_t)c * pixels + i] - m) / s;
+  }
+}
+
+// ------------------------------------------------------------------ x4 bilinear + channel softmax
+__global__ void upsample4x_softmax_kernel(const float* __restrict__ in, float* __restrict__ logits_up,
+                                          float* __restrict__ prob, int C, int h, int w) {
+  const int OH = 4 * h, OW = 4 * w;
+  const int64_t opix = (int64_t)OH * OW;
+  const int64_t ipix = (int64_t)h * w;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < opix; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW);
+    const int oy = (int)(i / OW);
+    const Lerp ly = lerp_index(oy, 0.25f, h), lx = lerp_index(ox, 0.25f, w);
+    float m = -INFINITY;
+    for (int c = 0; c < C; ++c) {
+      const float v = bilerp(in + c * ipix, w, ly, lx);
+      if (logits_up) logits_up[c * opix + i] = v;
+      m = fmaxf(m, v);
+    }
+    float s = 0.0f;
+    for (int c = 0; c < C; ++c) s += expf(bilerp(in + c * ipix, w, ly, lx) - m);
+    for (int c = 0; c < C; ++c) prob[c * opix + i] = expf(bilerp(in + c * ipix, w, ly, lx) - m) / s;
+  }
+}
+
+// ------------------------------------------------------------------ CBAM pieces
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float* smem) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_xor(v, off);
+    v = is_max ? fmaxf(v, o) : (v + o);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) smem[wave] = v;
+  __syncthreads();
+  const int nw = blockDim.x >> 6;
+  float r = smem[0];
+  for (int i = 1; i < nw; ++i) r = is_max ? fmaxf(r, smem[i]) : (r + smem[i]);
+  return r;
+}
+
+__global__ void global_avgmax_kernel(const float* __restrict__ x, float* __restrict__ avg,
+                                     float* __restrict__ mx, int hw) {
+  __shared__ float smem[8];
+  const float* src = x + (int64_t)blockIdx.x * hw;
+  float s = 0.0f, m = -INFINITY;
+  for (int i = threadIdx.x; i < hw; i += blockDim.x) {
+    const float v = src[i];
+    s += v;
+    m = fmaxf(m, v);
+  }
+  s = block_reduce(s, false, smem);
+  m = block_reduce(m, true, smem);
+  if (threadIdx.x == 0) {
+    avg[blockIdx.x] = s / (float)hw;
+    mx[blockIdx.x] = m;
+  }
+}
+
+// one block per batch item; scale = sigmoid(mlp(avg) + mlp(max))
+__global__ void cbam_mlp_kernel(const float* __restrict__ avg, const float* __restrict__ mx,
+                                const float* __restrict__ w1, const float* __restrict__ b1,
+                                const float* __restrict__ w2, const float* __restrict__ b2,
+                                float* __restrict__ scale, int C, int hidden) {
+  extern __shared__ float sm[];  // [2][C] inputs, then [2][hidden]
+  float* vin = sm;
+  float* hid = sm + 2 * C;
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < C; i += blockDim.x) {
+    vin[i] = avg[(int64_t)b * C + i];
+    vin[C + i] = mx[(int64_t)b * C + i];
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 2 * hidden; t += blockDim.x) {
+    const int which = t / hidden, j = t % hidden;
+    float s = 0.0f;
+    for (int c = 0; c < C; ++c) s += w1[(int64_t)j * C + c] * vin[which * C + c];
+    hid[t] = fmaxf(s + b1[j], 0.0f);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float sa = 0.0f, sm_ = 0.0f;
+    for (int j = 0; j < hidden; ++j) {
+      const float w = w2[(int64_t)c * hidden + j];
+      sa += w * hid[j];
+      sm_ += w * hid[hidden + j];
+    }
+    const float att = (sa + b2[c]) + (sm_ + b2[c]);
+    scale[(int64_t)b * C + c] = sigmoidf_(att);
+  }
+}
+
+__global__ void cbam_channel_pool_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                         float* __restrict__ pooled, int64_t total, int C, int hw) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int p = (int)(i % hw);
+    const int64_t b = i / hw;
+    const float* src = x + b * C * hw + p;
+    const float* sc = scale + b * C;
+    float m = -INFINITY, s = 0.0f;
+    for (int c = 0; c < C; ++c) {
+      const float v = src[(int64_t)c * hw] * sc[c];
+      m = fmaxf(m, v);
+      s += v;
+    }
+    pooled[(b * 2 + 0) * hw + p] = m;
+    pooled[(b * 2 + 1) * hw + p] = s / (float)C;
+  }
+}
+
+__global__ void cbam_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                  const float* __restrict__ gate, float* __restrict__ out, int64_t total,
+                                  int C, int hw) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int p = (int)(i % hw);
+    const int64_t bc = i / hw;
+    const int64_t b = bc / C;
+    const float v = x[i];
+    const float r = (v * scale[bc]) * sigmoidf_(gate[b * hw + p]);
+    out[i] = v + r;
+  }
+}
+
+// ------------------------------------------------------------------ GRU-style sensory update
+__global__ void gru_update_kernel(const float* __restrict__ values, const float* __restrict__ h,
+                                  float* __restrict__ new_h, int64_t total, int C, int hw) {
+  const int64_t chw = (int64_t)C * hw;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / chw;
+    const int64_t r = i - b * chw;
+    const float* v = values + b * 3 * chw + r;
+    const float f = sigmoidf_(v[0]);
+    const float u = sigmoidf_(v[chw]);
+    const float n = tanhf(v[2 * chw]);
+    const float hv = h[i];
+    new_h[i] = f * hv * (1.0f - u) + u * n;
+  }
+}
+
+}  // namespace
+}  // namespace deva
+
+using namespace deva;
+
+extern "C" int deva_maxpool3x3s2(const float* in, float* out, int64_t planes, int height, int width,
+                                 int relu_after, void* stream) {
+  DEVA_REQUIRE(in && out && planes > 0 && height > 0 && width > 0, "deva_maxpool3x3s2: bad args");
+  const int OH = (height + 2 - 3) / 2 + 1, OW = (width + 2 - 3) / 2 + 1;
+  const int64_t total = planes * OH * OW;
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, grid_for(total), dim3(TPB), 0, (hipStream_t)stream, in, out, total,
+                     height, width, OH, OW, relu_after);
+  return check_launch("deva_maxpool3x3s2");
+}
+
+extern "C" int deva_upsample2x_add(const float* in, const float* skip, float* out, int batch, int channels,
+                                   int height, int width, void* stream) {
+  DEVA_REQUIRE(in && out && batch > 0 && channels > 0 && height > 0 && width > 0, "deva_upsample2x_add: bad args");
+  const int64_t total = (int64_t)batch * channels * height * 2 * width * 2;
+  hipLaunchKernelGGL(upsample2x_add_kernel, grid_for(total), dim3(TPB), 0, (hipStream_t)stream, in, skip, out,
+                     total, channels, height, width);
+  return check_launch("deva_upsample2x_add");
+}
+
+extern "C" int deva_area_downsample(const float* in, float* out, int64_t planes, int height, int width,
+                                    int factor, void* stream) {
+  DEVA_REQUIRE(in && out && planes > 0 && factor >= 1, "deva_area_downsample: bad args");
+  DEVA_REQUIRE(height % factor == 0 && width % factor == 0, "deva_area_downsample: size %dx%d not divisible by %d",
+               height, width, factor);
+  const int64_t total = planes * (height / factor) * (width / factor);
+  hipLaunchKernelGGL(area_downsample_kernel, grid_for(total), dim3(TPB), 0, (hipStream_t)stream, in, out, total,
+                     height, width, factor);
+  return check_launch("deva_area_downsample");
+}
+
+extern "C" int deva_aggregate(const void* in, int in_is_u8, int apply_sigmoid, float* out, int num,
+                              int64_t pixels, void* stream) {
+  DEVA_REQUIRE(in && out && num >= 0 && pixels > 0, "deva_aggregate: bad args");
+  if (in_is_u8) {
+    hipLaunchKernelGGL(aggregate_kernel<true>, grid_for(pixels), dim3(TPB), 0, (hipStream_t)stream, in,
+                       apply_sigmoid, out, num, pixels);
+  } else {
+    hipLaunchKernelGGL(aggregate_kernel<false>, grid_for(pixels), dim3(TPB), 0, (hipStream_t)stream, in,
+                       apply_sigmoid, out, num, pixels);
+  }
+  return check_launch("deva_aggregate");
+}
+
+extern "C" int deva_softmax_channels(const float* in, float* out, int channels, int64_t pixels, void* stream) {
+  DEVA_REQUIRE(in && out && channels > 0 && pixels > 0, "deva_softmax_channels: bad args");
+  hipLaunchKernelGGL(softmax_channels_kernel, grid_for(pixels), dim3(TPB), 0, (hipStream_t)stream, in, out,
+                     channels, pixels);
+  return check_launch("deva_softmax_channels");
+}
+
+extern "C" int deva_upsample4x_softmax(const float* in, float* logits_up, float* prob, int channels, int height,
+                                       int width, void* stream) {
+  DEVA_REQUIRE(in && prob && channels > 0 && height > 0 && width > 0, "deva_upsample4x_softmax: bad args");
+  const int64_t opix = (int64_t)height * 4 * width * 4;
+  hipLaunchKernelGGL(upsample4x_softmax_kernel, grid_for(opix), dim3(TPB), 0, (hipStream_t)stream, in, logits_up,
+                     prob, channels, height, width);
+  return check_launch("deva_upsample4x_softmax");
+}
+
+extern "C" int deva_global_avgmax(const float* x, float* avg, float* mx, int64_t planes, int hw, void* stream) {
+  DEVA_REQUIRE(x && avg && mx && planes > 0 && hw > 0, "deva_global_avgmax: bad args");
+  DEVA_REQUIRE(planes < (1ll << 31), "deva_global_avgmax: too many planes");
+  hipLaunchKernelGGL(global_avgmax_kernel, dim3((unsigned)planes), dim3(TPB), 0, (hipStream_t)stream, x, avg, mx,
+                     hw);
+  return check_launch("deva_global_avgmax");
+}
+
+extern "C" int deva_cbam_mlp(const float* avg, const float* mx, const float* w1, const float* b1, const float* w2,
+                             const float* b2, float* scale, int batch, int channels, int hidden, void* stream) {
+  DEVA_REQUIRE(avg && mx && w1 && b1 && w2 && b2 && scale && batch > 0 && channels > 0 && hidden > 0,
+               "deva_cbam_mlp: bad args");
+  const size_t smem = sizeof(float) * (2 * (size_t)channels + 2 * (size_t)hidden);
+  DEVA_REQUIRE(smem <= 64 * 1024, "deva_cbam_mlp: channels too large");
+  hipLaunchKernelGGL(cbam_mlp_kernel, dim3((unsigned)batch), dim3(TPB), smem, (hipStream_t)stream, avg, mx, w1, b1,
+                     w2, b2, scale, channels, hidden);
+  return check_launch("deva_cbam_mlp");
+}
+
+extern "C" int deva_cbam_channel_pool(const float* x, const float* scale, float* pooled, int batch, int channels,
+                                      int hw, void* stream) {
+  DEVA_REQUIRE(x && scale && pooled && batch > 0 && channels > 0 && hw > 0, "deva_cbam_channel_pool: bad args");
+  const int64_t total = (int64_t)batch * hw;
+  hipLaunchKernelGGL(cbam_channel_pool_kernel, grid_for(total), dim3(TPB), 0, (hipStream_t)stream, x, scale, pooled,
+                     total, channels, hw);
+  return check_launch("deva_cbam_channel_pool");
+}
+
+extern "C" int deva_cbam_apply(const float* x, const float* scale, const float* gate, float* out, int batch,
+                               int channels, int hw, void* stream) {
+  DEVA_REQUIRE(x && scale && gate && out && batch > 0 && channels > 0 && hw > 0, "deva_cbam_apply: bad args");
+  const int64_t total = (int64_t)batch * channels * hw;
+  hipLaunchKernelGGL(cbam_apply_kernel, grid_for(total), dim3(TPB), 0, (hipStream_t)stream, x, scale, gate, out,
+                     total, channels, hw);
+  return check_launch("deva_cbam_apply");
+}
+
+extern "C" int deva_gru_update(const float* values, const float* h, float* new_h, int batch, int channels, int hw,
+                               void* stream) {
+  DEVA_REQUIRE(values && h && new_h && batch > 0 && channels > 0 && hw > 0, "deva_gru_update: bad args");
+  const int64_t total = (int64_t)batch * channels * hw;
+  hipLaunchKernelGGL(gru_update_kernel, grid_for(total), dim3(TPB), 0, (hipStream_t)stream, values, h, new_h, total,
+                     channels, hw);
+  return check_launch("deva_gru_update");
+}

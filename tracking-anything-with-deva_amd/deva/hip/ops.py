@@ -1,0 +1,334 @@
+"""Tensor-level wrappers over the C ABI of libdeva_hip.so.
+
+PyTorch is used for device memory (torch.empty on the caching allocator), views and the current
+HIP stream only; every arithmetic operation below runs in a hand-written gfx950 kernel.  All
+wrappers raise `DevaHipError` on non-HIP / non-contiguous / wrong-dtype tensors: there is no
+fallback path.
+"""
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQUARE_PLUS_ONE, ConvDesc, DevaHipError, check,
+               lib)
+
+__all__ = ['PackedConv', 'pack_conv', 'conv2d', 'maxpool3x3s2', 'upsample2x_add', 'area_downsample',
+           'aggregate', 'softmax_channels', 'upsample4x_softmax', 'cbam', 'gru_update',
+           'affinity_topk', 'usage_update', 'readout_sparse', 'bank_append', 'bank_gather_rows',
+           'bank_export', 'rank', 'rank_select', 'evict_select', 'similarity_dense', 'softmax_columns',
+           'ACT_NONE', 'ACT_RELU', 'ACT_SIGMOID', 'ACT_SQUARE_PLUS_ONE']
+
+
+def require_hip(device, what: str) -> None:
+    if torch.device(device).type != 'cuda':
+        raise DevaHipError(f'{what} must be on the HIP device to run (is on {device}); '
+                           'there is no CPU execution path')
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor], dtype=torch.float32, name: str = 'tensor') -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise DevaHipError(f'{name} must live on the HIP device (got {t.device}); there is no CPU path')
+    if t.dtype != dtype:
+        raise DevaHipError(f'{name} must be {dtype} (got {t.dtype})')
+    if not t.is_contiguous():
+        raise DevaHipError(f'{name} must be contiguous')
+    return t.data_ptr()
+
+
+def _batched(t: torch.Tensor, name: str) -> Tuple[int, int]:
+    """pointer and batch stride of an NCHW tensor whose per-item [C,H,W] block is contiguous"""
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise DevaHipError(f'{name} must be an fp32 HIP tensor')
+    if t.dim() != 4 or not t[0].is_contiguous():
+        raise DevaHipError(f'{name} must be [B,C,H,W] with contiguous items')
+    return t.data_ptr(), (t.stride(0) if t.shape[0] > 1 else 0)
+
+
+# ------------------------------------------------------------------------------------------ conv
+@dataclass
+class PackedConv:
+    """weights of one convolution in the kernel's layout: [KH*KW*Cin][cout_pad], k = tap*Cin + c"""
+    weight: torch.Tensor
+    bias: Optional[torch.Tensor]
+    cin: int
+    cout: int
+    cout_pad: int
+    kh: int
+    kw: int
+
+
+def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None,
+              device=None) -> PackedConv:
+    """One-time weight preparation (model load, not the frame path): fold an eval-mode BatchNorm
+    `bn = (gamma, beta, running_mean, running_var, eps)` into the convolution and repack
+    [cout][cin][kh][kw] -> [kh*kw*cin][cout_pad]."""
+    w = weight.detach().to(torch.float32)
+    cout, cin, kh, kw = w.shape
+    b = None if bias is None else bias.detach().to(torch.float32)
+    if bn is not None:
+        gamma, beta, mean, var, eps = bn
+        scale = gamma.detach().float() / torch.sqrt(var.detach().float() + eps)
+        w = w * scale.view(-1, 1, 1, 1)
+        shift = beta.detach().float() - mean.detach().float() * scale
+        b = shift if b is None else b * scale + shift
+    cout_pad = (cout + 31) // 32 * 32
+    packed = torch.zeros(kh * kw * cin, cout_pad, dtype=torch.float32, device=w.device)
+    packed[:, :cout] = w.permute(2, 3, 1, 0).reshape(kh * kw * cin, cout)
+    if device is not None:
+        packed = packed.to(device)
+        b = None if b is None else b.to(device)
+    return PackedConv(packed.contiguous(), None if b is None else b.contiguous(), cin, cout, cout_pad, kh, kw)
+
+
+def conv2d(pc: PackedConv, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *, stride: int = 1,
+           pad: int = 0, relu_in: bool = False, residual: Optional[torch.Tensor] = None,
+           act: int = ACT_NONE, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = act(conv(cat([x0, x1], 1)) + bias + residual); batch-1 operands broadcast."""
+    c0 = x0.shape[1]
+    c1 = 0 if x1 is None else x1.shape[1]
+    if c0 + c1 != pc.cin:
+        raise DevaHipError(f'conv2d: {c0}+{c1} input channels, weights expect {pc.cin}')
+    batch = max(x0.shape[0], 1 if x1 is None else x1.shape[0], 1 if residual is None else residual.shape[0])
+    h, w = x0.shape[-2:]
+    if x1 is not None and tuple(x1.shape[-2:]) != (h, w):
+        raise DevaHipError('conv2d: x0/x1 spatial size mismatch')
+    for t in (x0, x1, residual):
+        if t is not None and t.shape[0] not in (1, batch):
+            raise DevaHipError('conv2d: batch sizes must be 1 or equal')
+    oh = (h + 2 * pad - pc.kh) // stride + 1
+    ow = (w + 2 * pad - pc.kw) // stride + 1
+    if out is None:
+        out = torch.empty((batch, pc.cout, oh, ow), dtype=torch.float32, device=x0.device)
+    elif tuple(out.shape) != (batch, pc.cout, oh, ow):
+        raise DevaHipError('conv2d: bad output shape')
+    d = ConvDesc()
+    d.in0, d.in0_batch_stride = _batched(x0, 'x0')
+    if x1 is not None:
+        d.in1, d.in1_batch_stride = _batched(x1, 'x1')
+    else:
+        d.in1, d.in1_batch_stride = None, 0
+    d.c0, d.c1 = c0, c1
+    d.batch, d.height, d.width = batch, h, w
+    d.weight = _p(pc.weight, name='packed weight')
+    d.bias = _p(pc.bias, name='bias')
+    d.cout, d.cout_pad = pc.cout, pc.cout_pad
+    d.kh, d.kw, d.stride, d.pad = pc.kh, pc.kw, stride, pad
+    d.relu_in = 1 if relu_in else 0
+    if residual is not None:
+        if tuple(residual.shape[1:]) != (pc.cout, oh, ow):
+            raise DevaHipError('conv2d: residual shape mismatch')
+        d.residual, d.residual_batch_stride = _batched(residual, 'residual')
+    else:
+        d.residual, d.residual_batch_stride = None, 0
+    d.act = act
+    d.out = _p(out, name='out')
+    check(lib().deva_conv2d(d, _stream()), 'deva_conv2d')
+    return out
+
+
+# ------------------------------------------------------------------------------------------ pointwise
+def maxpool3x3s2(x: torch.Tensor, relu_after: bool = False) -> torch.Tensor:
+    b, c, h, w = x.shape
+    out = torch.empty((b, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+    check(lib().deva_maxpool3x3s2(_p(x), _p(out), b * c, h, w, int(relu_after), _stream()), 'deva_maxpool3x3s2')
+    return out
+
+
+def upsample2x_add(x: torch.Tensor, skip: Optional[torch.Tensor]) -> torch.Tensor:
+    """x [B,C,h,w] -> [B,C,2h,2w] bilinear (+ skip [1,C,2h,2w] broadcast over B)"""
+    b, c, h, w = x.shape
+    if skip is not None and tuple(skip.shape[-3:]) != (c, 2 * h, 2 * w):
+        raise DevaHipError('upsample2x_add: skip shape mismatch')
+    out = torch.empty((b, c, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+    check(lib().deva_upsample2x_add(_p(x), _p(skip), _p(out), b, c, h, w, _stream()), 'deva_upsample2x_add')
+    return out
+
+
+def area_downsample(x: torch.Tensor, factor: int) -> torch.Tensor:
+    """[..., H, W] -> [..., H/factor, W/factor] box mean"""
+    h, w = x.shape[-2:]
+    planes = x.numel() // (h * w)
+    out = torch.empty((*x.shape[:-2], h // factor, w // factor), dtype=torch.float32, device=x.device)
+    check(lib().deva_area_downsample(_p(x), _p(out), planes, h, w, factor, _stream()), 'deva_area_downsample')
+    return out
+
+
+def aggregate(prob: torch.Tensor, apply_sigmoid: bool = False) -> torch.Tensor:
+    """[no, ...] object probabilities (fp32, or uint8/bool one-hot) -> [no+1, ...] logits"""
+    no = prob.shape[0]
+    pixels = prob.numel() // max(no, 1)
+    is_u8 = prob.dtype in (torch.uint8, torch.bool)
+    if is_u8:
+        src = _p(prob.view(torch.uint8) if prob.dtype == torch.bool else prob, torch.uint8, 'prob')
+    else:
+        src = _p(prob, name='prob')
+    out = torch.empty((no + 1, *prob.shape[1:]), dtype=torch.float32, device=prob.device)
+    check(lib().deva_aggregate(src, int(is_u8), int(apply_sigmoid), _p(out), no, pixels, _stream()),
+          'deva_aggregate')
+    return out
+
+
+def softmax_channels(x: torch.Tensor) -> torch.Tensor:
+    c = x.shape[0]
+    out = torch.empty_like(x)
+    check(lib().deva_softmax_channels(_p(x), _p(out), c, x.numel() // c, _stream()), 'deva_softmax_channels')
+    return out
+
+
+def upsample4x_softmax(logits: torch.Tensor, need_logits: bool = True):
+    """[C,h,w] -> (logits_up [C,4h,4w] or None, prob [C,4h,4w])"""
+    c, h, w = logits.shape
+    prob = torch.empty((c, 4 * h, 4 * w), dtype=torch.float32, device=logits.device)
+    up = torch.empty_like(prob) if need_logits else None
+    check(lib().deva_upsample4x_softmax(_p(logits), _p(up), _p(prob), c, h, w, _stream()),
+          'deva_upsample4x_softmax')
+    return up, prob
+
+
+def cbam(x: torch.Tensor, w1, b1, w2, b2, spatial: PackedConv) -> torch.Tensor:
+    """returns x + CBAM(x) for x [B,C,h,w]  (cbam.py:21-76 + the residual add of
+    group_modules.py:149)"""
+    b, c, h, w = x.shape
+    hw = h * w
+    dev = x.device
+    avg = torch.empty((b, c), dtype=torch.float32, device=dev)
+    mx = torch.empty_like(avg)
+    check(lib().deva_global_avgmax(_p(x), _p(avg), _p(mx), b * c, hw, _stream()), 'deva_global_avgmax')
+    scale = torch.empty_like(avg)
+    check(lib().deva_cbam_mlp(_p(avg), _p(mx), _p(w1), _p(b1), _p(w2), _p(b2), _p(scale), b, c, w1.shape[0],
+                              _stream()), 'deva_cbam_mlp')
+    pooled = torch.empty((b, 2, h, w), dtype=torch.float32, device=dev)
+    check(lib().deva_cbam_channel_pool(_p(x), _p(scale), _p(pooled), b, c, hw, _stream()),
+          'deva_cbam_channel_pool')
+    gate = conv2d(spatial, pooled, pad=spatial.kh // 2)
+    out = torch.empty_like(x)
+    check(lib().deva_cbam_apply(_p(x), _p(scale), _p(gate), _p(out), b, c, hw, _stream()), 'deva_cbam_apply')
+    return out
+
+
+def gru_update(values: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
+    """values [B,3C,h,w], h [B,C,h,w] -> new h"""
+    b, c = h.shape[:2]
+    hw = h.shape[-2] * h.shape[-1]
+    if values.shape[1] != 3 * c:
+        raise DevaHipError('gru_update: values must have 3x the channels of h')
+    out = torch.empty_like(h)
+    check(lib().deva_gru_update(_p(values), _p(h), _p(out), b, c, hw, _stream()), 'deva_gru_update')
+    return out
+
+
+# ------------------------------------------------------------------------------------------ memory read
+def affinity_topk(key_long, shr_long, n_long: int, key_work, shr_work, n_work: int, qk: torch.Tensor,
+                  qe: torch.Tensor, k: int, usage_fix: Optional[torch.Tensor] = None,
+                  splits: Optional[int] = None):
+    """Fused similarity -> top-k -> softmax.  key_* token-major [>=n,64] arenas, shr_* [>=n];
+    qk/qe [64,hw].  Returns idx int32 [hw,k] (long-then-work token index), weight fp32 [hw,k];
+    adds weight*2^40 into usage_fix (uint64 viewed as int64, [>= n_long+n_work]) if given."""
+    hw = qk.shape[1]
+    if qk.shape[0] != 64 or tuple(qe.shape) != tuple(qk.shape):
+        raise DevaHipError('affinity_topk: queries must be [64, hw]')
+    L = lib()
+    if splits is None:
+        splits = L.deva_affinity_default_splits(n_long + n_work, hw)
+    part = torch.empty((L.deva_affinity_workspace(hw, k, splits),), dtype=torch.int64, device=qk.device)
+    check(L.deva_affinity_topk(_p(key_long) if n_long else None, _p(shr_long) if n_long else None, n_long,
+                               _p(key_work) if n_work else None, _p(shr_work) if n_work else None, n_work,
+                               _p(qk), _p(qe), hw, k, splits, _p(part, torch.int64), _stream()),
+          'deva_affinity_topk')
+    idx = torch.empty((hw, k), dtype=torch.int32, device=qk.device)
+    weight = torch.empty((hw, k), dtype=torch.float32, device=qk.device)
+    check(L.deva_affinity_finalize(_p(part, torch.int64), hw, k, splits, _p(idx, torch.int32), _p(weight),
+                                   _p(usage_fix, torch.int64), _stream()), 'deva_affinity_finalize')
+    return idx, weight
+
+
+def usage_update(usage_fix: torch.Tensor, offset: int, use: Optional[torch.Tensor], life: torch.Tensor,
+                 n: int) -> None:
+    check(lib().deva_usage_update(_p(usage_fix, torch.int64), offset, _p(use), _p(life), n, _stream()),
+          'deva_usage_update')
+
+
+def readout_sparse(idx: torch.Tensor, weight: torch.Tensor, val_long, n_long: int, val_work,
+                   out: torch.Tensor) -> torch.Tensor:
+    """out [cv, hw(...)] = sparse readout of token-major values ([>=n, cv] arenas)"""
+    hw, k = idx.shape
+    cv = out.shape[0]
+    if out.numel() != cv * hw:
+        raise DevaHipError('readout_sparse: bad output shape')
+    check(lib().deva_readout_sparse(_p(idx, torch.int32), _p(weight), hw, k, _p(val_long) if n_long else None,
+                                    n_long, _p(val_work), cv, _p(out), _stream()), 'deva_readout_sparse')
+    return out
+
+
+# ------------------------------------------------------------------------------------------ bank upkeep
+def bank_append(src: torch.Tensor, arena: torch.Tensor, row0: int) -> None:
+    """src [C, n] channel-major -> arena rows row0..row0+n (token-major [cap, C])"""
+    c, n = src.shape
+    if arena.shape[1] != c or row0 + n > arena.shape[0]:
+        raise DevaHipError('bank_append: arena too small or channel mismatch')
+    check(lib().deva_bank_append(_p(src), _p(arena), row0, c, n, _stream()), 'deva_bank_append')
+
+
+def bank_gather_rows(src: torch.Tensor, rows: Optional[torch.Tensor], dst: torch.Tensor, count: int) -> None:
+    c = src.shape[1] if src.dim() == 2 else 1
+    check(lib().deva_bank_gather_rows(_p(src), _p(rows, torch.int32), _p(dst), count, c, _stream()),
+          'deva_bank_gather_rows')
+
+
+def bank_export(arena: torch.Tensor, n: int) -> torch.Tensor:
+    """first n rows of a token-major arena -> channel-major [C, n] (reference layout)"""
+    c = arena.shape[1]
+    out = torch.empty((c, n), dtype=torch.float32, device=arena.device)
+    if n > 0:
+        check(lib().deva_bank_export(_p(arena), _p(out), c, n, _stream()), 'deva_bank_export')
+    return out
+
+
+def rank(x: torch.Tensor, n: int, descending: bool, life: Optional[torch.Tensor] = None):
+    """permutation rank of x[:n] (ties by index); with `life`, ranks x/life and returns it too"""
+    r = torch.empty((n,), dtype=torch.int32, device=x.device)
+    xn = torch.empty((n,), dtype=torch.float32, device=x.device) if life is not None else None
+    check(lib().deva_rank(_p(x), _p(life), _p(xn), n, int(descending), _p(r, torch.int32), _stream()),
+          'deva_rank')
+    return r, xn
+
+
+def rank_select(rank_t: torch.Tensor, k: int) -> torch.Tensor:
+    out = torch.empty((k,), dtype=torch.int32, device=rank_t.device)
+    check(lib().deva_rank_select(_p(rank_t, torch.int32), rank_t.numel(), k, _p(out, torch.int32), _stream()),
+          'deva_rank_select')
+    return out
+
+
+def evict_select(x: torch.Tensor, rank_asc: torch.Tensor, n_remove: int):
+    """survivor rows (x > x at ascending rank n_remove-1), in order; returns (idx int32 [n], count tensor)"""
+    n = rank_asc.numel()
+    idx = torch.empty((n,), dtype=torch.int32, device=x.device)
+    count = torch.zeros((1,), dtype=torch.int32, device=x.device)
+    check(lib().deva_evict_select(_p(x), _p(rank_asc, torch.int32), n, n_remove, _p(idx, torch.int32),
+                                  _p(count, torch.int32), _stream()), 'deva_evict_select')
+    return idx, count
+
+
+def similarity_dense(key: torch.Tensor, shr: torch.Tensor, sel: torch.Tensor, proto_idx: torch.Tensor,
+                     n_cand: int) -> torch.Tensor:
+    """dense [n_cand, ld] similarity of candidates vs prototypes, ld = P rounded up to 32 (zero pad)"""
+    p = proto_idx.numel()
+    ld = (p + 31) // 32 * 32
+    sim = torch.zeros((n_cand, ld), dtype=torch.float32, device=key.device)
+    check(lib().deva_similarity_dense(_p(key), _p(shr), _p(sel), _p(proto_idx, torch.int32), n_cand, p, ld,
+                                      _p(sim), _stream()), 'deva_similarity_dense')
+    return sim
+
+
+def softmax_columns(x: torch.Tensor, p: int) -> torch.Tensor:
+    n, ld = x.shape
+    check(lib().deva_softmax_columns(_p(x), n, p, ld, _stream()), 'deva_softmax_columns')
+    return x

@@ -1,0 +1,228 @@
+"""Parameter tree and execution graph of the DEVA propagation network on libdeva_hip.
+
+Two halves:
+
+* `build_parameter_tree` creates bare `nn.Module` containers whose `state_dict()` has exactly the
+  420 tensor names/shapes of the reference checkpoint (`DEVA-propagation.pth`; reference modules
+  deva/model/big_modules.py, modules.py, group_modules.py, cbam.py, resnet.py).  The modules are
+  parameter holders only -- their `forward` is never called.
+* `CompiledGraph` is built once per weight load: it folds every eval-mode BatchNorm into its
+  convolution, repacks all weights into the [K][cout] layout of `deva_conv2d`, and exposes the
+  four network stages as sequences of HIP kernel launches.
+"""
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from deva.hip import ops
+from deva.hip.ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQUARE_PLUS_ONE, PackedConv
+
+# ------------------------------------------------------------------------------------------------
+# parameter tree (names follow the reference checkpoint)
+# ------------------------------------------------------------------------------------------------
+
+
+def _box(**children) -> nn.Module:
+    m = nn.Module()
+    for name, child in children.items():
+        m.add_module(name, child)
+    return m
+
+
+def _conv(cin, cout, k, stride=1, bias=True) -> nn.Conv2d:
+    return nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=k // 2, bias=bias)
+
+
+def _resnet_stage(kind: str, cin: int, planes: int, blocks: int, stride: int) -> nn.Sequential:
+    """torchvision-style stage; kind 'bottleneck' (expansion 4) or 'basic' (expansion 1)"""
+    exp = 4 if kind == 'bottleneck' else 1
+    layers = []
+    for i in range(blocks):
+        s = stride if i == 0 else 1
+        inp = cin if i == 0 else planes * exp
+        if kind == 'bottleneck':
+            blk = _box(conv1=_conv(inp, planes, 1, bias=False), bn1=nn.BatchNorm2d(planes),
+                       conv2=_conv(planes, planes, 3, stride=s, bias=False), bn2=nn.BatchNorm2d(planes),
+                       conv3=_conv(planes, planes * 4, 1, bias=False), bn3=nn.BatchNorm2d(planes * 4))
+        else:
+            blk = _box(conv1=_conv(inp, planes, 3, stride=s, bias=False), bn1=nn.BatchNorm2d(planes),
+                       conv2=_conv(planes, planes, 3, bias=False), bn2=nn.BatchNorm2d(planes))
+        if i == 0 and (s != 1 or inp != planes * exp):
+            blk.add_module('downsample', nn.Sequential(_conv(inp, planes * exp, 1, stride=s, bias=False),
+                                                       nn.BatchNorm2d(planes * exp)))
+        layers.append(blk)
+    return nn.Sequential(*layers)
+
+
+def _group_res_block(cin: int, cout: int) -> nn.Module:
+    blk = _box(conv1=_conv(cin, cout, 3), conv2=_conv(cout, cout, 3))
+    if cin != cout:
+        blk.add_module('downsample', _conv(cin, cout, 1))
+    return blk
+
+
+def _fusion_block(x_dim: int, g_dim: int, mid: int, out: int) -> nn.Module:
+    mlp = nn.Sequential(nn.Identity(), nn.Linear(mid, mid // 16), nn.Identity(), nn.Linear(mid // 16, mid))
+    attention = _box(ChannelGate=_box(mlp=mlp), SpatialGate=_box(spatial=_box(conv=_conv(2, 1, 7))))
+    return _box(block1=_group_res_block(x_dim + g_dim, mid), attention=attention,
+                block2=_group_res_block(mid, out))
+
+
+def build_parameter_tree(pix_feat_dim: int, key_dim: int, value_dim: int) -> Dict[str, nn.Module]:
+    pixel_encoder = _box(conv1=_conv(3, 64, 7, stride=2, bias=False), bn1=nn.BatchNorm2d(64),
+                         res2=_resnet_stage('bottleneck', 64, 64, 3, 1),
+                         layer2=_resnet_stage('bottleneck', 256, 128, 4, 2),
+                         layer3=_resnet_stage('bottleneck', 512, 256, 6, 2),
+                         proj1=_conv(1024, pix_feat_dim, 1), proj2=_conv(1024, pix_feat_dim, 1))
+    mask_encoder = _box(conv1=_conv(4, 64, 7, stride=2, bias=False), bn1=nn.BatchNorm2d(64),
+                        layer1=_resnet_stage('basic', 64, 64, 2, 1),
+                        layer2=_resnet_stage('basic', 64, 128, 2, 2),
+                        layer3=_resnet_stage('basic', 128, 256, 2, 2),
+                        fuser=_fusion_block(pix_feat_dim, 256, value_dim, value_dim),
+                        sensory_update=_box(transform=_conv(value_dim * 2, value_dim * 3, 3)))
+    key_proj = _box(key_proj=_conv(pix_feat_dim, key_dim, 3), d_proj=_conv(pix_feat_dim, 1, 3),
+                    e_proj=_conv(pix_feat_dim, key_dim, 3))
+    mask_decoder = _box(
+        fuser=_fusion_block(512, value_dim, value_dim, value_dim),
+        sensory_compress=_conv(value_dim + 1, value_dim, 1),
+        sensory_update=_box(g16_conv=_conv(value_dim, 512, 1), g8_conv=_conv(256, 512, 1),
+                            g4_conv=_conv(256 + 1, 512, 1), transform=_conv(512 + 512, 512 * 3, 3)),
+        decoder_feat_proc=_box(transforms=nn.ModuleList([_conv(512, value_dim, 1), _conv(256, 256, 1)])),
+        up_16_8=_box(out_conv=_group_res_block(value_dim, 256)),
+        up_8_4=_box(out_conv=_group_res_block(256, 256)),
+        pred=_conv(256, 1, 3),
+        sensory_linear_pred=_box(projection=_conv(value_dim, 512 + 1, 1)))
+    return dict(pixel_encoder=pixel_encoder, mask_encoder=mask_encoder, key_proj=key_proj,
+                mask_decoder=mask_decoder)
+
+
+# ------------------------------------------------------------------------------------------------
+# compiled graph
+# ------------------------------------------------------------------------------------------------
+
+
+class CompiledGraph:
+    """Packed weights + the launch sequences of the four stages (all tensors fp32 NCHW on HIP)."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], device: torch.device):
+        ops.require_hip(device, 'DEVA network')
+        self.device = device
+        self.sd = sd
+        self.convs: Dict[str, PackedConv] = {}
+        self.vecs: Dict[str, torch.Tensor] = {}
+        for name in sd:
+            if not name.endswith('.weight') or sd[name].dim() != 4:
+                continue
+            base = name[:-len('.weight')]
+            self.convs[base] = ops.pack_conv(sd[name], sd.get(base + '.bias'), self._bn_after(base), device)
+        for name, t in sd.items():
+            if '.ChannelGate.mlp.' in name:
+                self.vecs[name] = t.detach().float().contiguous().to(device)
+
+    def _bn_after(self, conv: str):
+        """the BatchNorm that follows `conv` in the ResNets: convN -> bnN, downsample.0 -> downsample.1"""
+        head, leaf = conv.rsplit('.', 1)
+        if leaf.startswith('conv') and (head + '.bn' + leaf[4:] + '.running_mean') in self.sd:
+            bn = head + '.bn' + leaf[4:]
+        elif leaf == '0' and (head + '.1.running_mean') in self.sd:
+            bn = head + '.1'
+        else:
+            return None
+        g = self.sd
+        return (g[bn + '.weight'], g[bn + '.bias'], g[bn + '.running_mean'], g[bn + '.running_var'], 1e-5)
+
+    # ---------------------------------------------------------------- building blocks
+    def _bottleneck(self, pre: str, x, stride: int):
+        c = self.convs
+        y = ops.conv2d(c[pre + '.conv1'], x, act=ACT_RELU)
+        y = ops.conv2d(c[pre + '.conv2'], y, stride=stride, pad=1, act=ACT_RELU)
+        if (pre + '.downsample.0') in c:
+            x = ops.conv2d(c[pre + '.downsample.0'], x, stride=stride)
+        return ops.conv2d(c[pre + '.conv3'], y, residual=x, act=ACT_RELU)
+
+    def _basic(self, pre: str, x, stride: int):
+        c = self.convs
+        y = ops.conv2d(c[pre + '.conv1'], x, stride=stride, pad=1, act=ACT_RELU)
+        if (pre + '.downsample.0') in c:
+            x = ops.conv2d(c[pre + '.downsample.0'], x, stride=stride)
+        return ops.conv2d(c[pre + '.conv2'], y, pad=1, residual=x, act=ACT_RELU)
+
+    def _stage(self, pre: str, x, blocks: int, stride: int, block_fn):
+        for i in range(blocks):
+            x = block_fn(f'{pre}.{i}', x, stride if i == 0 else 1)
+        return x
+
+    def _res_block(self, pre: str, g0, g1=None):
+        """relu -> 3x3 -> relu -> 3x3, plus (1x1-projected) input; input = virtual cat(g0, g1)"""
+        c = self.convs
+        t = ops.conv2d(c[pre + '.conv1'], g0, g1, pad=1, relu_in=True)
+        if (pre + '.downsample') in c:
+            skip = ops.conv2d(c[pre + '.downsample'], g0, g1)
+        else:
+            assert g1 is None
+            skip = g0
+        return ops.conv2d(c[pre + '.conv2'], t, pad=1, relu_in=True, residual=skip)
+
+    def _fusion(self, pre: str, x, g):
+        """x [1,Cx,h,w] image feature (broadcast over objects), g [no,Cg,h,w]"""
+        g = self._res_block(pre + '.block1', x, g)
+        a = pre + '.attention.ChannelGate.mlp.'
+        g = ops.cbam(g, self.vecs[a + '1.weight'], self.vecs[a + '1.bias'], self.vecs[a + '3.weight'],
+                     self.vecs[a + '3.bias'], self.convs[pre + '.attention.SpatialGate.spatial.conv'])
+        return self._res_block(pre + '.block2', g)
+
+    def _gru(self, conv: str, g, h):
+        return ops.gru_update(ops.conv2d(self.convs[conv], g, h, pad=1), h)
+
+    # ---------------------------------------------------------------- stages
+    def encode_image(self, image):
+        c = self.convs
+        pe = 'pixel_encoder'
+        x = ops.conv2d(c[pe + '.conv1'], image, stride=2, pad=3, act=ACT_RELU)
+        x = ops.maxpool3x3s2(x)
+        f4 = self._stage(pe + '.res2', x, 3, 1, self._bottleneck)
+        f8 = self._stage(pe + '.layer2', f4, 4, 2, self._bottleneck)
+        f16 = self._stage(pe + '.layer3', f8, 6, 2, self._bottleneck)
+        return (ops.conv2d(c[pe + '.proj1'], f16), f8, f4), ops.conv2d(c[pe + '.proj2'], f16)
+
+    def transform_key(self, feat, need_s: bool, need_e: bool):
+        c = self.convs
+        shrinkage = ops.conv2d(c['key_proj.d_proj'], feat, pad=1, act=ACT_SQUARE_PLUS_ONE) if need_s else None
+        selection = ops.conv2d(c['key_proj.e_proj'], feat, pad=1, act=ACT_SIGMOID) if need_e else None
+        return ops.conv2d(c['key_proj.key_proj'], feat, pad=1), shrinkage, selection
+
+    def encode_mask(self, image, f16, sensory, masks, deep_update: bool):
+        """image [1,3,H,W]; masks [no,1,H,W]; sensory [no,C,h,w] -> value [no,C,h,w], sensory'"""
+        c = self.convs
+        me = 'mask_encoder'
+        g = ops.conv2d(c[me + '.conv1'], image, masks, stride=2, pad=3)
+        g = ops.maxpool3x3s2(g, relu_after=True)
+        g = self._stage(me + '.layer1', g, 2, 1, self._basic)
+        g = self._stage(me + '.layer2', g, 2, 2, self._basic)
+        g = self._stage(me + '.layer3', g, 2, 2, self._basic)
+        value = self._fusion(me + '.fuser', f16, g)
+        if deep_update:
+            sensory = self._gru(me + '.sensory_update.transform', value, sensory)
+        return value, sensory
+
+    def decode(self, ms_features, readout, sensory, last_mask16, update_sensory: bool):
+        """readout/sensory [no,C,h,w]; last_mask16 [no,1,h,w] -> sensory', object logits [no,1,4h,4w]"""
+        c = self.convs
+        md = 'mask_decoder'
+        f16, f8, f4 = ms_features
+        d8 = ops.conv2d(c[md + '.decoder_feat_proc.transforms.0'], f8)
+        d4 = ops.conv2d(c[md + '.decoder_feat_proc.transforms.1'], f4)
+        p16 = ops.conv2d(c[md + '.sensory_compress'], sensory, last_mask16, residual=readout)
+        p16 = self._fusion(md + '.fuser', f16, p16)
+        p8 = self._res_block(md + '.up_16_8.out_conv', ops.upsample2x_add(p16, d8))
+        p4 = self._res_block(md + '.up_8_4.out_conv', ops.upsample2x_add(p8, d4))
+        logits = ops.conv2d(c[md + '.pred'], p4, pad=1, relu_in=True)
+        if update_sensory:
+            su = md + '.sensory_update'
+            g = ops.conv2d(c[su + '.g16_conv'], p16)
+            g = ops.conv2d(c[su + '.g8_conv'], ops.area_downsample(p8, 2), residual=g)
+            g = ops.conv2d(c[su + '.g4_conv'], ops.area_downsample(p4, 4), ops.area_downsample(logits, 4),
+                           residual=g)
+            sensory = self._gru(su + '.transform', g, sensory)
+        return sensory, logits
