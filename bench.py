@@ -1,0 +1,285 @@
+#!/usr/bin/env python
+"""Propagation-FPS benchmark of the MI355X-native DEVA hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one propagated frame: `DEVAInferenceCore.step(image)` = key encoder -> memory affinity
++ readout -> mask decoder (-> value encoder + memory append on every `mem_every`-th frame), timed
+exactly like evaluation/eval_vos.py:150-186 but over the whole K-frame region.
+
+Workload at N=1 (config.workload): BASELINE.json configs[1] -- DAVIS-2017-style 480p (854x480 ->
+padded 480x864), 5 objects, working memory only, synthetic temporally-coherent frames, recipe
+weights (the checkpoint is a download; oracle/weights.py).  Frames are resident in HBM before the
+timed region.  N>1: independent clips, one per GPU (replicas; RCCL is used only for the barrier
+and the max-over-ranks reduction) -> "scaling": "weak".
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (conv implicit GEMM, fp32 MFMA): algorithmic FLOPs of every launch
+                / its HIP-event duration, measured in an instrumented pass right after the timed
+                region (so event overhead never touches `value`); peak = 157.3 TFLOP/s fp32 matrix.
+  affinity      the north-star kernel (fused similarity/top-k/softmax): event-timed at the
+                BASELINE shape (N=10 000 bank, 1080p queries), reported against the fp32-MFMA roof
+                that binds it and as HBM GB/s on algorithmic and on materialised-equivalent bytes
+                (SURVEY.md §8d asks for all three).
+  cpu_baseline  the CPU oracle (port of the reference's PyTorch path) on the same workload, on this
+                box's host cores, for a bounded sample of frames.
+  extra         1080p / 10k-token long-term bank propagation FPS (BASELINE target line).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'tracking-anything-with-deva_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md, dense fp32-in MFMA
+PEAK_HBM_GBPS = 8000.0
+
+
+def build_network(device):
+    from oracle import synth, weights
+    from deva.model.network import DEVA
+    with open(os.path.join(ROOT, 'tests', 'golden', 'state_dict_spec.json')) as f:
+        spec = json.load(f)['tensors']
+    sd = weights.make_state_dict([(k, tuple(s), getattr(torch, d)) for k, s, d in spec], seed=0)
+    net = DEVA(synth.base_config())
+    net.load_weights(sd)
+    return net.to(device).eval(), sd
+
+
+def make_clip(height, width, n_frames, seed, device):
+    from oracle import synth
+    stream = synth.FrameStream(height, width, seed=seed)
+    return [stream.next().to(device) for _ in range(n_frames)]
+
+
+def start_clip(net, cfg, frames, num_objects, device, lt_prefill=0):
+    """annotated first frame (+ optional pre-filled long-term bank)"""
+    from oracle import synth
+    from deva.inference.inference_core import DEVAInferenceCore
+    core = DEVAInferenceCore(net, cfg)
+    h, w = frames[0].shape[-2:]
+    mask = synth.box_mask(h, w, num_objects).to(device)
+    core.step(frames[0], mask, list(range(1, num_objects + 1)))
+    if lt_prefill:
+        g = torch.Generator().manual_seed(1)
+        key = torch.randn(64, lt_prefill, generator=g).to(device)
+        shr = (torch.rand(1, lt_prefill, generator=g) + 1).to(device)
+        vals = {o: torch.randn(512, lt_prefill, generator=g).to(device) for o in range(1, num_objects + 1)}
+        core.memory.long_mem.add(key, vals, shr, selection=None, supposed_bucket_id=0)
+    return core
+
+
+class ConvTimer:
+    """HIP-event timing of every deva_conv2d launch (events on torch's current stream, which is the
+    stream the kernels are launched on)"""
+
+    def __init__(self):
+        from deva.hip import ops
+        self.ops = ops
+        self.real = ops.conv2d
+        self.records = []
+
+    def __enter__(self):
+        def timed(pc, x0, x1=None, **kw):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = self.real(pc, x0, x1, **kw)
+            e.record()
+            self.records.append((2.0 * pc.cout * pc.cin * pc.kh * pc.kw * out.shape[0] * out.shape[2] * out.shape[3],
+                                 s, e))
+            return out
+
+        self.ops.conv2d = timed
+        return self
+
+    def __exit__(self, *a):
+        self.ops.conv2d = self.real
+        torch.cuda.synchronize()
+
+    def summary(self):
+        flops = sum(r[0] for r in self.records)
+        ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
+        return flops, ms, len(self.records)
+
+
+def affinity_microbench(device, n=10000, hw=8160, k=30, iters=20):
+    from deva.hip import ops
+    g = torch.Generator().manual_seed(0)
+    key = torch.randn(n, 64, generator=g).to(device)
+    shr = (torch.rand(n, generator=g) + 1).to(device)
+    qk = torch.randn(64, hw, generator=g).to(device)
+    qe = torch.rand(64, hw, generator=g).to(device)
+    fix = torch.zeros(n, dtype=torch.int64, device=device)
+    L = __import__('deva.hip', fromlist=['lib']).lib()
+    splits = L.deva_affinity_default_splits(n, hw)
+    part = torch.empty((L.deva_affinity_workspace(hw, k, splits),), dtype=torch.int64, device=device)
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        ops.affinity_topk(None, None, 0, key, shr, n, qk, qe, k, fix)
+    torch.cuda.synchronize()
+    t_main = t_fin = 0.0
+    idx = torch.empty((hw, k), dtype=torch.int32, device=device)
+    wgt = torch.empty((hw, k), dtype=torch.float32, device=device)
+    for _ in range(iters):
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        L.deva_affinity_topk(None, None, 0, key.data_ptr(), shr.data_ptr(), n, qk.data_ptr(), qe.data_ptr(), hw, k,
+                             splits, part.data_ptr(), st)
+        e1.record()
+        L.deva_affinity_finalize(part.data_ptr(), hw, k, splits, idx.data_ptr(), wgt.data_ptr(), fix.data_ptr(), st)
+        e2.record()
+        torch.cuda.synchronize()
+        t_main += e0.elapsed_time(e1)
+        t_fin += e1.elapsed_time(e2)
+    t_main, t_fin = t_main / iters * 1e-3, t_fin / iters * 1e-3
+    flops = 4.0 * 64 * n * hw
+    b_alg = 4.0 * (64 * n + n + 2 * 64 * hw) + 8.0 * k * hw + 4.0 * n
+    b_mat = 12.0 * 4 * n * hw
+    t = t_main + t_fin
+    return dict(shape=dict(n=n, hw=hw, k=k, splits=splits), us_topk=t_main * 1e6, us_finalize=t_fin * 1e6,
+                bound='mfma_fp32', achieved_tflops=flops / t / 1e12, peak_tflops=PEAK_FP32_MATRIX_TFLOPS,
+                frac=flops / t / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
+                hbm_algorithmic_gbps=b_alg / t / 1e9, hbm_algorithmic_frac=b_alg / t / 1e9 / PEAK_HBM_GBPS,
+                hbm_materialised_equiv_gbps=b_mat / t / 1e9)
+
+
+def cpu_baseline(sd, cfg, height, width, num_objects, frames_cpu):
+    from oracle import deva_oracle as O
+    from oracle import synth
+    core = O.OracleCore(sd, cfg)
+    mask = synth.box_mask(height, width, num_objects)
+    core.step(frames_cpu[0], mask, list(range(1, num_objects + 1)))
+    t0 = time.perf_counter()
+    for f in frames_cpu[1:]:
+        core.step(f)
+    dt = time.perf_counter() - t0
+    n = len(frames_cpu) - 1
+    return dict(value=n / dt, unit='frames/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'{n} propagated frames after the annotated one, same workload (CPU oracle, fp32)')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--height', type=int, default=480)
+    ap.add_argument('--width', type=int, default=854)
+    ap.add_argument('--objects', type=int, default=5)
+    ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--no_extra', action='store_true')
+    args = ap.parse_args()
+
+    torch.set_grad_enabled(False)
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    distributed = world > 1
+    device = torch.device(f'cuda:{local_rank}')
+    torch.cuda.set_device(device)
+    if distributed:
+        import torch.distributed as dist
+        dist.init_process_group(backend='nccl')  # RCCL on ROCm
+
+    from oracle import synth
+    net, sd = build_network(device)
+    cfg = synth.base_config(enable_long_term=False, enable_long_term_count_usage=False)
+    n_frames = 1 + args.warmup + args.steps
+    frames = make_clip(args.height, args.width, n_frames, seed=100 + rank, device=device)  # HBM resident
+
+    core = start_clip(net, cfg, frames, args.objects, device)
+    for t in range(1, 1 + args.warmup):
+        core.step(frames[t])
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for t in range(1 + args.warmup, n_frames):
+        core.step(frames[t])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        tt = torch.tensor([elapsed], device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    bank = {b: core.memory.work_mem.size(b) for b in core.memory.work_mem.buckets}
+
+    result = {
+        'metric': 'propagation FPS @480p (5 objects, working memory only)',
+        'value': world * args.steps / elapsed,
+        'unit': 'frames/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': elapsed / args.steps * 1e3,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {
+            'workload': f'BASELINE configs[1]: DAVIS-2017-style {args.width}x{args.height} clip, {args.objects} objects, '
+                        f'working memory only (mem_every=5, top_k=30), recipe weights, one clip per GPU',
+            'frame_padded': [frames[0].shape[-2] + (-frames[0].shape[-2]) % 16, frames[0].shape[-1] + (-frames[0].shape[-1]) % 16],
+            'bank_tokens_at_end': bank,
+            'parallelism': f'replicas x{world}',
+        },
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel, instrumented pass continuing the same clip
+        extra_frames = make_clip(args.height, args.width, 5, seed=999, device=device)
+        with ConvTimer() as ct:
+            for f in extra_frames:
+                core.step(f)
+        flops, ms, launches = ct.summary()
+        ach = flops / (ms * 1e-3) / 1e12
+        result['roofline'] = {
+            'kernel': 'conv_igemm_kernel (deva_conv2d, fp32 MFMA implicit GEMM)',
+            'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MATRIX_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': ach / PEAK_FP32_MATRIX_TFLOPS, 'traffic': None,
+            'launches_per_frame': launches / len(extra_frames),
+            'gflop_per_frame': flops / len(extra_frames) / 1e9,
+            'ms_in_kernel_per_frame': ms / len(extra_frames),
+        }
+        result['affinity'] = affinity_microbench(device)
+        if not args.no_extra:
+            cfg_lt = synth.base_config()
+            f1080 = make_clip(1080, 1920, 12, seed=7, device=device)
+            core2 = start_clip(net, cfg_lt, f1080, 1, device, lt_prefill=10000)
+            core2.step(f1080[1])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for f in f1080[2:]:
+                core2.step(f)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            result['extra'] = {
+                'fps_1080p_1obj_10k_longterm_bank': (len(f1080) - 2) / dt,
+                'note': 'BASELINE target line: 1920x1080 (padded 1088x1920), 1 object, long-term memory '
+                        'pre-filled with 10 000 tokens + working memory, 10 propagated frames',
+            }
+        if not args.no_cpu_baseline and world == 1:
+            n_cpu = 4
+            frames_cpu = [f.cpu() for f in frames[:1 + n_cpu]]
+            result['cpu_baseline'] = cpu_baseline(sd, cfg, args.height, args.width, args.objects, frames_cpu)
+        print(json.dumps(result))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,77 @@
+"""deva_conv2d (implicit-GEMM fp32 MFMA) against F.conv2d on the CPU: every geometry the network
+uses plus ragged / tiny / padded edge cases.  Tolerance: fp32 accumulation-order noise only."""
+import zlib
+
+import pytest
+import torch
+
+import emu_ops
+from deva.hip import ops
+from gpu_util import dev, max_err, rand, rel_err, to_dev
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+# (name, c0, c1, cout, k, stride, pad, batch, H, W, b0_bcast, relu_in, residual('none'|'full'|'bcast'), act, bias, bn)
+CASES = [
+    ('stem7x7_rgb', 3, 0, 64, 7, 2, 3, 1, 70, 94, False, False, 'none', ops.ACT_RELU, False, True),
+    ('stem7x7_rgb+mask', 3, 1, 64, 7, 2, 3, 3, 64, 96, True, False, 'none', ops.ACT_NONE, False, True),
+    ('bottleneck1x1', 64, 0, 256, 1, 1, 0, 1, 24, 32, False, False, 'full', ops.ACT_RELU, False, True),
+    ('bottleneck3x3s2', 128, 0, 128, 3, 2, 1, 1, 24, 32, False, False, 'none', ops.ACT_RELU, False, True),
+    ('down1x1s2', 256, 0, 512, 1, 2, 0, 1, 24, 32, False, False, 'none', ops.ACT_NONE, False, True),
+    ('proj1x1_bias', 1024, 0, 512, 1, 1, 0, 1, 6, 8, False, False, 'none', ops.ACT_NONE, True, False),
+    ('key3x3_64', 512, 0, 64, 3, 1, 1, 1, 6, 8, False, False, 'none', ops.ACT_NONE, True, False),
+    ('shrinkage_cout1', 512, 0, 1, 3, 1, 1, 1, 6, 8, False, False, 'none', ops.ACT_SQUARE_PLUS_ONE, True, False),
+    ('selection_sigmoid', 512, 0, 64, 3, 1, 1, 1, 6, 8, False, False, 'none', ops.ACT_SIGMOID, True, False),
+    ('fuse_cat_relu_in', 512, 256, 512, 3, 1, 1, 2, 6, 8, True, True, 'none', ops.ACT_NONE, True, False),
+    ('fuse_cat_1x1', 512, 512, 512, 1, 1, 0, 3, 6, 8, True, False, 'none', ops.ACT_NONE, True, False),
+    ('resblock_conv2_res', 512, 0, 512, 3, 1, 1, 2, 6, 8, False, True, 'full', ops.ACT_NONE, True, False),
+    ('compress_513', 512, 1, 512, 1, 1, 0, 2, 6, 8, False, False, 'full', ops.ACT_NONE, True, False),
+    ('g4_257_res', 256, 1, 512, 1, 1, 0, 2, 6, 8, False, False, 'full', ops.ACT_NONE, True, False),
+    ('gru_transform', 512, 512, 1536, 3, 1, 1, 2, 6, 8, False, False, 'none', ops.ACT_NONE, True, False),
+    ('up8_4_256', 256, 0, 256, 3, 1, 1, 2, 24, 32, False, True, 'full', ops.ACT_NONE, True, False),
+    ('pred_cout1', 256, 0, 1, 3, 1, 1, 2, 24, 32, False, True, 'none', ops.ACT_NONE, True, False),
+    ('cbam_gate7x7', 2, 0, 1, 7, 1, 3, 2, 6, 8, False, False, 'none', ops.ACT_NONE, True, False),
+    ('skip_bcast_res', 256, 0, 256, 1, 1, 0, 3, 12, 16, False, False, 'bcast', ops.ACT_NONE, True, False),
+    ('ragged_all', 37, 5, 45, 3, 1, 1, 2, 7, 9, False, True, 'full', ops.ACT_RELU, True, False),
+    ('one_pixel', 240, 0, 32, 1, 1, 0, 1, 1, 1, False, False, 'none', ops.ACT_NONE, False, False),
+    ('gemm_as_conv', 240, 0, 32, 1, 1, 0, 1, 1, 512, False, False, 'none', ops.ACT_NONE, False, False),
+    ('big_tile_128', 256, 0, 256, 3, 1, 1, 4, 60, 108, False, False, 'none', ops.ACT_RELU, True, False),
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+def test_conv_matches_cpu(case):
+    name, c0, c1, cout, k, stride, pad, batch, H, W, bcast0, relu_in, res, act, bias, bn = case
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 100000)
+    cin = c0 + c1
+    w = rand(g, cout, cin, k, k, scale=(2.0 / (cin * k * k))**0.5)
+    b = rand(g, cout, scale=0.1) if bias else None
+    bn_p = None
+    if bn:
+        bn_p = (torch.rand(cout, generator=g) + 0.5, rand(g, cout, scale=0.1), rand(g, cout, scale=0.1),
+                torch.rand(cout, generator=g) + 0.5, 1e-5)
+    pc = ops.pack_conv(w, b, bn_p)
+    x0 = rand(g, 1 if bcast0 else batch, c0, H, W)
+    x1 = rand(g, batch, c1, H, W) if c1 else None
+    oh, ow = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    residual = None
+    if res == 'full':
+        residual = rand(g, batch, cout, oh, ow)
+    elif res == 'bcast':
+        residual = rand(g, 1, cout, oh, ow)
+        x0 = rand(g, batch, c0, H, W)
+    want = emu_ops.conv2d(pc, x0, x1, stride=stride, pad=pad, relu_in=relu_in, residual=residual, act=act)
+    got = ops.conv2d(to_dev(pc), to_dev(x0), to_dev(x1), stride=stride, pad=pad, relu_in=relu_in,
+                     residual=to_dev(residual), act=act)
+    torch.cuda.synchronize()
+    assert got.shape == want.shape
+    err = max_err(got, want)
+    print(f'{name}: max abs err {err:.3e} (|ref|max {want.abs().max().item():.3e})')
+    assert err <= 2e-5 * max(1.0, want.abs().max().item()), (name, err)
+
+
+def test_conv_rejects_cpu_tensors():
+    pc = ops.pack_conv(torch.zeros(32, 16, 1, 1))
+    with pytest.raises(Exception):
+        ops.conv2d(pc, torch.zeros(1, 16, 4, 4))

@@ -1,0 +1,87 @@
+"""pooling / resampling / CBAM / GRU / aggregate kernels against their PyTorch definitions."""
+import pytest
+import torch
+
+import emu_ops
+from deva.hip import ops
+from gpu_util import dev, max_err, rand, to_dev
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def _check(name, got, want, tol=1e-5):
+    torch.cuda.synchronize()
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    err = max_err(got, want)
+    print(f'{name}: max abs err {err:.3e}')
+    assert err <= tol * max(1.0, want.abs().max().item()), (name, err)
+
+
+@pytest.mark.parametrize('shape', [(1, 64, 48, 64), (2, 8, 45, 65), (1, 3, 1, 1), (3, 5, 2, 7)])
+@pytest.mark.parametrize('relu', [False, True])
+def test_maxpool(shape, relu):
+    x = rand(torch.Generator().manual_seed(1), *shape)
+    _check('maxpool', ops.maxpool3x3s2(to_dev(x), relu), emu_ops.maxpool3x3s2(x, relu), 0)
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 6, 8), (1, 3, 1, 1), (3, 5, 7, 9)])
+@pytest.mark.parametrize('with_skip', [False, True])
+def test_upsample2x_add(shape, with_skip):
+    g = torch.Generator().manual_seed(2)
+    x = rand(g, *shape)
+    skip = rand(g, 1, shape[1], 2 * shape[2], 2 * shape[3]) if with_skip else None
+    _check('up2x', ops.upsample2x_add(to_dev(x), to_dev(skip)), emu_ops.upsample2x_add(x, skip))
+
+
+@pytest.mark.parametrize('shape,f', [((2, 5, 32, 48), 16), ((3, 7, 8, 12), 2), ((2, 1, 8, 12), 4), ((1, 2, 3, 3), 1)])
+def test_area_downsample(shape, f):
+    x = rand(torch.Generator().manual_seed(3), *shape)
+    _check('area', ops.area_downsample(to_dev(x), f), emu_ops.area_downsample(x, f))
+
+
+@pytest.mark.parametrize('no', [1, 2, 5])
+def test_aggregate_and_softmax(no):
+    g = torch.Generator().manual_seed(4)
+    logits = rand(g, no, 24, 33, scale=4.0)
+    _check('aggregate_sigmoid', ops.aggregate(to_dev(logits), True), emu_ops.aggregate(logits, True), 2e-6)
+    prob = torch.rand(no, 24, 33, generator=g)
+    prob[0, :3] = 0.0
+    prob[0, 3:6] = 1.0  # exercise the clamp
+    agg = emu_ops.aggregate(prob)
+    _check('aggregate_prob', ops.aggregate(to_dev(prob)), agg, 2e-6)
+    onehot = (torch.rand(24, 33, generator=g) * (no + 1)).long()
+    onehot = torch.stack([onehot == i + 1 for i in range(no)], 0)
+    _check('aggregate_bool', ops.aggregate(to_dev(onehot)), emu_ops.aggregate(onehot), 2e-6)
+    _check('softmax_channels', ops.softmax_channels(to_dev(agg)), emu_ops.softmax_channels(agg), 2e-6)
+
+
+@pytest.mark.parametrize('c,h,w', [(3, 6, 8), (6, 24, 32), (1, 1, 1), (2, 5, 3)])
+def test_upsample4x_softmax(c, h, w):
+    x = rand(torch.Generator().manual_seed(5), c, h, w, scale=5.0)
+    up, prob = ops.upsample4x_softmax(to_dev(x))
+    wup, wprob = emu_ops.upsample4x_softmax(x)
+    _check('up4x_logits', up, wup, 2e-6)
+    _check('up4x_prob', prob, wprob, 2e-6)
+    _, prob2 = ops.upsample4x_softmax(to_dev(x), need_logits=False)
+    _check('up4x_prob_only', prob2, wprob, 2e-6)
+
+
+@pytest.mark.parametrize('b,c,h,w', [(2, 512, 6, 8), (1, 512, 30, 54), (3, 64, 5, 7)])
+def test_cbam(b, c, h, w):
+    g = torch.Generator().manual_seed(6)
+    x = rand(g, b, c, h, w)
+    hid = c // 16
+    w1, b1 = rand(g, hid, c, scale=c**-0.5), rand(g, hid, scale=0.1)
+    w2, b2 = rand(g, c, hid, scale=hid**-0.5), rand(g, c, scale=0.1)
+    sp = ops.pack_conv(rand(g, 1, 2, 7, 7, scale=0.2), rand(g, 1, scale=0.1))
+    want = emu_ops.cbam(x, w1, b1, w2, b2, sp)
+    got = ops.cbam(to_dev(x), to_dev(w1), to_dev(b1), to_dev(w2), to_dev(b2), to_dev(sp))
+    _check('cbam', got, want, 1e-5)
+
+
+@pytest.mark.parametrize('b,c,h,w', [(2, 512, 6, 8), (1, 16, 3, 5)])
+def test_gru(b, c, h, w):
+    g = torch.Generator().manual_seed(7)
+    v, hh = rand(g, b, 3 * c, h, w, scale=2.0), rand(g, b, c, h, w)
+    _check('gru', ops.gru_update(to_dev(v), to_dev(hh)), emu_ops.gru_update(v, hh), 2e-6)

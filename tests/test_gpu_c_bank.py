@@ -1,0 +1,88 @@
+"""bank maintenance kernels (append / gather / export / rank / eviction / consolidation pieces)."""
+import pytest
+import torch
+
+import emu_ops
+from deva.hip import ops
+from gpu_util import dev, max_err, rand, to_dev
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.mark.parametrize('c,n', [(64, 48), (512, 1620), (1, 37), (64, 33), (7, 1)])
+def test_append_export_roundtrip(c, n):
+    g = torch.Generator().manual_seed(1)
+    src = rand(g, c, n)
+    arena = torch.full((n + 50, c), -7.0, device=dev())
+    ops.bank_append(to_dev(src), arena, 13)
+    torch.cuda.synchronize()
+    assert torch.equal(arena[13:13 + n].cpu(), src.t())
+    assert (arena[:13] == -7).all() and (arena[13 + n:] == -7).all()
+    back = ops.bank_export(arena[13:13 + n], n)
+    assert torch.equal(back.cpu(), src)
+
+
+def test_gather_rows():
+    g = torch.Generator().manual_seed(2)
+    src = rand(g, 200, 64)
+    rows = torch.randperm(200, generator=g)[:77].int()
+    dst = torch.zeros(77, 64, device=dev())
+    ops.bank_gather_rows(to_dev(src), to_dev(rows), dst, 77)
+    assert torch.equal(dst.cpu(), src[rows.long()])
+    dst1 = torch.zeros(50, device=dev())
+    v = rand(g, 300)
+    ops.bank_gather_rows(to_dev(v)[100:150], None, dst1, 50)
+    assert torch.equal(dst1.cpu(), v[100:150])
+
+
+@pytest.mark.parametrize('n', [1, 5, 300, 1000, 8100])
+@pytest.mark.parametrize('desc', [False, True])
+def test_rank_is_stable_sort_position(n, desc):
+    g = torch.Generator().manual_seed(3 + n)
+    x = (torch.rand(n, generator=g) * 20).round() / 20  # many exact ties
+    want, _ = emu_ops.rank(x, n, desc)
+    got, _ = ops.rank(to_dev(x), n, desc)
+    assert torch.equal(got.cpu(), want)
+    use, life = torch.rand(n, generator=g), torch.rand(n, generator=g) + 0.5
+    want, wx = emu_ops.rank(use, n, desc, life=life)
+    got, gx = ops.rank(to_dev(use), n, desc, life=to_dev(life))
+    assert torch.equal(gx.cpu(), wx) and torch.equal(got.cpu(), want)
+    if n >= 5:
+        k = min(128, n)
+        sel = ops.rank_select(got, k)
+        assert torch.equal(sel.cpu(), emu_ops.rank_select(want, k))
+
+
+@pytest.mark.parametrize('n,n_remove', [(64, 16), (3000, 1), (3000, 2999), (5000, 1234)])
+def test_evict_select(n, n_remove):
+    g = torch.Generator().manual_seed(4)
+    x = (torch.rand(n, generator=g) * 50).round() / 50
+    r, _ = emu_ops.rank(x, n, False)
+    widx, wcount = emu_ops.evict_select(x, r, n_remove)
+    gidx, gcount = ops.evict_select(to_dev(x), to_dev(r), n_remove)
+    c = int(gcount.item())
+    assert c == int(wcount.item())
+    assert torch.equal(gidx[:c].cpu(), widx[:c])
+
+
+@pytest.mark.parametrize('nc,p', [(240, 32), (1000, 128), (77, 5)])
+def test_similarity_dense_and_softmax_columns(nc, p):
+    g = torch.Generator().manual_seed(5)
+    key, shr, sel = rand(g, nc, 64, scale=2.0), torch.rand(nc, generator=g) + 1, torch.rand(nc, 64, generator=g)
+    proto = torch.randperm(nc, generator=g)[:p].int()
+    want = emu_ops.similarity_dense(key, shr, sel, proto, nc)
+    got = ops.similarity_dense(to_dev(key), to_dev(shr), to_dev(sel), to_dev(proto), nc)
+    err = max_err(got, want)
+    print(f'similarity_dense {nc}x{p}: max abs err {err:.3e} (|ref| max {want.abs().max():.3e})')
+    assert err <= 1e-5 * want.abs().max().item()
+    assert (got[:, p:] == 0).all()
+    want = emu_ops.softmax_columns(want.clone(), p)
+    got = ops.softmax_columns(got, p)
+    assert max_err(got, want) <= 1e-6
+    # prototype readout as a GEMM through deva_conv2d
+    vals = rand(g, nc, 512)
+    pc = ops.PackedConv(got, None, nc, p, got.shape[1], 1, 1)
+    out = ops.conv2d(pc, to_dev(vals).reshape(1, nc, 1, 512)).view(p, 512)
+    ref = want[:, :p].t() @ vals
+    assert max_err(out, ref) <= 1e-5 * max(1.0, ref.abs().max().item())
