@@ -49,10 +49,16 @@ def _compare(name, idx, w, usage, sim, k):
     got_scores = torch.gather(sim.t(), 1, idx.long())
     assert (got_scores[:, :-1] >= got_scores[:, 1:]).all(), f'{name}: not sorted by score'
     same = torch.tensor([idx[q].tolist() == ridx[:k, q].tolist() for q in range(hw)])
-    werr = (w[same] - rw.t()[same]).abs().max().item() if same.any() else 0.0
+    # weights; queries whose scores all underflow give 0/0 = NaN in the reference (no max
+    # subtraction, memory_utils.py:59-60) and must give NaN here too
+    ref_w = rw.t()
+    nan_ref, nan_got = torch.isnan(ref_w), torch.isnan(w)
+    assert torch.equal(nan_ref, nan_got), f'{name}: NaN pattern differs from the reference'
+    fin = same[:, None] & ~nan_ref
+    werr = (w[fin] - ref_w[fin]).abs().max().item() if fin.any() else 0.0
     assert werr <= 1e-5, f'{name}: weight error {werr:.3e}'
     if usage is not None:
-        dense = torch.zeros_like(sim).scatter_(0, ridx[:k], rw)
+        dense = torch.zeros_like(sim).scatter_(0, ridx[:k], torch.nan_to_num(rw))
         uerr = (usage - dense.sum(1)).abs().max().item()
         if bad == 0:
             assert uerr <= 1e-4, f'{name}: usage error {uerr:.3e}'

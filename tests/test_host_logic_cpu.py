@@ -88,6 +88,14 @@ def test_e2e_matches_reference(emu, golden_dir, recipe_state_dict, name):
     assert worst <= 2e-3, (name, worst)
 
 
+def test_lockstep_teacher_forced_small(emu, recipe_state_dict):
+    import lockstep
+    net = _network(recipe_state_dict)
+    P, _ = recipe_state_dict
+    worst = lockstep.run(net, P, 96, 128, 2, 6, torch.device('cpu'))
+    assert max(worst.values()) <= 2e-4, worst
+
+
 def test_store_views_follow_reference_layout(emu):
     from deva.inference.kv_memory_store import KeyValueMemoryStore
     st = KeyValueMemoryStore(save_selection=True, save_usage=True)

@@ -15,6 +15,6 @@ if [ "${RUN_BENCH:-1}" = "1" ]; then
   timeout -k 10 ${BENCH_TIMEOUT:-500} python bench.py --steps ${BENCH_STEPS:-20} --warmup 3 > gpurun_out/bench.log 2> gpurun_out/bench.err; echo "bench exit $?"; tail -c 3000 gpurun_out/bench.log; tail -5 gpurun_out/bench.err
 fi
 if [ "${RUN_PROF:-1}" = "1" ]; then
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o r01 -- python bench.py --steps 10 --warmup 2 --no_cpu_baseline --no_extra > gpurun_out/prof.log 2>&1; echo "prof exit $?"
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o ${PROF_TAG:-r01} -- python bench.py --steps 10 --warmup 2 --no_cpu_baseline --no_extra > gpurun_out/prof.log 2>&1; echo "prof exit $?"
   ls -R gpurun_out/prof | head -20
 fi

@@ -32,8 +32,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int CK = 64;
 constexpr int QT = 32;            // queries per wave
-constexpr int CAP = 64;           // candidate slots per query
+constexpr int CAP = 128;          // candidate slots per query (k <= 32 leaves >= 64 slots of slack)
 constexpr int STRIDE = CAP + 1;   // padded row (uint64 entries) to spread LDS banks
+constexpr int MAX_SPLITS = 16;    // splits * k <= 512 = 64 lanes x 8 keys in the merge kernel
 constexpr int WAVES = 4;
 constexpr int TOKT = 32;          // tokens per tile
 
@@ -51,6 +52,64 @@ __device__ __forceinline__ uint64_t make_key(float score, uint32_t token) {
 }
 
 #define DEVA_COMPILER_FENCE() asm volatile("" ::: "memory")
+
+__device__ __forceinline__ int wave_count(bool pred) { return __popcll(__ballot(pred)); }
+// number of set bits of a wave ballot below this lane
+__device__ __forceinline__ int prefix_below(unsigned long long b) {
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+}
+
+// Exact k-th largest of the unique non-zero 64-bit keys held E per lane (0 = empty slot) by bitwise
+// bisection with wave ballots: 32 steps on the score half; the index half only if the k-th score is
+// tied.  Requires >= k non-zero keys.  Everything >= the returned key is the top-k set.
+template <int E>
+__device__ __forceinline__ uint64_t kth_largest(const uint64_t (&e)[E], int n_live, int k) {
+  uint32_t T = 0;
+  for (int b = 31; b >= 0; --b) {
+    const uint32_t trial = T | (1u << b);
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < E; ++i)
+      if (i < n_live) cnt += wave_count((uint32_t)(e[i] >> 32) >= trial);
+    if (cnt >= k) T = trial;
+  }
+  int above = 0, ties = 0;
+#pragma unroll
+  for (int i = 0; i < E; ++i)
+    if (i < n_live) {
+      above += wave_count((uint32_t)(e[i] >> 32) > T);
+      ties += wave_count((uint32_t)(e[i] >> 32) == T);
+    }
+  const int need = k - above;  // ties to keep: the ones with the largest low half (lowest token index)
+  uint32_t L = 0;
+  if (ties > need) {
+    for (int b = 31; b >= 0; --b) {
+      const uint32_t trial = L | (1u << b);
+      int cnt = 0;
+#pragma unroll
+      for (int i = 0; i < E; ++i)
+        if (i < n_live) cnt += wave_count((uint32_t)(e[i] >> 32) == T && (uint32_t)e[i] >= trial);
+      if (cnt >= need) L = trial;
+    }
+  }
+  return ((uint64_t)T << 32) | L;
+}
+
+// prune one candidate list (wave-cooperative, c <= 128 entries, c >= k) to its exact best k
+// (unsorted); returns the k-th best key
+__device__ __forceinline__ uint64_t prune_list(volatile uint64_t* row, uint32_t c, int k, int lane) {
+  uint64_t e[2];
+  e[0] = ((uint32_t)lane < c) ? row[lane] : 0ull;
+  e[1] = ((uint32_t)lane + 64u < c) ? row[lane + 64] : 0ull;
+  const uint64_t thr = kth_largest<2>(e, 2, k);
+  const bool s0 = e[0] >= thr && e[0] != 0ull, s1 = e[1] >= thr && e[1] != 0ull;
+  const unsigned long long b0 = __ballot(s0), b1 = __ballot(s1);
+  DEVA_COMPILER_FENCE();
+  if (s0) row[prefix_below(b0)] = e[0];
+  if (s1) row[__popcll(b0) + prefix_below(b1)] = e[1];
+  DEVA_COMPILER_FENCE();
+  return thr;
+}
 
 struct AffArgs {
   const float* key_long;
@@ -123,16 +182,11 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
       while (need) {
         const int qq = __ffsll((unsigned long long)need) - 1;
         need &= need - 1;
-        const uint32_t c = cnt[qq];
-        volatile uint64_t* row = cand + qq * STRIDE;
-        const uint64_t mine = ((uint32_t)lane < c) ? row[lane] : 0ull;
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < c; ++j) rank += (row[j] > mine) ? 1u : 0u;
-        DEVA_COMPILER_FENCE();
-        if ((uint32_t)lane < c && rank < (uint32_t)p.k) row[rank] = mine;
-        if ((uint32_t)lane < c && c >= (uint32_t)p.k && rank == (uint32_t)p.k - 1)
-          tau[qq] = from_orderable((uint32_t)(mine >> 32));
-        if (lane == 0) cnt[qq] = min(c, (uint32_t)p.k);
+        const uint64_t thr = prune_list(cand + qq * STRIDE, cnt[qq], p.k, lane);
+        if (lane == 0) {
+          cnt[qq] = (uint32_t)p.k;
+          tau[qq] = from_orderable((uint32_t)(thr >> 32));
+        }
         DEVA_COMPILER_FENCE();
       }
     }
@@ -193,17 +247,14 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
     DEVA_COMPILER_FENCE();
   }
 
-  // ---- final prune of every list, then the sorted best-k of this range go to global memory
+  // ---- final prune of every over-full list; the (unsorted) best <= k of this range go to global memory
   for (int qq = 0; qq < QT; ++qq) {
     const uint32_t c = cnt[qq];
-    volatile uint64_t* row = cand + qq * STRIDE;
-    const uint64_t mine = ((uint32_t)lane < c) ? row[lane] : 0ull;
-    uint32_t rank = 0;
-    for (uint32_t j = 0; j < c; ++j) rank += (row[j] > mine) ? 1u : 0u;
-    DEVA_COMPILER_FENCE();
-    if ((uint32_t)lane < c && rank < (uint32_t)p.k) row[rank] = mine;
-    if (lane == 0) cnt[qq] = min(c, (uint32_t)p.k);
-    DEVA_COMPILER_FENCE();
+    if (c > (uint32_t)p.k) {
+      prune_list(cand + qq * STRIDE, c, p.k, lane);
+      if (lane == 0) cnt[qq] = (uint32_t)p.k;
+      DEVA_COMPILER_FENCE();
+    }
   }
   const int nq = min(QT, p.hw - q0);
   uint64_t* dst = p.part + ((int64_t)split * p.hw + q0) * p.k;
@@ -214,49 +265,71 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
   }
 }
 
-__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const uint32_t lo = __shfl_xor((uint32_t)v, off);
-    const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), off);
-    const uint64_t o = ((uint64_t)hi << 32) | lo;
-    v = (o > v) ? o : v;
-  }
-  return v;
-}
-
-// one wave per query: tournament merge of `splits` sorted lists (lane s owns list s)
+// one wave per query: exact top-k of the splits*k candidates (8 keys per lane), sorted by rank
+// counting, then exp / normalise / usage
+constexpr int ME = 8;
 __global__ __launch_bounds__(256) void affinity_finalize_kernel(const uint64_t* __restrict__ part, int hw, int k,
                                                                 int splits, int32_t* __restrict__ idx,
                                                                 float* __restrict__ weight,
                                                                 unsigned long long* __restrict__ usage_fix) {
+  __shared__ uint64_t s_buf[4][2][64];
   const int lane = threadIdx.x & 63;
-  const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int wave = threadIdx.x >> 6;
+  const int q = blockIdx.x * 4 + wave;
   if (q >= hw) return;
-  const uint64_t* list = part + ((int64_t)lane * hw + q) * k;
-  int ptr = 0;
-  uint64_t head = (lane < splits) ? list[0] : 0ull;
-  uint64_t mine = 0ull;
-  for (int r = 0; r < k; ++r) {
-    const uint64_t best = wave_max_u64(head);
-    if (lane == r) mine = best;
-    if (head == best && best != 0ull) {
-      ++ptr;
-      head = (ptr < k) ? list[ptr] : 0ull;
+  volatile uint64_t* unsorted = &s_buf[wave][0][0];
+  volatile uint64_t* sorted = &s_buf[wave][1][0];
+
+  const int total = splits * k;
+  const int n_live = (total + 63) >> 6;
+  uint64_t e[ME];
+#pragma unroll
+  for (int i = 0; i < ME; ++i) {
+    const int c = lane + 64 * i;
+    uint64_t v = 0ull;
+    if (c < total) {
+      const int sp = c / k;
+      v = part[((int64_t)sp * hw + q) * k + (c - sp * k)];
+    }
+    e[i] = v;
+  }
+  const uint64_t thr = kth_largest<ME>(e, n_live, k);
+  // compact the k survivors into LDS (any order), then sort them by rank counting
+  int base = 0;
+#pragma unroll
+  for (int i = 0; i < ME; ++i) {
+    if (i < n_live) {
+      const bool keep = e[i] >= thr && e[i] != 0ull;
+      const unsigned long long b = __ballot(keep);
+      if (keep) unsorted[base + prefix_below(b)] = e[i];
+      base += __popcll(b);
     }
   }
-  // lanes 0..k-1 hold the winners in descending order
+  DEVA_COMPILER_FENCE();
   const bool live = lane < k;
+  const uint64_t cand = live ? unsorted[lane] : 0ull;
+  int rank = 0;
+  for (int j = 0; j < k; ++j) {  // lane j's key, broadcast through SGPRs (j is wave-uniform)
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cand, j);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cand >> 32), j);
+    rank += ((((uint64_t)hi << 32) | lo) > cand) ? 1 : 0;
+  }
+  DEVA_COMPILER_FENCE();
+  if (live) sorted[rank] = cand;
+  DEVA_COMPILER_FENCE();
+  const uint64_t mine = live ? sorted[lane] : 0ull;  // lane r holds the r-th best
+
   const float score = from_orderable((uint32_t)(mine >> 32));
   const uint32_t token = ~(uint32_t)mine;
-  const float e = live ? expf(score) : 0.0f;
+  const float ex = live ? expf(score) : 0.0f;
   float sum = 0.0f;
-  for (int r = 0; r < k; ++r) sum += __shfl(e, r);  // sequential, like torch.sum over the sorted top-k
-  const float w = e / sum;
+  for (int r = 0; r < k; ++r)  // sequential, like torch.sum over the sorted top-k
+    sum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ex), r));
+  const float w = ex / sum;
   if (live) {
     idx[(int64_t)q * k + lane] = (int32_t)token;
     weight[(int64_t)q * k + lane] = w;
-    if (usage_fix && mine != 0ull && w == w) {
+    if (usage_fix && w == w) {
       atomicAdd(&usage_fix[token], (unsigned long long)(w * 1099511627776.0f));  // w * 2^40, exact scaling
     }
   }
@@ -330,11 +403,12 @@ using namespace deva;
 extern "C" int64_t deva_affinity_workspace(int hw, int k, int splits) { return (int64_t)splits * hw * k; }
 
 extern "C" int deva_affinity_default_splits(int n_total, int hw) {
+  // one 4-wave workgroup per CU is resident (132 KB of candidate lists): aim at ~256 workgroups
   const int qblocks = (int)ceil_div(hw, WAVES * QT);
   const int tiles = (int)ceil_div(n_total, TOKT);
-  int s = (int)ceil_div(512, qblocks);
+  int s = (int)ceil_div(256, qblocks);
   if (s > tiles / 4) s = tiles / 4;  // keep >= 4 tiles (128 tokens) per range
-  if (s > 64) s = 64;
+  if (s > MAX_SPLITS) s = MAX_SPLITS;
   if (s < 1) s = 1;
   return s;
 }
@@ -346,12 +420,12 @@ extern "C" int deva_affinity_topk(const float* key_long, const float* shr_long, 
   DEVA_REQUIRE(n_long >= 0 && n_work >= 0, "deva_affinity_topk: negative bank size");
   DEVA_REQUIRE(n_long == 0 || (key_long && shr_long), "deva_affinity_topk: null long-term segment");
   DEVA_REQUIRE(n_work == 0 || (key_work && shr_work), "deva_affinity_topk: null working segment");
-  DEVA_REQUIRE(k >= 1 && k <= CAP - TOKT, "deva_affinity_topk: k=%d unsupported (1..%d)", k, CAP - TOKT);
+  DEVA_REQUIRE(k >= 1 && k <= 32, "deva_affinity_topk: k=%d unsupported (1..32)", k);
   const int64_t n_total = (int64_t)n_long + n_work;
   DEVA_REQUIRE(n_total >= k, "deva_affinity_topk: selected index k out of range (bank has %lld tokens, k=%d)",
                (long long)n_total, k);
   DEVA_REQUIRE(n_total < (1ll << 31), "deva_affinity_topk: bank too large");
-  DEVA_REQUIRE(splits >= 1 && splits <= 64, "deva_affinity_topk: splits must be 1..64");
+  DEVA_REQUIRE(splits >= 1 && splits <= MAX_SPLITS, "deva_affinity_topk: splits must be 1..%d", MAX_SPLITS);
   AffArgs a;
   a.key_long = key_long ? key_long : key_work;
   a.shr_long = shr_long ? shr_long : shr_work;
@@ -375,7 +449,8 @@ extern "C" int deva_affinity_topk(const float* key_long, const float* shr_long, 
 extern "C" int deva_affinity_finalize(const uint64_t* part_keys, int hw, int k, int splits, int32_t* idx,
                                       float* weight, uint64_t* usage_fix, void* stream) {
   DEVA_REQUIRE(part_keys && idx && weight && hw > 0, "deva_affinity_finalize: bad args");
-  DEVA_REQUIRE(k >= 1 && k <= 64 && splits >= 1 && splits <= 64, "deva_affinity_finalize: k/splits out of range");
+  DEVA_REQUIRE(k >= 1 && k <= 32 && splits >= 1 && splits <= MAX_SPLITS,
+               "deva_affinity_finalize: k/splits out of range");
   hipLaunchKernelGGL(affinity_finalize_kernel, dim3((unsigned)ceil_div(hw, 4)), dim3(256), 0, (hipStream_t)stream,
                      part_keys, hw, k, splits, idx, weight, (unsigned long long*)usage_fix);
   return check_launch("deva_affinity_finalize");

@@ -101,23 +101,28 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+  // staged operands: raw loaded values + validity bits; select/relu happen in store_tiles, AFTER
+  // the MFMA block, so the loads stay in flight while the matrix pipe works on the current tile
   float4 ra[A_V4];
   float rb[B_PT];
+  unsigned ok_a = 0, ok_b = 0;
 
   auto load_tiles = [&](int k0) {
+    ok_a = 0;
+    ok_b = 0;
     // A: rows k0..k0+BK-1 of the packed weights, columns m0..m0+BM-1
 #pragma unroll
     for (int i = 0; i < A_V4; ++i) {
       const int e = tid + i * THREADS;
       const int kr = e / (BM / 4);
       const int mc = (e % (BM / 4)) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < BK * BM / 4) {
-        const int k = k0 + kr;
-        const int m = m0 + mc;
-        if (k < p.K && m < p.cout_pad) v = *reinterpret_cast<const float4*>(p.w + (int64_t)k * p.cout_pad + m);
-      }
-      ra[i] = v;
+      // unconditional load from a clamped (always valid) address + select: a load under a branch
+      // makes hipcc wait vmcnt(0) right behind it and serialises the whole staging phase
+      const int k = k0 + kr;
+      const int m = m0 + mc;
+      const bool ok = (e < BK * BM / 4) && (k < p.K) && (m < p.cout_pad);
+      ra[i] = *reinterpret_cast<const float4*>(p.w + (ok ? ((int64_t)k * p.cout_pad + m) : 0));
+      ok_a |= ok ? (1u << i) : 0u;
     }
     // B: im2col gather
     int tap_u = 0, cbase_u = 0;
@@ -147,13 +152,12 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvArgs p) {
         iw += tap - dy * p.KW;
       }
       const bool ok = n_ok && (k < p.K) && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
-      float v = 0.0f;
-      if (ok) {
-        const float* s = (c < p.c0) ? (src0 + (int64_t)c * p.HW) : (src1 + (int64_t)(c - p.c0) * p.HW);
-        v = s[ih * p.W + iw];
-        if (p.relu_in) v = fmaxf(v, 0.0f);
-      }
-      rb[i] = v;
+      // branch-free gather (see above): clamp to element 0 of source 0 when out of range
+      const bool first = ok ? (c < p.c0) : true;
+      const float* s = first ? src0 : src1;
+      const int64_t off = ok ? ((int64_t)(first ? c : (c - p.c0)) * p.HW + (ih * p.W + iw)) : 0;
+      rb[i] = s[off];
+      ok_b |= ok ? (1u << i) : 0u;
     }
   };
 
@@ -164,11 +168,16 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvArgs p) {
       if (e < BK * BM / 4) {
         const int kr = e / (BM / 4);
         const int mc = (e % (BM / 4)) * 4;
-        *reinterpret_cast<float4*>(&As[buf][kr][mc]) = ra[i];
+        *reinterpret_cast<float4*>(&As[buf][kr][mc]) =
+            (ok_a & (1u << i)) ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
 #pragma unroll
-    for (int i = 0; i < B_PT; ++i) Bs[buf][bk_group + i * KG][bn_local] = rb[i];
+    for (int i = 0; i < B_PT; ++i) {
+      float v = rb[i];
+      if (p.relu_in) v = fmaxf(v, 0.0f);
+      Bs[buf][bk_group + i * KG][bn_local] = (ok_b & (1u << i)) ? v : 0.0f;
+    }
   };
 
   const int ksteps = (p.K + BK - 1) / BK;
@@ -207,13 +216,20 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvArgs p) {
     const int64_t rbase = (int64_t)b * p.res_bs + pix;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      float bv[16], rv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (m >= p.cout) continue;
+        const int mm = (m < p.cout) ? m : 0;
+        bv[r] = p.bias ? p.bias[mm] : 0.0f;
+        rv[r] = p.res ? p.res[rbase + (int64_t)mm * p.OHW] : 0.0f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         float v = acc[i][j][r];
-        if (p.bias) v += p.bias[m];
-        if (p.res) v += p.res[rbase + (int64_t)m * p.OHW];
+        if (p.bias) v += bv[r];
+        if (p.res) v += rv[r];
         if (p.act == DEVA_ACT_RELU) {
           v = fmaxf(v, 0.0f);
         } else if (p.act == DEVA_ACT_SIGMOID) {
@@ -221,7 +237,7 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvArgs p) {
         } else if (p.act == DEVA_ACT_SQUARE_PLUS_ONE) {
           v = v * v + 1.0f;
         }
-        p.out[obase + (int64_t)m * p.OHW] = v;
+        if (m < p.cout) p.out[obase + (int64_t)m * p.OHW] = v;
       }
     }
   }
