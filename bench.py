@@ -94,7 +94,8 @@ class ConvTimer:
             out = self.real(pc, x0, x1, **kw)
             e.record()
             self.records.append((2.0 * pc.cout * pc.cin * pc.kh * pc.kw * out.shape[0] * out.shape[2] * out.shape[3],
-                                 s, e))
+                                 s, e, (pc.cin, pc.cout, pc.kh, kw.get('stride', 1), out.shape[0], out.shape[2],
+                                        out.shape[3])))
             return out
 
         self.ops.conv2d = timed
@@ -108,6 +109,19 @@ class ConvTimer:
         flops = sum(r[0] for r in self.records)
         ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
         return flops, ms, len(self.records)
+
+    def per_layer(self, frames):
+        """time and achieved TFLOP/s per distinct (cin, cout, k, stride, batch, OH, OW)"""
+        agg = {}
+        for fl, s, e, sig in self.records:
+            a = agg.setdefault(sig, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += fl
+            a[2] += s.elapsed_time(e)
+        rows = [dict(cin=k[0], cout=k[1], k=k[2], stride=k[3], batch=k[4], oh=k[5], ow=k[6],
+                     calls_per_frame=v[0] / frames, ms_per_frame=v[2] / frames, gflop_per_call=v[1] / v[0] / 1e9,
+                     tflops=v[1] / (v[2] * 1e-3) / 1e12) for k, v in agg.items()]
+        return sorted(rows, key=lambda r: -r['ms_per_frame'])
 
 
 def affinity_microbench(device, n=10000, hw=8160, k=30, iters=20):
@@ -245,6 +259,9 @@ def main():
             for f in extra_frames:
                 core.step(f)
         flops, ms, launches = ct.summary()
+        if os.environ.get('DEVA_BENCH_LAYERS'):
+            with open(os.environ['DEVA_BENCH_LAYERS'], 'w') as f:
+                json.dump(ct.per_layer(len(extra_frames)), f, indent=1)
         ach = flops / (ms * 1e-3) / 1e12
         result['roofline'] = {
             'kernel': 'conv_igemm_kernel (deva_conv2d, fp32 MFMA implicit GEMM)',

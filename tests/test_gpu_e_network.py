@@ -38,22 +38,46 @@ def _margin_aware_mismatch(got: torch.Tensor, ref: torch.Tensor, err: float) -> 
     return int(((got.argmax(0) != ref.argmax(0)) & decisive).sum())
 
 
-def _free_running_check(tag, got: torch.Tensor, ref: torch.Tensor):
-    """Free-running clips at full resolution: a near-tied top-k decision can legitimately flip when
-    the keys differ in the last bits (SURVEY.md §7 -- the reference does the same against itself),
-    which moves the read-out of that one query by percents and shows up as an isolated spike.  So:
-    report the max, require that all but a vanishing fraction of the soft outputs are within 1e-3,
-    and require argmax identity wherever the reference's margin is decisive."""
-    d = (got - ref).abs()
-    err = d.max().item()
-    frac = (d > 1e-3).float().mean().item()
-    bad = _margin_aware_mismatch(got, ref, err)
-    flips = int((got.argmax(0) != ref.argmax(0)).sum())
-    print(f'{tag}: max-abs {err:.2e}, p99.99 {d.flatten().kthvalue(int(d.numel() * 0.9999))[0].item():.2e}, '
-          f'frac>1e-3 {frac:.2e}, raw argmax flips {flips}/{got.shape[1] * got.shape[2]}, margin-aware mismatches {bad}')
-    assert frac <= 1e-3, (tag, frac)
-    assert err <= 2e-2, (tag, err)
-    assert bad == 0, (tag, bad)
+class _Drift:
+    """Free-running full-resolution clips.  A near-tied top-k decision legitimately flips when the
+    keys differ in the last bits, which moves that query's read-out by percents and is then carried
+    by the recurrent state (the reference does this against ITSELF).  The bound is
+    therefore set by the reference's own noise floor on the same clip: the CPU oracle is run twice,
+    once on the frames and once on the frames perturbed by 1e-6 relative noise, and the HIP
+    runtime's drift from the reference must stay within 3x that self-drift (or the 1e-3 target,
+    whichever is larger), with argmax identity wherever the reference's margin is decisive."""
+
+    def __init__(self, tag):
+        self.tag, self.ours, self.floor = tag, [], []
+
+    @staticmethod
+    def _stats(a, b):
+        d = (a - b).abs()
+        return d.max().item(), (d > 1e-3).float().mean().item()
+
+    def add(self, got, ref, ref_perturbed=None):
+        err, frac = self._stats(got, ref)
+        bad = _margin_aware_mismatch(got, ref, err)
+        flips = int((got.argmax(0) != ref.argmax(0)).sum())
+        self.ours.append((err, frac))
+        msg = (f'{self.tag} frame {len(self.ours) - 1}: HIP vs ref max-abs {err:.2e} frac>1e-3 {frac:.2e} '
+               f'raw flips {flips} margin-aware mismatches {bad}')
+        if ref_perturbed is not None:
+            f_err, f_frac = self._stats(ref_perturbed, ref)
+            self.floor.append((f_err, f_frac))
+            msg += (f' | ref vs ref(1e-6 input noise) max-abs {f_err:.2e} frac>1e-3 {f_frac:.2e} '
+                    f'flips {int((ref_perturbed.argmax(0) != ref.argmax(0)).sum())}')
+        print(msg)
+        assert bad == 0, msg
+
+    def finish(self):
+        ours_err, ours_frac = max(e for e, _ in self.ours), max(f for _, f in self.ours)
+        fl_err = max([e for e, _ in self.floor] + [0.0])
+        fl_frac = max([f for _, f in self.floor] + [0.0])
+        print(f'{self.tag}: clip max-abs {ours_err:.2e} (reference self-drift {fl_err:.2e}); '
+              f'frac>1e-3 {ours_frac:.2e} (reference self-drift {fl_frac:.2e})')
+        assert ours_err <= max(1e-3, 3 * fl_err), (self.tag, ours_err, fl_err)
+        assert ours_frac <= max(1e-4, 3 * fl_frac), (self.tag, ours_frac, fl_frac)
 
 
 def test_stages_teacher_forced(network, golden_dir):
@@ -97,23 +121,30 @@ def test_e2e_against_reference_golden(network, golden_dir, name):
     assert max(errs) <= 1e-3, (name, max(errs))
 
 
-def test_vos_example_against_reference_golden(network, golden_dir):
+def test_vos_example_against_reference_golden(network, golden_dir, recipe_state_dict):
     """BASELINE config 1: example/vos bmx-trees, 854x480 real frames, 2 objects, default flags"""
     from deva.inference.inference_core import DEVAInferenceCore
+    P, _ = recipe_state_dict
     g = np.load(os.path.join(golden_dir, 'e2e_vos_example.npz'))
     mean = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)
     std = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
-    core = DEVAInferenceCore(network, synth.base_config(enable_long_term_count_usage=False))
+    cfg = synth.base_config(enable_long_term_count_usage=False)
+    core, noisy = DEVAInferenceCore(network, cfg), O.OracleCore(P, cfg)
     labels = g['labels'].tolist()
     n = g['frames'].shape[0]
+    ann = torch.from_numpy(g['annotation'].astype(np.int64))
+    gen = torch.Generator().manual_seed(0)
+    drift = _Drift('vos example')
     for t in range(n):
-        img = ((torch.from_numpy(g['frames'][t]).permute(2, 0, 1).float() / 255 - mean) / std).to(dev())
+        img = (torch.from_numpy(g['frames'][t]).permute(2, 0, 1).float() / 255 - mean) / std
+        img_n = img * (1 + 1e-6 * torch.randn(img.shape, generator=gen))
         if t == 0:
-            p = core.step(img, torch.from_numpy(g['annotation'].astype(np.int64)).to(dev()), labels)
+            p, pn = core.step(img.to(dev()), ann.to(dev()), labels), noisy.step(img_n, ann, labels)
         else:
-            p = core.step(img, end=(t == n - 1))
-        p = p.cpu()
-        _free_running_check(f'vos example frame {t}', p[:, ::4, ::4], torch.from_numpy(g['prob_sub'][t]))
+            p, pn = core.step(img.to(dev()), end=(t == n - 1)), noisy.step(img_n, end=(t == n - 1))
+        ref = torch.from_numpy(g['prob_sub'][t])  # the reference's own output
+        drift.add(p.cpu()[:, ::4, ::4], ref, pn[:, ::4, ::4])
+    drift.finish()
 
 
 def test_480p_five_objects_against_oracle(network, recipe_state_dict):
@@ -123,17 +154,21 @@ def test_480p_five_objects_against_oracle(network, recipe_state_dict):
     P, _ = recipe_state_dict
     cfg = synth.base_config(enable_long_term=False, enable_long_term_count_usage=False)
     H, W, no, frames = 480, 854, 5, 7
-    hip, orc = DEVAInferenceCore(network, cfg), O.OracleCore(P, cfg)
+    hip, orc, noisy = DEVAInferenceCore(network, cfg), O.OracleCore(P, cfg), O.OracleCore(P, cfg)
     stream = synth.FrameStream(H, W, seed=2)
     mask0 = synth.box_mask(H, W, no)
     objs = list(range(1, no + 1))
+    gen = torch.Generator().manual_seed(0)
+    drift = _Drift('480p/5obj')
     for t in range(frames):
         img = stream.next()
+        img_n = img * (1 + 1e-6 * torch.randn(img.shape, generator=gen))
         if t == 0:
-            a, b = hip.step(img.to(dev()), mask0.to(dev()), objs), orc.step(img, mask0, objs)
+            a, b, c = hip.step(img.to(dev()), mask0.to(dev()), objs), orc.step(img, mask0, objs), noisy.step(img_n, mask0, objs)
         else:
-            a, b = hip.step(img.to(dev())), orc.step(img)
-        _free_running_check(f'480p/5obj frame {t}', a.cpu(), b)
+            a, b, c = hip.step(img.to(dev())), orc.step(img), noisy.step(img_n)
+        drift.add(a.cpu(), b, c)
+    drift.finish()
 
 
 def test_480p_lockstep_teacher_forced(network, recipe_state_dict):

@@ -42,12 +42,12 @@ struct ConvArgs {
   int tiles_n;
 };
 
-constexpr int BK = 16;
 constexpr int THREADS = 256;
 
-// MODE 0: 1x1 kernel (tap == 0);  MODE 1: both channel counts multiples of BK (tap and source are
-// uniform over a K step);  MODE 2: anything (per-element decode, used by the 3/4/2-channel stems).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE>
+// MODE 0: 1x1 kernel with c0 a multiple of BK (source uniform per K step, K tail allowed);
+// MODE 1: k x k kernel with c0 and c0+c1 multiples of BK (tap and source uniform per K step);
+// MODE 2: anything (per-element decode: the 2/3/4-channel stems, odd channel splits).
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MODE>
 __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvArgs p) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -125,39 +125,48 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvArgs p) {
       ok_a |= ok ? (1u << i) : 0u;
     }
     // B: im2col gather
-    int tap_u = 0, cbase_u = 0;
-    if (MODE == 1) {
-      tap_u = k0 / p.ctot;
-      cbase_u = k0 - tap_u * p.ctot;
-    }
+    if (MODE == 2) {
+      // generic: per-element decode of k -> (tap, channel, source); only the 2/3/4-channel stems
+      // and odd channel splits come here
 #pragma unroll
-    for (int i = 0; i < B_PT; ++i) {
-      const int kl = bk_group + i * KG;
-      const int k = k0 + kl;
-      int tap, c;
-      if (MODE == 0) {
-        tap = 0;
-        c = k;
-      } else if (MODE == 1) {
-        tap = tap_u;
-        c = cbase_u + kl;
-      } else {
-        tap = k / p.ctot;
-        c = k - tap * p.ctot;
+      for (int i = 0; i < B_PT; ++i) {
+        const int k = k0 + bk_group + i * KG;
+        const int tap = k / p.ctot;
+        const int c = k - tap * p.ctot;
+        const int dy = tap / p.KW;
+        const int ih = ih0 + dy, iw = iw0 + (tap - dy * p.KW);
+        const bool ok = n_ok && (k < p.K) && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+        const bool first = ok ? (c < p.c0) : true;
+        const float* s = first ? src0 : src1;
+        const int64_t off = ok ? ((int64_t)(first ? c : (c - p.c0)) * p.HW + (ih * p.W + iw)) : 0;
+        rb[i] = s[off];
+        ok_b |= ok ? (1u << i) : 0u;
+      }
+    } else {
+      // fast path: the tap and the source tensor are uniform over the K step (channel counts are
+      // multiples of BK), so the address arithmetic is one pointer per step + a stride per element
+      int tap = 0, cbase = k0;
+      if (MODE == 1) {
+        tap = k0 / p.ctot;
+        cbase = k0 - tap * p.ctot;
       }
       int ih = ih0, iw = iw0;
-      if (MODE != 0) {
+      if (MODE == 1) {
         const int dy = tap / p.KW;
         ih += dy;
         iw += tap - dy * p.KW;
       }
-      const bool ok = n_ok && (k < p.K) && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
-      // branch-free gather (see above): clamp to element 0 of source 0 when out of range
-      const bool first = ok ? (c < p.c0) : true;
-      const float* s = first ? src0 : src1;
-      const int64_t off = ok ? ((int64_t)(first ? c : (c - p.c0)) * p.HW + (ih * p.W + iw)) : 0;
-      rb[i] = s[off];
-      ok_b |= ok ? (1u << i) : 0u;
+      const bool okp = n_ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+      const bool first = cbase < p.c0;
+      const float* ptr = (first ? (src0 + (int64_t)cbase * p.HW) : (src1 + (int64_t)(cbase - p.c0) * p.HW)) +
+                         (int64_t)bk_group * p.HW + (okp ? (ih * p.W + iw) : 0);
+      const int64_t step = (int64_t)KG * p.HW;
+#pragma unroll
+      for (int i = 0; i < B_PT; ++i) {
+        const bool kin = (MODE == 1) || (k0 + bk_group + i * KG < p.K);  // MODE 0 may have a K tail
+        rb[i] = ptr[kin ? (int64_t)i * step : 0];
+        ok_b |= (okp && kin) ? (1u << i) : 0u;
+      }
     }
   };
 
@@ -243,18 +252,26 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvArgs p) {
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-int launch_mode(const ConvArgs& a, int mode, hipStream_t st) {
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+int launch_tile(const ConvArgs& a, hipStream_t st) {
   ConvArgs p = a;
+  int mode;
+  if (a.KH == 1 && a.KW == 1 && a.c0 % BK == 0) {
+    mode = 0;
+  } else if (a.ctot % BK == 0 && a.c0 % BK == 0) {
+    mode = 1;
+  } else {
+    mode = 2;
+  }
   const int tiles_m = (int)ceil_div(a.cout, BM);
   p.tiles_n = (int)ceil_div(a.n_total, BN);
   dim3 grid((unsigned)(tiles_m * p.tiles_n));
   if (mode == 0) {
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, 0>), grid, dim3(THREADS), 0, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 0>), grid, dim3(THREADS), 0, st, p);
   } else if (mode == 1) {
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, 1>), grid, dim3(THREADS), 0, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 1>), grid, dim3(THREADS), 0, st, p);
   } else {
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, 2>), grid, dim3(THREADS), 0, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 2>), grid, dim3(THREADS), 0, st, p);
   }
   return check_launch("deva_conv2d");
 }
@@ -304,20 +321,11 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
   a.out = d->out;
   a.tiles_n = 0;
 
-  int mode;
-  if (d->kh == 1 && d->kw == 1) {
-    mode = 0;
-  } else if (a.ctot % BK == 0) {
-    mode = 1;
-  } else {
-    mode = 2;
-  }
   hipStream_t st = (hipStream_t)stream;
-  // Tile choice: the largest tile that still yields >= ~2 workgroups per CU (256 CUs).
+  // Tile choice: the largest tile that still yields >= ~2 workgroups per CU (256 CUs).  The small
+  // tiles run 32-deep K steps so the per-step address set-up and the barrier are amortised.
   const int64_t blocks128 = ceil_div(a.cout, 128) * ceil_div(a.n_total, 128);
-  const int64_t blocks64 = ceil_div(a.cout, 64) * ceil_div(a.n_total, 64);
-  if (a.cout <= 32) return launch_mode<32, 128, 1, 4>(a, mode, st);
-  if (a.cout >= 128 && blocks128 >= 512) return launch_mode<128, 128, 2, 2>(a, mode, st);
-  if (blocks64 >= 384 || a.cout <= 64) return launch_mode<64, 64, 2, 2>(a, mode, st);
-  return launch_mode<64, 64, 2, 2>(a, mode, st);
+  if (a.cout <= 32) return launch_tile<32, 128, 32, 1, 4>(a, st);
+  if (a.cout >= 128 && blocks128 >= 512) return launch_tile<128, 128, 16, 2, 2>(a, st);
+  return launch_tile<64, 64, 32, 2, 2>(a, st);
 }
