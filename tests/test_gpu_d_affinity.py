@@ -63,7 +63,7 @@ def _compare(name, idx, w, usage, sim, k):
     if usage is not None:
         dense = torch.zeros_like(sim).scatter_(0, ridx[:k], torch.nan_to_num(rw))
         uerr = (usage - dense.sum(1)).abs().max().item()
-        if bad == 0:
+        if bad == 0 and bool(sane.all()):
             assert uerr <= 1e-4, f'{name}: usage error {uerr:.3e}'
     print(f'{name}: N={sim.shape[0]} HW={hw} tie-swapped queries={bad} identical order={int(same.sum())}/{hw} '
           f'weight err={werr:.2e}')

@@ -159,12 +159,12 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvArgs p) {
       const bool okp = n_ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
       const bool first = cbase < p.c0;
       const float* ptr = (first ? (src0 + (int64_t)cbase * p.HW) : (src1 + (int64_t)(cbase - p.c0) * p.HW)) +
-                         (int64_t)bk_group * p.HW + (okp ? (ih * p.W + iw) : 0);
-      const int64_t step = (int64_t)KG * p.HW;
+                         (okp ? (ih * p.W + iw) : 0);
 #pragma unroll
       for (int i = 0; i < B_PT; ++i) {
-        const bool kin = (MODE == 1) || (k0 + bk_group + i * KG < p.K);  // MODE 0 may have a K tail
-        rb[i] = ptr[kin ? (int64_t)i * step : 0];
+        const int ci = bk_group + i * KG;                    // channel within this K step
+        const bool kin = (MODE == 1) || (k0 + ci < p.K);      // MODE 0 may have a K tail (e.g. 513 channels)
+        rb[i] = ptr[kin ? (int64_t)ci * p.HW : 0];            // clamped: never reads past the source tensor
         ok_b |= (okp && kin) ? (1u << i) : 0u;
       }
     }
