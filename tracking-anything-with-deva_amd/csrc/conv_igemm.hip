@@ -107,44 +107,20 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvArgs p) {
   float rb[B_PT];
   unsigned ok_a = 0, ok_b = 0;
 
-  auto load_tiles = [&](int k0) {
+  // ---- staging of one K step, split into pieces so the main loop can interleave them with the
+  // MFMAs of the current step (an MFMA occupies the matrix pipe for 64 cycles while the wave keeps
+  // issuing independent VALU / memory instructions in its shadow)
+  const float* st_ptr = nullptr;  // fast path: per-step gather base of this thread
+  bool st_okp = false;
+  int st_k0 = 0;
+
+  auto stage_begin = [&](int k0) {
+    st_k0 = k0;
     ok_a = 0;
     ok_b = 0;
-    // A: rows k0..k0+BK-1 of the packed weights, columns m0..m0+BM-1
-#pragma unroll
-    for (int i = 0; i < A_V4; ++i) {
-      const int e = tid + i * THREADS;
-      const int kr = e / (BM / 4);
-      const int mc = (e % (BM / 4)) * 4;
-      // unconditional load from a clamped (always valid) address + select: a load under a branch
-      // makes hipcc wait vmcnt(0) right behind it and serialises the whole staging phase
-      const int k = k0 + kr;
-      const int m = m0 + mc;
-      const bool ok = (e < BK * BM / 4) && (k < p.K) && (m < p.cout_pad);
-      ra[i] = *reinterpret_cast<const float4*>(p.w + (ok ? ((int64_t)k * p.cout_pad + m) : 0));
-      ok_a |= ok ? (1u << i) : 0u;
-    }
-    // B: im2col gather
-    if (MODE == 2) {
-      // generic: per-element decode of k -> (tap, channel, source); only the 2/3/4-channel stems
-      // and odd channel splits come here
-#pragma unroll
-      for (int i = 0; i < B_PT; ++i) {
-        const int k = k0 + bk_group + i * KG;
-        const int tap = k / p.ctot;
-        const int c = k - tap * p.ctot;
-        const int dy = tap / p.KW;
-        const int ih = ih0 + dy, iw = iw0 + (tap - dy * p.KW);
-        const bool ok = n_ok && (k < p.K) && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
-        const bool first = ok ? (c < p.c0) : true;
-        const float* s = first ? src0 : src1;
-        const int64_t off = ok ? ((int64_t)(first ? c : (c - p.c0)) * p.HW + (ih * p.W + iw)) : 0;
-        rb[i] = s[off];
-        ok_b |= ok ? (1u << i) : 0u;
-      }
-    } else {
-      // fast path: the tap and the source tensor are uniform over the K step (channel counts are
-      // multiples of BK), so the address arithmetic is one pointer per step + a stride per element
+    if (MODE != 2) {
+      // the tap and the source tensor are uniform over the K step (channel counts are multiples
+      // of BK): one pointer per step + a channel stride per element
       int tap = 0, cbase = k0;
       if (MODE == 1) {
         tap = k0 / p.ctot;
@@ -156,17 +132,47 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvArgs p) {
         ih += dy;
         iw += tap - dy * p.KW;
       }
-      const bool okp = n_ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+      st_okp = n_ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
       const bool first = cbase < p.c0;
-      const float* ptr = (first ? (src0 + (int64_t)cbase * p.HW) : (src1 + (int64_t)(cbase - p.c0) * p.HW)) +
-                         (okp ? (ih * p.W + iw) : 0);
-#pragma unroll
-      for (int i = 0; i < B_PT; ++i) {
-        const int ci = bk_group + i * KG;                    // channel within this K step
-        const bool kin = (MODE == 1) || (k0 + ci < p.K);      // MODE 0 may have a K tail (e.g. 513 channels)
-        rb[i] = ptr[kin ? (int64_t)ci * p.HW : 0];            // clamped: never reads past the source tensor
-        ok_b |= (okp && kin) ? (1u << i) : 0u;
-      }
+      st_ptr = (first ? (src0 + (int64_t)cbase * p.HW) : (src1 + (int64_t)(cbase - p.c0) * p.HW)) +
+               (st_okp ? (ih * p.W + iw) : 0);
+    }
+  };
+
+  // A: rows k0..k0+BK-1 of the packed weights, columns m0..m0+BM-1.  Loads are unconditional from a
+  // clamped (always valid) address, the select happens when the tile is written to LDS: a load under
+  // a branch makes hipcc wait vmcnt(0) right behind it and serialises the staging.
+  auto stage_a = [&](int i) {
+    const int e = tid + i * THREADS;
+    const int kr = e / (BM / 4);
+    const int mc = (e % (BM / 4)) * 4;
+    const int k = st_k0 + kr;
+    const int m = m0 + mc;
+    const bool ok = (e < BK * BM / 4) && (k < p.K) && (m < p.cout_pad);
+    ra[i] = *reinterpret_cast<const float4*>(p.w + (ok ? ((int64_t)k * p.cout_pad + m) : 0));
+    ok_a |= ok ? (1u << i) : 0u;
+  };
+
+  // B: im2col gather of element i of this thread
+  auto stage_b = [&](int i) {
+    const int ci = bk_group + i * KG;  // row within this K step
+    if (MODE == 2) {
+      // generic per-element decode of k -> (tap, channel, source): 2/3/4-channel stems, odd splits
+      const int k = st_k0 + ci;
+      const int tap = k / p.ctot;
+      const int c = k - tap * p.ctot;
+      const int dy = tap / p.KW;
+      const int ih = ih0 + dy, iw = iw0 + (tap - dy * p.KW);
+      const bool ok = n_ok && (k < p.K) && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+      const bool first = ok ? (c < p.c0) : true;
+      const float* sp = first ? src0 : src1;
+      const int64_t off = ok ? ((int64_t)(first ? c : (c - p.c0)) * p.HW + (ih * p.W + iw)) : 0;
+      rb[i] = sp[off];
+      ok_b |= ok ? (1u << i) : 0u;
+    } else {
+      const bool kin = (MODE == 1) || (st_k0 + ci < p.K);    // MODE 0 may have a K tail (513 channels)
+      rb[i] = st_ptr[kin ? (int64_t)ci * p.HW : 0];           // clamped: never reads past the source
+      ok_b |= (st_okp && kin) ? (1u << i) : 0u;
     }
   };
 
@@ -189,28 +195,50 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvArgs p) {
     }
   };
 
+  constexpr int NKK = BK / 2;  // MFMA groups (k pairs) per K step
   const int ksteps = (p.K + BK - 1) / BK;
-  load_tiles(0);
+  stage_begin(0);
+#pragma unroll
+  for (int i = 0; i < A_V4; ++i) stage_a(i);
+#pragma unroll
+  for (int i = 0; i < B_PT; ++i) stage_b(i);
   store_tiles(0);
   __syncthreads();
 
   for (int s = 0; s < ksteps; ++s) {
     const int buf = s & 1;
-    if (s + 1 < ksteps) load_tiles((s + 1) * BK);  // global loads in flight during the MFMAs
+    // the last step re-stages step 0 (valid addresses, result unused) instead of branching
+    const int k_next = (s + 1 < ksteps) ? (s + 1) * BK : 0;
+    float fa[2][TM], fb[2][TN];
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      float a[TM], b[TN];
+    for (int i = 0; i < TM; ++i) fa[0][i] = As[buf][half][wm0 + i * 32 + l31];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = As[buf][2 * kk + half][wm0 + i * 32 + l31];
+    for (int j = 0; j < TN; ++j) fb[0][j] = Bs[buf][half][wn0 + j * 32 + l31];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bs[buf][2 * kk + half][wn0 + j * 32 + l31];
+    for (int kk = 0; kk < NKK; ++kk) {
+      if (kk + 1 < NKK) {  // fragments of the next k pair, in flight during this pair's MFMAs
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[(kk + 1) & 1][i] = As[buf][2 * (kk + 1) + half][wm0 + i * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[(kk + 1) & 1][j] = Bs[buf][2 * (kk + 1) + half][wn0 + j * 32 + l31];
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][i], fb[kk & 1][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // a slice of the next tile's staging in the shadow of the MFMAs just issued
+      if (kk == 0) stage_begin(k_next);
+#pragma unroll
+      for (int i = 0; i < A_V4; ++i)
+        if (i * NKK / A_V4 == kk) stage_a(i);
+#pragma unroll
+      for (int i = 0; i < B_PT; ++i)
+        if (i * NKK / B_PT == kk) stage_b(i);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (s + 1 < ksteps) store_tiles(buf ^ 1);
+    store_tiles(buf ^ 1);
     __syncthreads();
   }
 
