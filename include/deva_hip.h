@@ -41,9 +41,15 @@ const char* deva_hip_last_error(void);
  * Input  = virtual channel-concat of up to two NCHW tensors (replaces torch.cat in
  *          group_modules.py:119-121, modules.py:139,163, big_modules.py:180), each with its own
  *          batch stride (0 = broadcast over the batch, replaces .expand()).
- * Weight = packed [KH*KW][C0+C1][cout_pad] (tap-major, cout contiguous, cout_pad = cout rounded
- *          up to 32, zero filled).
+ * Weight = packed [K][cout_pad] (cout contiguous, cout_pad = cout rounded up to 32, zero filled)
+ *          with the K index ordered by `k_layout`:
+ *            DEVA_KLAYOUT_TAP_MAJOR   k = tap*(C0+C1) + c                      (any channel count)
+ *            DEVA_KLAYOUT_CHUNK32     k = ((c/32)*KH*KW + tap)*32 + c%32       (C0, C1 multiples of 32)
+ *          CHUNK32 walks all taps of a 32-channel slab before moving on, so the 9 shifted
+ *          re-reads of a 3x3 convolution hit the same L2 lines back to back.
  * out[b][m][oh][ow] = act( sum_k W[k][m] * in(k, b, oh, ow) + bias[m] + residual ) */
+enum { DEVA_KLAYOUT_TAP_MAJOR = 0, DEVA_KLAYOUT_CHUNK32 = 1 };
+
 enum {
   DEVA_ACT_NONE = 0,
   DEVA_ACT_RELU = 1,
@@ -61,6 +67,7 @@ typedef struct deva_conv_desc {
   const float* weight; /* packed, see above */
   const float* bias;   /* [cout] or NULL */
   int32_t cout, cout_pad;
+  int32_t k_layout;
   int32_t kh, kw, stride, pad;
   int32_t relu_in; /* apply max(x,0) to the inputs while loading (F.relu before the conv) */
   const float* residual; /* [batch or 1][cout][OH][OW] or NULL, added before the activation */

@@ -25,7 +25,11 @@ def pack_conv(weight, bias=None, bn=None, device=None):
 
 
 def _unpack(pc: PackedConv):
-    return pc.weight[:, :pc.cout].reshape(pc.kh, pc.kw, pc.cin, pc.cout).permute(3, 2, 0, 1).contiguous()
+    w = pc.weight[:, :pc.cout]
+    if pc.k_layout == 1:  # [cin/32][tap][32][cout]
+        w = w.reshape(pc.cin // 32, pc.kh * pc.kw, 32, pc.cout).permute(3, 0, 2, 1)
+        return w.reshape(pc.cout, pc.cin, pc.kh, pc.kw).contiguous()
+    return w.reshape(pc.kh, pc.kw, pc.cin, pc.cout).permute(3, 2, 0, 1).contiguous()
 
 
 def _act(y, act):

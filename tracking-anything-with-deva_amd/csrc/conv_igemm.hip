@@ -31,6 +31,7 @@ struct ConvArgs {
   const float* w;
   const float* bias;
   int cout, cout_pad;
+  int k_layout;
   int KH, KW, stride, pad;
   int K;        // KH*KW*ctot
   int n_total;  // batch*OH*OW
@@ -39,7 +40,7 @@ struct ConvArgs {
   int64_t res_bs;
   int act;
   float* out;
-  int tiles_n;
+  int tiles_n, tiles_m;
 };
 
 constexpr int THREADS = 256;
@@ -68,8 +69,17 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvArgs p) {
   const int l31 = lane & 31;
   const int half = lane >> 5;
 
-  const int tile_m = blockIdx.x / p.tiles_n;
-  const int tile_n = blockIdx.x % p.tiles_n;
+  // Tile order: cout tiles fastest (the workgroups sharing one pixel tile run together), and an
+  // XCD-aware remap -- hardware places workgroup b on XCD b % 8, so XCD x gets a CONTIGUOUS range
+  // of logical tiles and neighbouring pixel tiles (shared halo rows, shared B tile) meet in one L2.
+  int logical;
+  {
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int q = nb >> 3, r = nb & 7, xcd = b & 7;
+    logical = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int tile_n = logical / p.tiles_m;
+  const int tile_m = logical - tile_n * p.tiles_m;
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
 
@@ -123,8 +133,15 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvArgs p) {
       // of BK): one pointer per step + a channel stride per element
       int tap = 0, cbase = k0;
       if (MODE == 1) {
-        tap = k0 / p.ctot;
-        cbase = k0 - tap * p.ctot;
+        if (p.k_layout == DEVA_KLAYOUT_CHUNK32) {  // k = ((c/32)*taps + tap)*32 + c%32, BK == 32
+          const int slab = k0 / BK, taps = p.KH * p.KW;
+          const int chunk = slab / taps;
+          tap = slab - chunk * taps;
+          cbase = chunk * BK;
+        } else {  // k = tap*ctot + c
+          tap = k0 / p.ctot;
+          cbase = k0 - tap * p.ctot;
+        }
       }
       int ih = ih0, iw = iw0;
       if (MODE == 1) {
@@ -291,9 +308,14 @@ int launch_tile(const ConvArgs& a, hipStream_t st) {
   } else {
     mode = 2;
   }
-  const int tiles_m = (int)ceil_div(a.cout, BM);
+  static_assert(BK == 32, "the 32-channel-slab K layout assumes 32-deep K steps");
+  p.tiles_m = (int)ceil_div(a.cout, BM);
   p.tiles_n = (int)ceil_div(a.n_total, BN);
-  dim3 grid((unsigned)(tiles_m * p.tiles_n));
+  if (a.k_layout == DEVA_KLAYOUT_CHUNK32 && mode != 1) {
+    set_error("deva_conv2d: 32-channel-slab weights need c0 and c1 to be multiples of 32");
+    return 2;
+  }
+  dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
   if (mode == 0) {
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 0>), grid, dim3(THREADS), 0, st, p);
   } else if (mode == 1) {
@@ -315,6 +337,8 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
   DEVA_REQUIRE(d->batch > 0 && d->height > 0 && d->width > 0 && d->cout > 0, "deva_conv2d: bad shape");
   DEVA_REQUIRE(d->cout_pad % 32 == 0 && d->cout_pad >= d->cout, "deva_conv2d: cout_pad must be cout rounded up to 32");
   DEVA_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "deva_conv2d: bad kernel geometry");
+  DEVA_REQUIRE(d->k_layout == DEVA_KLAYOUT_TAP_MAJOR || d->k_layout == DEVA_KLAYOUT_CHUNK32,
+               "deva_conv2d: unknown k_layout %d", d->k_layout);
   ConvArgs a;
   a.in0 = d->in0;
   a.in1 = d->c1 ? d->in1 : nullptr;
@@ -334,6 +358,7 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
   a.bias = d->bias;
   a.cout = d->cout;
   a.cout_pad = d->cout_pad;
+  a.k_layout = d->k_layout;
   a.KH = d->kh;
   a.KW = d->kw;
   a.stride = d->stride;
@@ -348,12 +373,13 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
   a.act = d->act;
   a.out = d->out;
   a.tiles_n = 0;
+  a.tiles_m = 0;
 
   hipStream_t st = (hipStream_t)stream;
   // Tile choice: the largest tile that still yields >= ~2 workgroups per CU (256 CUs).  The small
   // tiles run 32-deep K steps so the per-step address set-up and the barrier are amortised.
   const int64_t blocks128 = ceil_div(a.cout, 128) * ceil_div(a.n_total, 128);
   if (a.cout <= 32) return launch_tile<32, 128, 32, 1, 4>(a, st);
-  if (a.cout >= 128 && blocks128 >= 512) return launch_tile<128, 128, 16, 2, 2>(a, st);
+  if (a.cout >= 128 && blocks128 >= 512) return launch_tile<128, 128, 32, 2, 2>(a, st);
   return launch_tile<64, 64, 32, 2, 2>(a, st);
 }

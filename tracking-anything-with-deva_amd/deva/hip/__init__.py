@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'libdeva_hip.so')
 ABI_VERSION = 1
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQUARE_PLUS_ONE = 0, 1, 2, 3
+KLAYOUT_TAP_MAJOR, KLAYOUT_CHUNK32 = 0, 1
 
 
 class ConvDesc(Structure):
@@ -24,6 +25,7 @@ class ConvDesc(Structure):
         ('batch', c_int32), ('height', c_int32), ('width', c_int32),
         ('weight', c_void_p), ('bias', c_void_p),
         ('cout', c_int32), ('cout_pad', c_int32),
+        ('k_layout', c_int32),
         ('kh', c_int32), ('kw', c_int32), ('stride', c_int32), ('pad', c_int32),
         ('relu_in', c_int32),
         ('residual', c_void_p), ('residual_batch_stride', c_int64),

@@ -10,8 +10,8 @@ from typing import Optional, Tuple
 
 import torch
 
-from . import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQUARE_PLUS_ONE, ConvDesc, DevaHipError, check,
-               lib)
+from . import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQUARE_PLUS_ONE, KLAYOUT_CHUNK32, KLAYOUT_TAP_MAJOR, ConvDesc,
+               DevaHipError, check, lib)
 
 __all__ = ['PackedConv', 'pack_conv', 'conv2d', 'maxpool3x3s2', 'upsample2x_add', 'area_downsample',
            'aggregate', 'softmax_channels', 'upsample4x_softmax', 'cbam', 'gru_update',
@@ -54,7 +54,9 @@ def _batched(t: torch.Tensor, name: str) -> Tuple[int, int]:
 # ------------------------------------------------------------------------------------------ conv
 @dataclass
 class PackedConv:
-    """weights of one convolution in the kernel's layout: [KH*KW*Cin][cout_pad], k = tap*Cin + c"""
+    """weights of one convolution in the kernel's layout [K][cout_pad]; K ordered tap-major
+    (k = tap*Cin + c) or, for Cin % 32 == 0 and kernels larger than 1x1, in 32-channel slabs
+    (k = ((c/32)*KH*KW + tap)*32 + c%32) -- see include/deva_hip.h"""
     weight: torch.Tensor
     bias: Optional[torch.Tensor]
     cin: int
@@ -62,6 +64,7 @@ class PackedConv:
     cout_pad: int
     kh: int
     kw: int
+    k_layout: int = KLAYOUT_TAP_MAJOR
 
 
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None,
@@ -80,11 +83,17 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
         b = shift if b is None else b * scale + shift
     cout_pad = (cout + 31) // 32 * 32
     packed = torch.zeros(kh * kw * cin, cout_pad, dtype=torch.float32, device=w.device)
-    packed[:, :cout] = w.permute(2, 3, 1, 0).reshape(kh * kw * cin, cout)
+    if kh * kw > 1 and cin % 32 == 0:
+        layout = KLAYOUT_CHUNK32  # [cin/32][tap][32][cout]
+        packed[:, :cout] = w.reshape(cout, cin // 32, 32, kh * kw).permute(1, 3, 2, 0).reshape(-1, cout)
+    else:
+        layout = KLAYOUT_TAP_MAJOR  # [tap][cin][cout]
+        packed[:, :cout] = w.permute(2, 3, 1, 0).reshape(kh * kw * cin, cout)
     if device is not None:
         packed = packed.to(device)
         b = None if b is None else b.to(device)
-    return PackedConv(packed.contiguous(), None if b is None else b.contiguous(), cin, cout, cout_pad, kh, kw)
+    return PackedConv(packed.contiguous(), None if b is None else b.contiguous(), cin, cout, cout_pad, kh, kw,
+                      layout)
 
 
 def conv2d(pc: PackedConv, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *, stride: int = 1,
@@ -95,6 +104,8 @@ def conv2d(pc: PackedConv, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, 
     c1 = 0 if x1 is None else x1.shape[1]
     if c0 + c1 != pc.cin:
         raise DevaHipError(f'conv2d: {c0}+{c1} input channels, weights expect {pc.cin}')
+    if pc.k_layout == KLAYOUT_CHUNK32 and (c0 % 32 or c1 % 32):
+        raise DevaHipError('conv2d: 32-channel-slab weights need both concatenated inputs to be multiples of 32 channels')
     batch = max(x0.shape[0], 1 if x1 is None else x1.shape[0], 1 if residual is None else residual.shape[0])
     h, w = x0.shape[-2:]
     if x1 is not None and tuple(x1.shape[-2:]) != (h, w):
@@ -119,6 +130,7 @@ def conv2d(pc: PackedConv, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, 
     d.weight = _p(pc.weight, name='packed weight')
     d.bias = _p(pc.bias, name='bias')
     d.cout, d.cout_pad = pc.cout, pc.cout_pad
+    d.k_layout = pc.k_layout
     d.kh, d.kw, d.stride, d.pad = pc.kh, pc.kw, stride, pad
     d.relu_in = 1 if relu_in else 0
     if residual is not None:
