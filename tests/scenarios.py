@@ -34,7 +34,7 @@ E2E: Dict[str, Dict] = {
 
 
 def run_scenario(make_core: Callable[[Dict], object], sc: Dict, device: str = 'cpu',
-                 on_frame: Callable = None) -> List[torch.Tensor]:
+                 on_frame: Callable = None, perturb: Callable = None) -> List[torch.Tensor]:
     """Returns the per-frame `step` outputs ([no+1,H,W] probabilities, on CPU)."""
     cfg = synth.base_config(**sc['cfg'])
     core = make_core(cfg)
@@ -43,7 +43,10 @@ def run_scenario(make_core: Callable[[Dict], object], sc: Dict, device: str = 'c
     objs = list(range(1, sc['nobj'] + 1))
     outs = []
     for t in range(sc['frames']):
-        img = stream.next().to(device)
+        img = stream.next()
+        if perturb is not None:
+            img = perturb(img)
+        img = img.to(device)
         end = (t == sc['frames'] - 1)
         if t == 0:
             p = core.step(img, mask0.to(device), objs, end=end)

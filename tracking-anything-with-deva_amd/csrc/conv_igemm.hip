@@ -14,6 +14,8 @@
 // Each of the 4 waves owns a (WM x WN) sub-tile made of 32x32 MFMA tiles.  Operand fragments for
 // v_mfma_f32_32x32x2_f32:  A: lane l holds A[i = l&31][k = l>>5],  B: B[k = l>>5][j = l&31],
 // D: reg r of lane l is D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace deva {
@@ -43,14 +45,15 @@ struct ConvArgs {
   int tiles_n, tiles_m;
 };
 
-constexpr int THREADS = 256;
 
 // MODE 0: 1x1 kernel with c0 a multiple of BK (source uniform per K step, K tail allowed);
 // MODE 1: k x k kernel with c0 and c0+c1 multiples of BK (tap and source uniform per K step);
 // MODE 2: anything (per-element decode: the 2/3/4-channel stems, odd channel splits).
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MODE>
-__global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvArgs p) {
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 4 : 1) void conv_igemm_kernel(
+    const ConvArgs p) {
+  constexpr int THREADS = 64 * WAVES_M * WAVES_N;
+  static_assert(WAVES_M * WAVES_N == 4 || WAVES_M * WAVES_N == 8, "4 or 8 waves per block");
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
   static_assert(TM >= 1 && TN >= 1, "wave tile");
@@ -317,11 +320,11 @@ int launch_tile(const ConvArgs& a, hipStream_t st) {
   }
   dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
   if (mode == 0) {
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 0>), grid, dim3(THREADS), 0, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 0>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
   } else if (mode == 1) {
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 1>), grid, dim3(THREADS), 0, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 1>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
   } else {
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 2>), grid, dim3(THREADS), 0, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 2>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
   }
   return check_launch("deva_conv2d");
 }
@@ -380,6 +383,6 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
   // tiles run 32-deep K steps so the per-step address set-up and the barrier are amortised.
   const int64_t blocks128 = ceil_div(a.cout, 128) * ceil_div(a.n_total, 128);
   if (a.cout <= 32) return launch_tile<32, 128, 32, 1, 4>(a, st);
-  if (a.cout >= 128 && blocks128 >= 512) return launch_tile<128, 128, 32, 2, 2>(a, st);
+  if (a.cout >= 128 && blocks128 >= 512) return (getenv("DEVA_CONV_BIG4") ? launch_tile<128, 128, 32, 2, 2>(a, st) : launch_tile<128, 128, 32, 2, 4>(a, st));
   return launch_tile<64, 64, 32, 2, 2>(a, st);
 }
