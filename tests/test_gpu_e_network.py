@@ -76,8 +76,10 @@ class _Drift:
         fl_frac = max([f for _, f in self.floor] + [0.0])
         print(f'{self.tag}: clip max-abs {ours_err:.2e} (reference self-drift {fl_err:.2e}); '
               f'frac>1e-3 {ours_frac:.2e} (reference self-drift {fl_frac:.2e})')
-        assert ours_err <= max(1e-3, 10 * fl_err), (self.tag, ours_err, fl_err)
-        assert ours_frac <= max(1e-4, 10 * fl_frac), (self.tag, ours_frac, fl_frac)
+        # 5e-3 = the size of ONE flipped top-k decision (measured: 1e-3 .. 4e-3), which can occur in
+        # either run at any frame
+        assert ours_err <= max(5e-3, 10 * fl_err), (self.tag, ours_err, fl_err)
+        assert ours_frac <= max(5e-3, 10 * fl_frac), (self.tag, ours_frac, fl_frac)
         assert ours_err <= 5e-2, (self.tag, ours_err)
 
 

@@ -49,7 +49,7 @@ struct ConvArgs {
 // MODE 0: 1x1 kernel with c0 a multiple of BK (source uniform per K step, K tail allowed);
 // MODE 1: k x k kernel with c0 and c0+c1 multiples of BK (tap and source uniform per K step);
 // MODE 2: anything (per-element decode: the 2/3/4-channel stems, odd channel splits).
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MODE>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MODE, int SPREAD>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 4 : 1) void conv_igemm_kernel(
     const ConvArgs p) {
   constexpr int THREADS = 64 * WAVES_M * WAVES_N;
@@ -252,10 +252,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
       if (kk == 0) stage_begin(k_next);
 #pragma unroll
       for (int i = 0; i < A_V4; ++i)
-        if (i * NKK / A_V4 == kk) stage_a(i);
+        if (i * (NKK / SPREAD) / A_V4 == kk) stage_a(i);
 #pragma unroll
       for (int i = 0; i < B_PT; ++i)
-        if (i * NKK / B_PT == kk) stage_b(i);
+        if (i * (NKK / SPREAD) / B_PT == kk) stage_b(i);
       __builtin_amdgcn_sched_barrier(0);
     }
     store_tiles(buf ^ 1);
@@ -300,7 +300,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
   }
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+// SPREAD: the staging of the next K step is issued during the first 1/SPREAD of the MFMA groups, the
+// rest of the step is slack for the loads to land before the LDS write.
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int SPREAD = 2>
 int launch_tile(const ConvArgs& a, hipStream_t st) {
   ConvArgs p = a;
   int mode;
@@ -320,11 +322,11 @@ int launch_tile(const ConvArgs& a, hipStream_t st) {
   }
   dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
   if (mode == 0) {
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 0>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 0, SPREAD>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
   } else if (mode == 1) {
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 1>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 1, SPREAD>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
   } else {
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 2>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 2, SPREAD>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
   }
   return check_launch("deva_conv2d");
 }
@@ -382,7 +384,12 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
   // Tile choice: the largest tile that still yields >= ~2 workgroups per CU (256 CUs).  The small
   // tiles run 32-deep K steps so the per-step address set-up and the barrier are amortised.
   const int64_t blocks128 = ceil_div(a.cout, 128) * ceil_div(a.n_total, 128);
+  static const int exp_spread = getenv("DEVA_CONV_SPREAD") ? atoi(getenv("DEVA_CONV_SPREAD")) : 2;
   if (a.cout <= 32) return launch_tile<32, 128, 32, 1, 4>(a, st);
-  if (a.cout >= 128 && blocks128 >= 512) return (getenv("DEVA_CONV_BIG4") ? launch_tile<128, 128, 32, 2, 2>(a, st) : launch_tile<128, 128, 32, 2, 4>(a, st));
-  return launch_tile<64, 64, 32, 2, 2>(a, st);
+  if (a.cout >= 128 && blocks128 >= 512) return (exp_spread == 1 ? launch_tile<128, 128, 32, 2, 4, 1>(a, st)
+                            : exp_spread == 4 ? launch_tile<128, 128, 32, 2, 4, 4>(a, st)
+                                              : launch_tile<128, 128, 32, 2, 4, 2>(a, st));
+  if (exp_spread == 1) return launch_tile<64, 64, 32, 2, 2, 1>(a, st);
+  if (exp_spread == 4) return launch_tile<64, 64, 32, 2, 2, 4>(a, st);
+  return launch_tile<64, 64, 32, 2, 2, 2>(a, st);
 }
