@@ -14,8 +14,6 @@
 // Each of the 4 waves owns a (WM x WN) sub-tile made of 32x32 MFMA tiles.  Operand fragments for
 // v_mfma_f32_32x32x2_f32:  A: lane l holds A[i = l&31][k = l>>5],  B: B[k = l>>5][j = l&31],
 // D: reg r of lane l is D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
-#include <stdlib.h>
-
 #include "common.h"
 
 namespace deva {
@@ -384,12 +382,7 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
   // Tile choice: the largest tile that still yields >= ~2 workgroups per CU (256 CUs).  The small
   // tiles run 32-deep K steps so the per-step address set-up and the barrier are amortised.
   const int64_t blocks128 = ceil_div(a.cout, 128) * ceil_div(a.n_total, 128);
-  static const int exp_spread = getenv("DEVA_CONV_SPREAD") ? atoi(getenv("DEVA_CONV_SPREAD")) : 2;
   if (a.cout <= 32) return launch_tile<32, 128, 32, 1, 4>(a, st);
-  if (a.cout >= 128 && blocks128 >= 512) return (exp_spread == 1 ? launch_tile<128, 128, 32, 2, 4, 1>(a, st)
-                            : exp_spread == 4 ? launch_tile<128, 128, 32, 2, 4, 4>(a, st)
-                                              : launch_tile<128, 128, 32, 2, 4, 2>(a, st));
-  if (exp_spread == 1) return launch_tile<64, 64, 32, 2, 2, 1>(a, st);
-  if (exp_spread == 4) return launch_tile<64, 64, 32, 2, 2, 4>(a, st);
-  return launch_tile<64, 64, 32, 2, 2, 2>(a, st);
+  if (a.cout >= 128 && blocks128 >= 512) return launch_tile<128, 128, 32, 2, 4>(a, st);
+  return launch_tile<64, 64, 32, 2, 2>(a, st);
 }
