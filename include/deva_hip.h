@@ -74,6 +74,10 @@ typedef struct deva_conv_desc {
   int64_t residual_batch_stride; /* elements; 0 broadcasts */
   int32_t act;
   float* out; /* [batch][cout][OH][OW] */
+  /* optional scratch for split-K (layers with too few output tiles to fill the GPU accumulate
+   * K ranges in parallel and a second kernel reduces them in a fixed order); NULL disables it */
+  float* workspace;
+  int64_t workspace_elems;
 } deva_conv_desc;
 
 int deva_conv2d(const deva_conv_desc* desc, void* stream);

@@ -19,6 +19,10 @@ SHAPES = [  # name, cin, cout, k, batch, H, W
     ('up8_4 3x3 256->256 @272x480 x1', 256, 256, 3, 1, 272, 480),
     ('res 3x3 64->64 @272x480 x1', 64, 64, 3, 1, 272, 480),
     ('res 1x1 256->64 @272x480 x1', 256, 64, 1, 1, 272, 480),
+    ('key 3x3 512->64 @30x54 x1', 512, 64, 3, 1, 30, 54),
+    ('shrink 3x3 512->1 @30x54 x1', 512, 1, 3, 1, 30, 54),
+    ('pred 3x3 256->1 @120x216 x5', 256, 1, 3, 5, 120, 216),
+    ('res 1x1 256->1024 @30x54 x1', 256, 1024, 1, 1, 30, 54),
 ]
 
 

@@ -172,6 +172,20 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
   const int t_begin = split * p.tiles_per_split;
   const int t_end = min(p.total_tiles, t_begin + p.tiles_per_split);
 
+  // key rows are software-prefetched one tile ahead: lane (l31, half) reads the whole 256-B row of
+  // token n_base + l31 into xbuf while the matrix pipe works on the previous tile
+  float4 xbuf[CK / 4];
+  float ms_buf;
+  auto prefetch = [&](int tile) {
+    const int n_mine = min(tile * TOKT + l31, p.n_total - 1);
+    const float* krow = (n_mine < p.n_long) ? (p.key_long + (int64_t)n_mine * CK)
+                                            : (p.key_work + (int64_t)(n_mine - p.n_long) * CK);
+    ms_buf = (n_mine < p.n_long) ? p.shr_long[n_mine] : p.shr_work[n_mine - p.n_long];
+#pragma unroll
+    for (int j = 0; j < CK / 4; ++j) xbuf[j] = reinterpret_cast<const float4*>(krow)[j];
+  };
+  if (t_begin < t_end) prefetch(t_begin);
+
   for (int tile = t_begin; tile < t_end; ++tile) {
     const int n_base = tile * TOKT;
 
@@ -192,14 +206,17 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
     }
     const float tau_l = tau[l31];
 
-    // ---- key tile: lane (l31, half) reads the whole 256-B row of token n_base + l31
-    const int n_mine = min(n_base + l31, p.n_total - 1);
-    const float* krow = (n_mine < p.n_long) ? (p.key_long + (int64_t)n_mine * CK)
-                                            : (p.key_work + (int64_t)(n_mine - p.n_long) * CK);
-    const float ms_mine = (n_mine < p.n_long) ? p.shr_long[n_mine] : p.shr_work[n_mine - p.n_long];
-    float4 x[CK / 4];
+    // ---- this tile's operand: channel 2t + half of this lane's token, then start the next loads
+    float a_op[CK / 2];
 #pragma unroll
-    for (int j = 0; j < CK / 4; ++j) x[j] = reinterpret_cast<const float4*>(krow)[j];
+    for (int t = 0; t < CK / 2; ++t) {
+      const float4 v = xbuf[t >> 1];
+      const float lo = (t & 1) ? v.z : v.x;
+      const float hi = (t & 1) ? v.w : v.y;
+      a_op[t] = half ? hi : lo;
+    }
+    const float ms_mine = ms_buf;
+    prefetch(min(tile + 1, t_end - 1));
 
     f32x16 accA, accB;
 #pragma unroll
@@ -209,11 +226,7 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
     }
 #pragma unroll
     for (int t = 0; t < CK / 2; ++t) {
-      // channel 2t + half of this lane's token
-      const float4 v = x[t >> 1];
-      const float lo = (t & 1) ? v.z : v.x;
-      const float hi = (t & 1) ? v.w : v.y;
-      const float a = half ? hi : lo;
+      const float a = a_op[t];
       accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a * a, bqe[t], accA, 0, 0, 0);
       accB = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bqk[t], accB, 0, 0, 0);
     }

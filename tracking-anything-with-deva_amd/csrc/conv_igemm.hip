@@ -17,6 +17,28 @@
 #include "common.h"
 
 namespace deva {
+
+// conv_cout1.hip
+struct Cout1Args {
+  const float* in0;
+  const float* in1;
+  int64_t bs0, bs1;
+  int c0, ctot;
+  int H, W, OH, OW, OHW;
+  int64_t HW;
+  const float* w;
+  const float* bias;
+  int cout_pad, k_layout;
+  int KH, KW, stride, pad;
+  int n_total;
+  int relu_in;
+  const float* res;
+  int64_t res_bs;
+  int act;
+  float* out;
+};
+int launch_conv_cout1(const Cout1Args& a, hipStream_t st);
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -41,6 +63,9 @@ struct ConvArgs {
   int act;
   float* out;
   int tiles_n, tiles_m;
+  int64_t ws_elems;
+  int splits;        // split-K factor (gridDim.y); > 1 writes raw partial sums to ws
+  float* ws;         // [splits][cout][n_total]
 };
 
 
@@ -214,8 +239,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
   };
 
   constexpr int NKK = BK / 2;  // MFMA groups (k pairs) per K step
-  const int ksteps = (p.K + BK - 1) / BK;
-  stage_begin(0);
+  // split-K: this workgroup accumulates K steps [ks0, ks0 + ksteps) of the layer
+  int ks0 = 0, ksteps = (p.K + BK - 1) / BK;
+  if (p.splits > 1) {
+    const int per = (ksteps + p.splits - 1) / p.splits;
+    ks0 = (int)blockIdx.y * per;
+    ksteps = max(0, min(ksteps - ks0, per));
+  }
+  stage_begin(ks0 * BK);
 #pragma unroll
   for (int i = 0; i < A_V4; ++i) stage_a(i);
 #pragma unroll
@@ -226,7 +257,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
   for (int s = 0; s < ksteps; ++s) {
     const int buf = s & 1;
     // the last step re-stages step 0 (valid addresses, result unused) instead of branching
-    const int k_next = (s + 1 < ksteps) ? (s + 1) * BK : 0;
+    const int k_next = (s + 1 < ksteps) ? (ks0 + s + 1) * BK : 0;
     float fa[2][TM], fb[2][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) fa[0][i] = As[buf][half][wm0 + i * 32 + l31];
@@ -258,6 +289,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
     }
     store_tiles(buf ^ 1);
     __syncthreads();
+  }
+
+  if (p.splits > 1) {
+    // ---- split-K: raw partial sums, reduced (+ bias / residual / activation) by splitk_reduce_kernel
+    float* ws = p.ws + (int64_t)blockIdx.y * p.cout * p.n_total;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn0 + j * 32 + l31;
+      if (n >= p.n_total) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (m < p.cout) ws[(int64_t)m * p.n_total + n] = acc[i][j][r];
+        }
+    }
+    return;
   }
 
   // ---- epilogue: bias + residual + activation, NCHW store (32 consecutive pixels per half-wave)
@@ -298,6 +347,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
   }
 }
 
+// out[b][m][pix] = act(sum_s ws[s][m][n] + bias[m] + residual), n = b*OHW + pix
+__global__ void splitk_reduce_kernel(const ConvArgs p) {
+  const int64_t total = (int64_t)p.cout * p.n_total;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / p.n_total);
+    const int n = (int)(i - (int64_t)m * p.n_total);
+    float v = 0.0f;
+    for (int s = 0; s < p.splits; ++s) v += p.ws[(int64_t)s * total + i];
+    const int b = n / p.OHW;
+    const int pix = n - b * p.OHW;
+    if (p.bias) v += p.bias[m];
+    if (p.res) v += p.res[(int64_t)b * p.res_bs + (int64_t)m * p.OHW + pix];
+    if (p.act == DEVA_ACT_RELU) {
+      v = fmaxf(v, 0.0f);
+    } else if (p.act == DEVA_ACT_SIGMOID) {
+      v = sigmoidf_(v);
+    } else if (p.act == DEVA_ACT_SQUARE_PLUS_ONE) {
+      v = v * v + 1.0f;
+    }
+    p.out[((int64_t)b * p.cout + m) * p.OHW + pix] = v;
+  }
+}
+
 // SPREAD: the staging of the next K step is issued during the first 1/SPREAD of the MFMA groups, the
 // rest of the step is slack for the loads to land before the LDS write.
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int SPREAD = 2>
@@ -318,13 +390,37 @@ int launch_tile(const ConvArgs& a, hipStream_t st) {
     set_error("deva_conv2d: 32-channel-slab weights need c0 and c1 to be multiples of 32");
     return 2;
   }
-  dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
+  // split-K when the layer has too few tiles to fill the 256 CUs (small frames / single objects):
+  // partial sums go to the caller's workspace, a second kernel reduces them deterministically
+  const int ksteps_total = (int)ceil_div(a.K, BK);
+  const int64_t blocks = (int64_t)p.tiles_m * p.tiles_n;
+  p.splits = 1;
+  if (a.ws && blocks < 256 && ksteps_total >= 8) {
+    int64_t sp = ceil_div(512, blocks);
+    if (sp > ksteps_total / 4) sp = ksteps_total / 4;
+    if (sp > 16) sp = 16;
+    const int64_t fit = a.ws_elems / ((int64_t)a.cout * a.n_total);
+    if (sp > fit) sp = fit;
+    if (sp >= 2) {
+      // every split must own at least one K step
+      const int per = (int)ceil_div(ksteps_total, sp);
+      sp = ceil_div(ksteps_total, per);
+      p.splits = (int)sp;
+    }
+  }
+  dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splits);
   if (mode == 0) {
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 0, SPREAD>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
   } else if (mode == 1) {
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 1, SPREAD>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
   } else {
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 2, SPREAD>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
+  }
+  if (p.splits > 1) {
+    const int64_t total = (int64_t)p.cout * p.n_total;
+    int64_t rb = ceil_div(total, 256);
+    if (rb > 4096) rb = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, p);
   }
   return check_launch("deva_conv2d");
 }
@@ -377,8 +473,41 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
   a.out = d->out;
   a.tiles_n = 0;
   a.tiles_m = 0;
+  a.splits = 1;
+  a.ws = d->workspace;
+  a.ws_elems = d->workspace ? d->workspace_elems : 0;
 
   hipStream_t st = (hipStream_t)stream;
+  if (a.cout == 1) {  // single output channel: coalesced VALU dot product (conv_cout1.hip)
+    Cout1Args c;
+    c.in0 = a.in0;
+    c.in1 = a.in1;
+    c.bs0 = a.bs0;
+    c.bs1 = a.bs1;
+    c.c0 = a.c0;
+    c.ctot = a.ctot;
+    c.H = a.H;
+    c.W = a.W;
+    c.OH = a.OH;
+    c.OW = a.OW;
+    c.OHW = a.OHW;
+    c.HW = a.HW;
+    c.w = a.w;
+    c.bias = a.bias;
+    c.cout_pad = a.cout_pad;
+    c.k_layout = a.k_layout;
+    c.KH = a.KH;
+    c.KW = a.KW;
+    c.stride = a.stride;
+    c.pad = a.pad;
+    c.n_total = a.n_total;
+    c.relu_in = a.relu_in;
+    c.res = a.res;
+    c.res_bs = a.res_bs;
+    c.act = a.act;
+    c.out = a.out;
+    return launch_conv_cout1(c, st);
+  }
   // Tile choice: the largest tile that still yields >= ~2 workgroups per CU (256 CUs).  The small
   // tiles run 32-deep K steps so the per-step address set-up and the barrier are amortised.
   const int64_t blocks128 = ceil_div(a.cout, 128) * ceil_div(a.n_total, 128);

@@ -96,6 +96,17 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
                       layout)
 
 
+_WORKSPACE = {}
+_WORKSPACE_ELEMS = 16 * 1024 * 1024  # 64 MB of split-K scratch per device
+
+
+def _workspace(device) -> torch.Tensor:
+    ws = _WORKSPACE.get(device)
+    if ws is None:
+        ws = _WORKSPACE[device] = torch.empty(_WORKSPACE_ELEMS, dtype=torch.float32, device=device)
+    return ws
+
+
 def conv2d(pc: PackedConv, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *, stride: int = 1,
            pad: int = 0, relu_in: bool = False, residual: Optional[torch.Tensor] = None,
            act: int = ACT_NONE, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -141,6 +152,8 @@ def conv2d(pc: PackedConv, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, 
         d.residual, d.residual_batch_stride = None, 0
     d.act = act
     d.out = _p(out, name='out')
+    ws = _workspace(out.device)
+    d.workspace, d.workspace_elems = ws.data_ptr(), ws.numel()
     check(lib().deva_conv2d(d, _stream()), 'deva_conv2d')
     return out
 
