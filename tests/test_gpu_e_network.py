@@ -47,8 +47,8 @@ class _Drift:
     runtime's drift from the reference must stay within 10x that self-drift (or the 1e-3 target,
     whichever is larger; both are single draws of a heavy-tailed quantity), with argmax identity wherever the reference's margin is decisive."""
 
-    def __init__(self, tag):
-        self.tag, self.ours, self.floor = tag, [], []
+    def __init__(self, tag, stride=1):
+        self.tag, self.ours, self.floor, self.pixels, self.stride = tag, [], [], 1, stride
 
     @staticmethod
     def _stats(a, b):
@@ -57,6 +57,7 @@ class _Drift:
 
     def add(self, got, ref, ref_perturbed=None):
         err, frac = self._stats(got, ref)
+        self.pixels = got.shape[-1] * got.shape[-2]
         bad = _margin_aware_mismatch(got, ref, err)
         flips = int((got.argmax(0) != ref.argmax(0)).sum())
         self.ours.append((err, frac))
@@ -79,7 +80,9 @@ class _Drift:
         # 5e-3 = the size of ONE flipped top-k decision (measured: 1e-3 .. 4e-3), which can occur in
         # either run at any frame
         assert ours_err <= max(5e-3, 10 * fl_err), (self.tag, ours_err, fl_err)
-        assert ours_frac <= max(5e-3, 10 * fl_frac), (self.tag, ours_frac, fl_frac)
+        # a flipped query perturbs (at least) its own 16x16-pixel cell: allow a few cells' worth
+        cell = 4 * 256.0 / (self.pixels * self.stride * self.stride)
+        assert ours_frac <= max(5e-3, cell, 10 * fl_frac), (self.tag, ours_frac, fl_frac)
         assert ours_err <= 5e-2, (self.tag, ours_err)
 
 
@@ -123,7 +126,7 @@ def test_e2e_against_reference_golden(network, golden_dir, recipe_state_dict, na
     sc_noisy = dict(sc)
     noisy_outs, _ = scenarios.run_scenario(lambda cfg: O.OracleCore(P, cfg), sc_noisy,
                                            perturb=lambda img: img * (1 + 1e-6 * torch.randn(img.shape, generator=gen)))
-    drift = _Drift(name)
+    drift = _Drift(name, stride=2)
     for t, p in enumerate(outs):
         drift.add(p[:, ::2, ::2], torch.from_numpy(g[f'prob_sub_{t}']), noisy_outs[t][:, ::2, ::2])
     drift.finish()
@@ -142,7 +145,7 @@ def test_vos_example_against_reference_golden(network, golden_dir, recipe_state_
     n = g['frames'].shape[0]
     ann = torch.from_numpy(g['annotation'].astype(np.int64))
     gen = torch.Generator().manual_seed(0)
-    drift = _Drift('vos example')
+    drift = _Drift('vos example', stride=4)
     for t in range(n):
         img = (torch.from_numpy(g['frames'][t]).permute(2, 0, 1).float() / 255 - mean) / std
         img_n = img * (1 + 1e-6 * torch.randn(img.shape, generator=gen))

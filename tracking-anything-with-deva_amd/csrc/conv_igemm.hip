@@ -478,7 +478,7 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
   a.ws_elems = d->workspace ? d->workspace_elems : 0;
 
   hipStream_t st = (hipStream_t)stream;
-  if (a.cout == 1) {  // single output channel: coalesced VALU dot product (conv_cout1.hip)
+  if (a.cout == 1 && a.K <= 12288) {  // single output channel: coalesced VALU dot product (conv_cout1.hip)
     Cout1Args c;
     c.in0 = a.in0;
     c.in1 = a.in1;
