@@ -104,11 +104,7 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const Cout1Args p) {
 int launch_conv_cout1(const Cout1Args& a, hipStream_t st) {
   const int K = a.KH * a.KW * a.ctot;
   const size_t smem = sizeof(float) * (((size_t)K + 63) / 64 * 64 + 256);
-  if (a.n_total >= 16384) {
-    hipLaunchKernelGGL((conv_cout1_kernel<64, 4>), dim3((unsigned)ceil_div(a.n_total, 64)), dim3(256), smem, st, a);
-  } else {
-    hipLaunchKernelGGL((conv_cout1_kernel<16, 16>), dim3((unsigned)ceil_div(a.n_total, 16)), dim3(256), smem, st, a);
-  }
+  hipLaunchKernelGGL((conv_cout1_kernel<16, 16>), dim3((unsigned)ceil_div(a.n_total, 16)), dim3(256), smem, st, a);
   return check_launch("deva_conv2d(cout=1)");
 }
 

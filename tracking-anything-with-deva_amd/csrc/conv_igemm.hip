@@ -478,7 +478,9 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
   a.ws_elems = d->workspace ? d->workspace_elems : 0;
 
   hipStream_t st = (hipStream_t)stream;
-  if (a.cout == 1 && a.K <= 12288) {  // single output channel: coalesced VALU dot product (conv_cout1.hip)
+  // single output channel on a small map (shrinkage head, CBAM gate): VALU dot product (conv_cout1.hip);
+  // large maps stay on the MFMA tile, which is faster there despite the 31 padded rows
+  if (a.cout == 1 && a.K <= 12288 && a.n_total < 16384) {
     Cout1Args c;
     c.in0 = a.in0;
     c.in1 = a.in1;
