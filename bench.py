@@ -78,31 +78,37 @@ def start_clip(net, cfg, frames, num_objects, device, lt_prefill=0):
 
 
 class ConvTimer:
-    """HIP-event timing of every deva_conv2d launch (events on torch's current stream, which is the
-    stream the kernels are launched on)"""
+    """HIP-event timing of every deva_conv2d launch.  The events are recorded on torch's current
+    stream (the stream the kernels are launched on) immediately around the C call, with a device
+    sync before each launch so that the interval is the kernel(s) of that launch and not host-side
+    gaps (the un-instrumented frame loop is GPU-bound, the instrumented one would not be)."""
 
     def __init__(self):
-        from deva.hip import ops
-        self.ops = ops
-        self.real = ops.conv2d
+        from deva.hip import lib
+        self.handle = lib()
+        self.real = self.handle.deva_conv2d
         self.records = []
 
     def __enter__(self):
-        def timed(pc, x0, x1=None, **kw):
+        def timed(desc_ref, stream):
+            d = desc_ref._obj if hasattr(desc_ref, '_obj') else desc_ref
+            oh = (d.height + 2 * d.pad - d.kh) // d.stride + 1
+            ow = (d.width + 2 * d.pad - d.kw) // d.stride + 1
+            flops = 2.0 * d.cout * (d.c0 + d.c1) * d.kh * d.kw * d.batch * oh * ow
+            sig = (d.c0 + d.c1, d.cout, d.kh, d.stride, d.batch, oh, ow)
+            torch.cuda.synchronize()
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            out = self.real(pc, x0, x1, **kw)
+            rc = self.real(desc_ref, stream)
             e.record()
-            self.records.append((2.0 * pc.cout * pc.cin * pc.kh * pc.kw * out.shape[0] * out.shape[2] * out.shape[3],
-                                 s, e, (pc.cin, pc.cout, pc.kh, kw.get('stride', 1), out.shape[0], out.shape[2],
-                                        out.shape[3])))
-            return out
+            self.records.append((flops, s, e, sig))
+            return rc
 
-        self.ops.conv2d = timed
+        self.handle.deva_conv2d = timed
         return self
 
     def __exit__(self, *a):
-        self.ops.conv2d = self.real
+        self.handle.deva_conv2d = self.real
         torch.cuda.synchronize()
 
     def summary(self):
@@ -180,6 +186,33 @@ def cpu_baseline(sd, cfg, height, width, num_objects, frames_cpu):
                 sample=f'{n} propagated frames after the annotated one, same workload (CPU oracle, fp32)')
 
 
+def timed_region(fn, dist=None, device=None):
+    """barrier + device sync, run fn, barrier + device sync; returns the MAX elapsed seconds over all
+    ranks (replicas: the job is as slow as its slowest clip).  `dist` is torch.distributed when
+    world_size > 1 (RCCL on the GPU box, gloo in the CPU test), else None."""
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        if device is not None and torch.device(device).type == 'cuda':
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    fn()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def whole_job_fps(steps_per_rank: int, world: int, elapsed: float) -> float:
+    """weak scaling over independent clips: every rank propagates `steps_per_rank` frames"""
+    return world * steps_per_rank / elapsed
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -213,26 +246,16 @@ def main():
     for t in range(1, 1 + args.warmup):
         core.step(frames[t])
 
-    def barrier():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def timed_steps():
+        for t in range(1 + args.warmup, n_frames):
+            core.step(frames[t])
 
-    barrier()
-    t0 = time.perf_counter()
-    for t in range(1 + args.warmup, n_frames):
-        core.step(frames[t])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        tt = torch.tensor([elapsed], device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = timed_region(timed_steps, dist if distributed else None, device)
     bank = {b: core.memory.work_mem.size(b) for b in core.memory.work_mem.buckets}
 
     result = {
         'metric': 'propagation FPS @480p (5 objects, working memory only)',
-        'value': world * args.steps / elapsed,
+        'value': whole_job_fps(args.steps, world, elapsed),
         'unit': 'frames/s',
         'n_gpus': world,
         'steps': args.steps,
