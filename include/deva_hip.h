@@ -74,6 +74,11 @@ typedef struct deva_conv_desc {
   int64_t residual_batch_stride; /* elements; 0 broadcasts */
   int32_t act;
   float* out; /* [batch][cout][OH][OW] */
+  /* Number of float elements that are allocated and readable immediately before the first and
+   * after the last element of BOTH inputs (0 if unknown).  With >= pad*(W+1)+4 the stride-1
+   * 'same' convolutions gather 4 consecutive pixels per 16-byte load (reads may touch the guard
+   * band, the values are masked); otherwise every element is gathered with a clamped scalar load. */
+  int32_t in_guard_elems;
   /* optional scratch for split-K (layers with too few output tiles to fill the GPU accumulate
    * K ranges in parallel and a second kernel reduces them in a fixed order); NULL disables it */
   float* workspace;

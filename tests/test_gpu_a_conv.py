@@ -40,8 +40,28 @@ CASES = [
 ]
 
 
+CASES += [
+    ('vec_rowwrap_3x3', 64, 0, 64, 3, 1, 1, 2, 6, 10, False, True, 'full', ops.ACT_NONE, True, False),
+    ('vec_rowwrap_cat', 32, 32, 96, 3, 1, 1, 3, 10, 6, True, False, 'none', ops.ACT_RELU, True, False),
+    ('vec_1x1_tail513', 512, 1, 64, 1, 1, 0, 2, 6, 10, False, False, 'none', ops.ACT_NONE, True, False),
+    ('vec_7x7_same', 32, 0, 40, 7, 1, 3, 1, 12, 20, False, False, 'none', ops.ACT_NONE, True, False),
+]
+
+
+def _guarded(x):
+    """the tensor inside a NaN-filled buffer with ops.GUARD floats on either side: what ops._alloc
+    returns, with poison in the guard bands so that any unmasked over-read shows up as NaN"""
+    if x is None:
+        return None
+    flat = torch.full((x.numel() + 2 * ops.GUARD,), float('nan'), device=dev())
+    view = flat[ops.GUARD:ops.GUARD + x.numel()].view(*x.shape)
+    view.copy_(x)
+    return view
+
+
+@pytest.mark.parametrize('guarded', [False, True], ids=['scalar_gather', 'vector_gather'])
 @pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
-def test_conv_matches_cpu(case):
+def test_conv_matches_cpu(case, guarded):
     name, c0, c1, cout, k, stride, pad, batch, H, W, bcast0, relu_in, res, act, bias, bn = case
     g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 100000)
     cin = c0 + c1
@@ -62,11 +82,13 @@ def test_conv_matches_cpu(case):
         residual = rand(g, 1, cout, oh, ow)
         x0 = rand(g, batch, c0, H, W)
     want = emu_ops.conv2d(pc, x0, x1, stride=stride, pad=pad, relu_in=relu_in, residual=residual, act=act)
-    got = ops.conv2d(to_dev(pc), to_dev(x0), to_dev(x1), stride=stride, pad=pad, relu_in=relu_in,
+    dx0, dx1 = (_guarded(x0), _guarded(x1)) if guarded else (to_dev(x0), to_dev(x1))
+    got = ops.conv2d(to_dev(pc), dx0, dx1, stride=stride, pad=pad, relu_in=relu_in,
                      residual=to_dev(residual), act=act)
     torch.cuda.synchronize()
     assert got.shape == want.shape
     err = max_err(got, want)
+    assert not torch.isnan(got).any(), f'{name}: guard-band values leaked into the result'
     print(f'{name}: max abs err {err:.3e} (|ref|max {want.abs().max().item():.3e})')
     assert err <= 2e-5 * max(1.0, want.abs().max().item()), (name, err)
 

@@ -42,6 +42,8 @@ int launch_conv_cout1(const Cout1Args& a, hipStream_t st);
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef f32x4 f32x4_u __attribute__((aligned(4)));  // 4 consecutive pixels, dword-aligned only
 
 struct ConvArgs {
   const float* in0;
@@ -62,6 +64,7 @@ struct ConvArgs {
   int64_t res_bs;
   int act;
   float* out;
+  int vec_ok;        // inputs are guard-banded + 'same' stride-1 geometry: 4-pixel vector gathers allowed
   int tiles_n, tiles_m;
   int64_t ws_elems;
   int splits;        // split-K factor (gridDim.y); > 1 writes raw partial sums to ws
@@ -72,7 +75,7 @@ struct ConvArgs {
 // MODE 0: 1x1 kernel with c0 a multiple of BK (source uniform per K step, K tail allowed);
 // MODE 1: k x k kernel with c0 and c0+c1 multiples of BK (tap and source uniform per K step);
 // MODE 2: anything (per-element decode: the 2/3/4-channel stems, odd channel splits).
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MODE, int SPREAD>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MODE, int SPREAD, int VEC>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 4 : 1) void conv_igemm_kernel(
     const ConvArgs p) {
   constexpr int THREADS = 64 * WAVES_M * WAVES_N;
@@ -129,6 +132,39 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
     src1 = p.in1 ? p.in1 + (int64_t)b * p.bs1 : p.in0;
   }
 
+  // ---- vector gather (VEC): stride-1 "same" convolutions read 4 consecutive pixels of one channel
+  // with a single dword-aligned 16-B load (flat input pixel = flat output pixel + tap offset); pixels
+  // that fall into the zero padding are masked when the tile is written to LDS.  Needs readable
+  // guard bands of pad*(W+1)+4 floats around the inputs (checked by the host, see deva_hip.h).
+  constexpr int NQ = BN / 4;          // pixel quads per tile row
+  constexpr int KGV = THREADS / NQ;   // K rows covered per pass
+  constexpr int B_V4 = BK / KGV;      // 16-B gathers per thread
+  static_assert(VEC == 0 || (B_V4 >= 1 && B_V4 * KGV == BK), "vector gather geometry");
+  const int vq = tid % NQ, vk = tid / NQ;
+  bool vq_ok = false;
+  int v_oh[4], v_ow[4];
+  const float* vsrc0 = nullptr;
+  const float* vsrc1 = nullptr;
+  int v_pix0 = 0;
+  if (VEC) {
+    const int n4 = n0 + 4 * vq;
+    vq_ok = n4 < p.n_total;  // OHW % 4 == 0: a quad never straddles images or the end
+    const int nn = vq_ok ? n4 : 0;
+    const int b = nn / p.OHW;
+    v_pix0 = nn - b * p.OHW;
+    const int oh = v_pix0 / p.OW, ow = v_pix0 - oh * p.OW;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool wrap = ow + j >= p.OW;  // OW >= 4: at most one row wrap inside a quad
+      v_oh[j] = oh + (wrap ? 1 : 0);
+      v_ow[j] = ow + j - (wrap ? p.OW : 0);
+    }
+    vsrc0 = p.in0 + (int64_t)b * p.bs0;
+    vsrc1 = p.in1 ? p.in1 + (int64_t)b * p.bs1 : p.in0;
+  }
+  f32x4 rbv[VEC ? B_V4 : 1];
+  unsigned v_mask = 0;
+
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -175,10 +211,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
         ih += dy;
         iw += tap - dy * p.KW;
       }
-      st_okp = n_ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
       const bool first = cbase < p.c0;
-      st_ptr = (first ? (src0 + (int64_t)cbase * p.HW) : (src1 + (int64_t)(cbase - p.c0) * p.HW)) +
-               (st_okp ? (ih * p.W + iw) : 0);
+      if (VEC) {
+        const int dy = ih - ih0 - p.pad, dx = iw - iw0 - p.pad;  // tap offset relative to the centre
+        v_mask = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool ok = vq_ok && ((unsigned)(v_oh[j] + dy) < (unsigned)p.H) &&
+                          ((unsigned)(v_ow[j] + dx) < (unsigned)p.W);
+          v_mask |= ok ? (1u << j) : 0u;
+        }
+        st_ptr = (first ? (vsrc0 + (int64_t)cbase * p.HW) : (vsrc1 + (int64_t)(cbase - p.c0) * p.HW)) +
+                 (v_pix0 + dy * p.W + dx);
+      } else {
+        st_okp = n_ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+        st_ptr = (first ? (src0 + (int64_t)cbase * p.HW) : (src1 + (int64_t)(cbase - p.c0) * p.HW)) +
+                 (st_okp ? (ih * p.W + iw) : 0);
+      }
     }
   };
 
@@ -197,6 +246,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
   };
 
   // B: im2col gather of element i of this thread
+  auto stage_bv = [&](int i) {  // VEC: 4 consecutive pixels of K row vk + i*KGV
+    const int ci = vk + i * KGV;
+    const bool kin = (MODE == 1) || (st_k0 + ci < p.K);
+    rbv[i] = *reinterpret_cast<const f32x4_u*>(st_ptr + (kin ? (int64_t)ci * p.HW : 0));
+    ok_b |= kin ? (1u << i) : 0u;
+  };
+
   auto stage_b = [&](int i) {
     const int ci = bk_group + i * KG;  // row within this K step
     if (MODE == 2) {
@@ -230,6 +286,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
             (ok_a & (1u << i)) ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
+    if (VEC) {
+#pragma unroll
+      for (int i = 0; i < B_V4; ++i) {
+        f32x4 v = rbv[i];
+        const bool kin = ok_b & (1u << i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float x = v[j];
+          if (p.relu_in) x = fmaxf(x, 0.0f);
+          v[j] = (kin && (v_mask & (1u << j))) ? x : 0.0f;
+        }
+        *reinterpret_cast<f32x4*>(&Bs[buf][vk + i * KGV][4 * vq]) = v;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < B_PT; ++i) {
       float v = rb[i];
@@ -249,8 +320,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
   stage_begin(ks0 * BK);
 #pragma unroll
   for (int i = 0; i < A_V4; ++i) stage_a(i);
+  if (VEC) {
 #pragma unroll
-  for (int i = 0; i < B_PT; ++i) stage_b(i);
+    for (int i = 0; i < B_V4; ++i) stage_bv(i);
+  } else {
+#pragma unroll
+    for (int i = 0; i < B_PT; ++i) stage_b(i);
+  }
   store_tiles(0);
   __syncthreads();
 
@@ -282,9 +358,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
 #pragma unroll
       for (int i = 0; i < A_V4; ++i)
         if (i * (NKK / SPREAD) / A_V4 == kk) stage_a(i);
+      if (VEC) {
 #pragma unroll
-      for (int i = 0; i < B_PT; ++i)
-        if (i * (NKK / SPREAD) / B_PT == kk) stage_b(i);
+        for (int i = 0; i < B_V4; ++i)
+          if (i * (NKK / SPREAD) / B_V4 == kk) stage_bv(i);
+      } else {
+#pragma unroll
+        for (int i = 0; i < B_PT; ++i)
+          if (i * (NKK / SPREAD) / B_PT == kk) stage_b(i);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     store_tiles(buf ^ 1);
@@ -409,12 +491,25 @@ int launch_tile(const ConvArgs& a, hipStream_t st) {
     }
   }
   dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splits);
+  const bool vec = a.vec_ok && mode != 2;
   if (mode == 0) {
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 0, SPREAD>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
+    if (vec) {
+      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 0, SPREAD, 1>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
+    } else {
+      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 0, SPREAD, 0>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
+    }
   } else if (mode == 1) {
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 1, SPREAD>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
+    if (vec) {
+      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 1, SPREAD, 1>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
+    } else {
+      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 1, SPREAD, 0>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
+    }
   } else {
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 2, SPREAD>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
+    if (vec) {
+      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 1, SPREAD, 1>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
+    } else {
+      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 2, SPREAD, 0>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
+    }
   }
   if (p.splits > 1) {
     const int64_t total = (int64_t)p.cout * p.n_total;
@@ -473,6 +568,12 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
   a.out = d->out;
   a.tiles_n = 0;
   a.tiles_m = 0;
+  // 4-pixel vector gathers: stride-1 'same' geometry, quads never straddle images, and the caller
+  // vouches for readable guard bands around both inputs
+  a.vec_ok = (d->stride == 1 && a.OH == a.H && a.OW == a.W && a.OHW % 4 == 0 && a.OW >= 4 &&
+              (int64_t)d->in_guard_elems >= (int64_t)d->pad * (a.W + 1) + 4)
+                 ? 1
+                 : 0;
   a.splits = 1;
   a.ws = d->workspace;
   a.ws_elems = d->workspace ? d->workspace_elems : 0;

@@ -31,6 +31,7 @@ class ConvDesc(Structure):
         ('residual', c_void_p), ('residual_batch_stride', c_int64),
         ('act', c_int32),
         ('out', c_void_p),
+        ('in_guard_elems', c_int32),
         ('workspace', c_void_p), ('workspace_elems', c_int64),
     ]
 

@@ -96,6 +96,29 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
                       layout)
 
 
+GUARD = 8192  # floats of readable slack on both sides of every tensor this module allocates
+
+
+def _alloc(shape, device) -> torch.Tensor:
+    """fp32 output tensor with GUARD readable floats before and after it: the vector gathers of
+    deva_conv2d may touch (and then mask) a few elements beyond the ends of their inputs"""
+    n = 1
+    for s_ in shape:
+        n *= int(s_)
+    flat = torch.empty(n + 2 * GUARD, dtype=torch.float32, device=device)
+    return flat[GUARD:GUARD + n].view(*shape)
+
+
+def _guard_elems(t: Optional[torch.Tensor]) -> int:
+    """readable floats before the first / after the last element of t inside its storage"""
+    if t is None:
+        return 1 << 30
+    first = t.storage_offset()
+    last = first + sum((int(n) - 1) * int(st) for n, st in zip(t.shape, t.stride()))
+    total = t.untyped_storage().nbytes() // 4
+    return max(0, min(first, total - 1 - last))
+
+
 _WORKSPACE = {}
 _WORKSPACE_ELEMS = 16 * 1024 * 1024  # 64 MB of split-K scratch per device
 
@@ -127,7 +150,7 @@ def conv2d(pc: PackedConv, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, 
     oh = (h + 2 * pad - pc.kh) // stride + 1
     ow = (w + 2 * pad - pc.kw) // stride + 1
     if out is None:
-        out = torch.empty((batch, pc.cout, oh, ow), dtype=torch.float32, device=x0.device)
+        out = _alloc((batch, pc.cout, oh, ow), x0.device)
     elif tuple(out.shape) != (batch, pc.cout, oh, ow):
         raise DevaHipError('conv2d: bad output shape')
     d = ConvDesc()
@@ -152,6 +175,7 @@ def conv2d(pc: PackedConv, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, 
         d.residual, d.residual_batch_stride = None, 0
     d.act = act
     d.out = _p(out, name='out')
+    d.in_guard_elems = min(_guard_elems(x0), _guard_elems(x1), (1 << 31) - 1)
     ws = _workspace(out.device)
     d.workspace, d.workspace_elems = ws.data_ptr(), ws.numel()
     check(lib().deva_conv2d(d, _stream()), 'deva_conv2d')
@@ -161,7 +185,7 @@ def conv2d(pc: PackedConv, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, 
 # ------------------------------------------------------------------------------------------ pointwise
 def maxpool3x3s2(x: torch.Tensor, relu_after: bool = False) -> torch.Tensor:
     b, c, h, w = x.shape
-    out = torch.empty((b, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+    out = _alloc((b, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1), x.device)
     check(lib().deva_maxpool3x3s2(_p(x), _p(out), b * c, h, w, int(relu_after), _stream()), 'deva_maxpool3x3s2')
     return out
 
@@ -171,7 +195,7 @@ def upsample2x_add(x: torch.Tensor, skip: Optional[torch.Tensor]) -> torch.Tenso
     b, c, h, w = x.shape
     if skip is not None and tuple(skip.shape[-3:]) != (c, 2 * h, 2 * w):
         raise DevaHipError('upsample2x_add: skip shape mismatch')
-    out = torch.empty((b, c, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+    out = _alloc((b, c, 2 * h, 2 * w), x.device)
     check(lib().deva_upsample2x_add(_p(x), _p(skip), _p(out), b, c, h, w, _stream()), 'deva_upsample2x_add')
     return out
 
@@ -180,7 +204,7 @@ def area_downsample(x: torch.Tensor, factor: int) -> torch.Tensor:
     """[..., H, W] -> [..., H/factor, W/factor] box mean"""
     h, w = x.shape[-2:]
     planes = x.numel() // (h * w)
-    out = torch.empty((*x.shape[:-2], h // factor, w // factor), dtype=torch.float32, device=x.device)
+    out = _alloc((*x.shape[:-2], h // factor, w // factor), x.device)
     check(lib().deva_area_downsample(_p(x), _p(out), planes, h, w, factor, _stream()), 'deva_area_downsample')
     return out
 
@@ -229,11 +253,11 @@ def cbam(x: torch.Tensor, w1, b1, w2, b2, spatial: PackedConv) -> torch.Tensor:
     scale = torch.empty_like(avg)
     check(lib().deva_cbam_mlp(_p(avg), _p(mx), _p(w1), _p(b1), _p(w2), _p(b2), _p(scale), b, c, w1.shape[0],
                               _stream()), 'deva_cbam_mlp')
-    pooled = torch.empty((b, 2, h, w), dtype=torch.float32, device=dev)
+    pooled = _alloc((b, 2, h, w), dev)
     check(lib().deva_cbam_channel_pool(_p(x), _p(scale), _p(pooled), b, c, hw, _stream()),
           'deva_cbam_channel_pool')
     gate = conv2d(spatial, pooled, pad=spatial.kh // 2)
-    out = torch.empty_like(x)
+    out = _alloc(x.shape, dev)
     check(lib().deva_cbam_apply(_p(x), _p(scale), _p(gate), _p(out), b, c, hw, _stream()), 'deva_cbam_apply')
     return out
 
@@ -244,7 +268,7 @@ def gru_update(values: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
     hw = h.shape[-2] * h.shape[-1]
     if values.shape[1] != 3 * c:
         raise DevaHipError('gru_update: values must have 3x the channels of h')
-    out = torch.empty_like(h)
+    out = _alloc(h.shape, h.device)
     check(lib().deva_gru_update(_p(values), _p(h), _p(out), b, c, hw, _stream()), 'deva_gru_update')
     return out
 
