@@ -162,6 +162,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
     vsrc0 = p.in0 + (int64_t)b * p.bs0;
     vsrc1 = p.in1 ? p.in1 + (int64_t)b * p.bs1 : p.in0;
   }
+  f32x4 rbv[VEC ? B_V4 : 1];
+  unsigned v_mask = 0;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -171,27 +173,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  // ---- staging registers.  Two sets: the operands of K step s+2 are loaded while step s is on the
-  // matrix pipe and are written to LDS one step later, so a load has more than a full K step to land.
-  // Raw loaded values + validity bits are kept; select/relu happen at the LDS write.
-  struct Stage {
-    float4 ra[A_V4];
-    float rb[B_PT];
-    f32x4 rbv[VEC ? B_V4 : 1];
-    unsigned ok_a, ok_b, v_mask;
-  };
-  Stage sA, sB;
+  // staged operands: raw loaded values + validity bits; select/relu happen in store_tiles, AFTER
+  // the MFMA block, so the loads stay in flight while the matrix pipe works on the current tile
+  float4 ra[A_V4];
+  float rb[B_PT];
+  unsigned ok_a = 0, ok_b = 0;
 
-  // per-step temporaries of the gather (valid between stage_begin and the last stage_b of a step)
-  const float* st_ptr = nullptr;
+  // ---- staging of one K step, split into pieces so the main loop can interleave them with the
+  // MFMAs of the current step (an MFMA occupies the matrix pipe for 64 cycles while the wave keeps
+  // issuing independent VALU / memory instructions in its shadow)
+  const float* st_ptr = nullptr;  // fast path: per-step gather base of this thread
   bool st_okp = false;
   int st_k0 = 0;
 
-  auto stage_begin = [&](Stage& S, int k0) {
+  auto stage_begin = [&](int k0) {
     st_k0 = k0;
-    S.ok_a = 0;
-    S.ok_b = 0;
-    S.v_mask = 0;
+    ok_a = 0;
+    ok_b = 0;
     if (MODE != 2) {
       // the tap and the source tensor are uniform over the K step (channel counts are multiples
       // of BK): one pointer per step + a channel stride per element
@@ -207,24 +205,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
           cbase = k0 - tap * p.ctot;
         }
       }
-      int dy = 0, dx = 0;  // tap offset in the input
+      int ih = ih0, iw = iw0;
       if (MODE == 1) {
-        dy = tap / p.KW;
-        dx = tap - dy * p.KW;
+        const int dy = tap / p.KW;
+        ih += dy;
+        iw += tap - dy * p.KW;
       }
       const bool first = cbase < p.c0;
       if (VEC) {
-        const int ry = dy - p.pad, rx = dx - p.pad;  // relative to the output pixel ('same' conv)
+        const int dy = ih - ih0 - p.pad, dx = iw - iw0 - p.pad;  // tap offset relative to the centre
+        v_mask = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const bool ok = vq_ok && ((unsigned)(v_oh[j] + ry) < (unsigned)p.H) &&
-                          ((unsigned)(v_ow[j] + rx) < (unsigned)p.W);
-          S.v_mask |= ok ? (1u << j) : 0u;
+          const bool ok = vq_ok && ((unsigned)(v_oh[j] + dy) < (unsigned)p.H) &&
+                          ((unsigned)(v_ow[j] + dx) < (unsigned)p.W);
+          v_mask |= ok ? (1u << j) : 0u;
         }
         st_ptr = (first ? (vsrc0 + (int64_t)cbase * p.HW) : (vsrc1 + (int64_t)(cbase - p.c0) * p.HW)) +
-                 (v_pix0 + ry * p.W + rx);
+                 (v_pix0 + dy * p.W + dx);
       } else {
-        const int ih = ih0 + dy, iw = iw0 + dx;
         st_okp = n_ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
         st_ptr = (first ? (src0 + (int64_t)cbase * p.HW) : (src1 + (int64_t)(cbase - p.c0) * p.HW)) +
                  (st_okp ? (ih * p.W + iw) : 0);
@@ -233,28 +232,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
   };
 
   // A: rows k0..k0+BK-1 of the packed weights, columns m0..m0+BM-1.  Loads are unconditional from a
-  // clamped (always valid) address: a load under a branch makes hipcc wait vmcnt(0) right behind it
-  // and serialises the staging.
-  auto stage_a = [&](Stage& S, int i) {
+  // clamped (always valid) address, the select happens when the tile is written to LDS: a load under
+  // a branch makes hipcc wait vmcnt(0) right behind it and serialises the staging.
+  auto stage_a = [&](int i) {
     const int e = tid + i * THREADS;
     const int kr = e / (BM / 4);
     const int mc = (e % (BM / 4)) * 4;
     const int k = st_k0 + kr;
     const int m = m0 + mc;
     const bool ok = (e < BK * BM / 4) && (k < p.K) && (m < p.cout_pad);
-    S.ra[i] = *reinterpret_cast<const float4*>(p.w + (ok ? ((int64_t)k * p.cout_pad + m) : 0));
-    S.ok_a |= ok ? (1u << i) : 0u;
+    ra[i] = *reinterpret_cast<const float4*>(p.w + (ok ? ((int64_t)k * p.cout_pad + m) : 0));
+    ok_a |= ok ? (1u << i) : 0u;
   };
 
-  auto stage_bv = [&](Stage& S, int i) {  // VEC: 4 consecutive pixels of K row vk + i*KGV
+  // B: im2col gather of element i of this thread
+  auto stage_bv = [&](int i) {  // VEC: 4 consecutive pixels of K row vk + i*KGV
     const int ci = vk + i * KGV;
     const bool kin = (MODE == 1) || (st_k0 + ci < p.K);
-    S.rbv[i] = *reinterpret_cast<const f32x4_u*>(st_ptr + (kin ? (int64_t)ci * p.HW : 0));
-    S.ok_b |= kin ? (1u << i) : 0u;
+    rbv[i] = *reinterpret_cast<const f32x4_u*>(st_ptr + (kin ? (int64_t)ci * p.HW : 0));
+    ok_b |= kin ? (1u << i) : 0u;
   };
 
-  // B: im2col gather of element i of this thread (scalar path)
-  auto stage_b = [&](Stage& S, int i) {
+  auto stage_b = [&](int i) {
     const int ci = bk_group + i * KG;  // row within this K step
     if (MODE == 2) {
       // generic per-element decode of k -> (tap, channel, source): 2/3/4-channel stems, odd splits
@@ -267,34 +266,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
       const bool first = ok ? (c < p.c0) : true;
       const float* sp = first ? src0 : src1;
       const int64_t off = ok ? ((int64_t)(first ? c : (c - p.c0)) * p.HW + (ih * p.W + iw)) : 0;
-      S.rb[i] = sp[off];
-      S.ok_b |= ok ? (1u << i) : 0u;
+      rb[i] = sp[off];
+      ok_b |= ok ? (1u << i) : 0u;
     } else {
       const bool kin = (MODE == 1) || (st_k0 + ci < p.K);    // MODE 0 may have a K tail (513 channels)
-      S.rb[i] = st_ptr[kin ? (int64_t)ci * p.HW : 0];         // clamped: never reads past the source
-      S.ok_b |= (st_okp && kin) ? (1u << i) : 0u;
+      rb[i] = st_ptr[kin ? (int64_t)ci * p.HW : 0];           // clamped: never reads past the source
+      ok_b |= (st_okp && kin) ? (1u << i) : 0u;
     }
   };
 
-  // slice `kk` of the staging of one K step (kk == -1: everything at once, for the prologue)
-  constexpr int NKK = BK / 2;  // MFMA groups (k pairs) per K step
-  auto stage_slice = [&](Stage& S, int k0, int kk) {
-    if (kk <= 0) stage_begin(S, k0);
-#pragma unroll
-    for (int i = 0; i < A_V4; ++i)
-      if (kk < 0 || i * (NKK / SPREAD) / A_V4 == kk) stage_a(S, i);
-    if (VEC) {
-#pragma unroll
-      for (int i = 0; i < B_V4; ++i)
-        if (kk < 0 || i * (NKK / SPREAD) / B_V4 == kk) stage_bv(S, i);
-    } else {
-#pragma unroll
-      for (int i = 0; i < B_PT; ++i)
-        if (kk < 0 || i * (NKK / SPREAD) / B_PT == kk) stage_b(S, i);
-    }
-  };
-
-  auto store_tiles = [&](const Stage& S, int buf) {
+  auto store_tiles = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < A_V4; ++i) {
       const int e = tid + i * THREADS;
@@ -302,19 +283,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
         const int kr = e / (BM / 4);
         const int mc = (e % (BM / 4)) * 4;
         *reinterpret_cast<float4*>(&As[buf][kr][mc]) =
-            (S.ok_a & (1u << i)) ? S.ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            (ok_a & (1u << i)) ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
     if (VEC) {
 #pragma unroll
       for (int i = 0; i < B_V4; ++i) {
-        f32x4 v = S.rbv[i];
-        const bool kin = S.ok_b & (1u << i);
+        f32x4 v = rbv[i];
+        const bool kin = ok_b & (1u << i);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float x = v[j];
           if (p.relu_in) x = fmaxf(x, 0.0f);
-          v[j] = (kin && (S.v_mask & (1u << j))) ? x : 0.0f;
+          v[j] = (kin && (v_mask & (1u << j))) ? x : 0.0f;
         }
         *reinterpret_cast<f32x4*>(&Bs[buf][vk + i * KGV][4 * vq]) = v;
       }
@@ -322,15 +303,37 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
     }
 #pragma unroll
     for (int i = 0; i < B_PT; ++i) {
-      float v = S.rb[i];
+      float v = rb[i];
       if (p.relu_in) v = fmaxf(v, 0.0f);
-      Bs[buf][bk_group + i * KG][bn_local] = (S.ok_b & (1u << i)) ? v : 0.0f;
+      Bs[buf][bk_group + i * KG][bn_local] = (ok_b & (1u << i)) ? v : 0.0f;
     }
   };
 
-  // one K step on the matrix pipe (LDS buffer `buf`), with the staging of K offset k_stage into S
-  // sliced into the shadow of the MFMA groups
-  auto compute_step = [&](int buf, Stage& S, int k_stage) {
+  constexpr int NKK = BK / 2;  // MFMA groups (k pairs) per K step
+  // split-K: this workgroup accumulates K steps [ks0, ks0 + ksteps) of the layer
+  int ks0 = 0, ksteps = (p.K + BK - 1) / BK;
+  if (p.splits > 1) {
+    const int per = (ksteps + p.splits - 1) / p.splits;
+    ks0 = (int)blockIdx.y * per;
+    ksteps = max(0, min(ksteps - ks0, per));
+  }
+  stage_begin(ks0 * BK);
+#pragma unroll
+  for (int i = 0; i < A_V4; ++i) stage_a(i);
+  if (VEC) {
+#pragma unroll
+    for (int i = 0; i < B_V4; ++i) stage_bv(i);
+  } else {
+#pragma unroll
+    for (int i = 0; i < B_PT; ++i) stage_b(i);
+  }
+  store_tiles(0);
+  __syncthreads();
+
+  for (int s = 0; s < ksteps; ++s) {
+    const int buf = s & 1;
+    // the last step re-stages step 0 (valid addresses, result unused) instead of branching
+    const int k_next = (s + 1 < ksteps) ? (ks0 + s + 1) * BK : 0;
     float fa[2][TM], fb[2][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) fa[0][i] = As[buf][half][wm0 + i * 32 + l31];
@@ -350,35 +353,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][i], fb[kk & 1][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      stage_slice(S, k_stage, kk);
+      // a slice of the next tile's staging in the shadow of the MFMAs just issued
+      if (kk == 0) stage_begin(k_next);
+#pragma unroll
+      for (int i = 0; i < A_V4; ++i)
+        if (i * (NKK / SPREAD) / A_V4 == kk) stage_a(i);
+      if (VEC) {
+#pragma unroll
+        for (int i = 0; i < B_V4; ++i)
+          if (i * (NKK / SPREAD) / B_V4 == kk) stage_bv(i);
+      } else {
+#pragma unroll
+        for (int i = 0; i < B_PT; ++i)
+          if (i * (NKK / SPREAD) / B_PT == kk) stage_b(i);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
-  };
-
-  // split-K: this workgroup accumulates K steps [ks0, ks0 + ksteps) of the layer
-  int ks0 = 0, ksteps = (p.K + BK - 1) / BK;
-  if (p.splits > 1) {
-    const int per = (ksteps + p.splits - 1) / p.splits;
-    ks0 = (int)blockIdx.y * per;
-    ksteps = max(0, min(ksteps - ks0, per));
-  }
-  // K offset of local step t; steps past the end re-stage offset 0 (valid addresses, result unused)
-  auto k_of = [&](int t) { return (t < ksteps) ? (ks0 + t) * BK : 0; };
-
-  stage_slice(sA, k_of(0), -1);
-  store_tiles(sA, 0);
-  __syncthreads();
-  stage_slice(sB, k_of(1), -1);  // step 1 in flight
-
-  for (int s = 0; s < ksteps; s += 2) {
-    compute_step(0, sA, k_of(s + 2));  // step s on buffer 0; step s+2 -> sA
-    store_tiles(sB, 1);                // step s+1 -> buffer 1
+    store_tiles(buf ^ 1);
     __syncthreads();
-    if (s + 1 < ksteps) {
-      compute_step(1, sB, k_of(s + 3));
-      store_tiles(sA, 0);
-      __syncthreads();
-    }
   }
 
   if (p.splits > 1) {
