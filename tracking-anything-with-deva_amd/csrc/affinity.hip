@@ -111,72 +111,6 @@ __device__ __forceinline__ uint64_t prune_list(volatile uint64_t* row, uint32_t 
   return thr;
 }
 
-// Prune MANY lists at once: lanes (q, q+32) own the list of query q and select its exact k-th best
-// key by per-lane bisection over their half of the list (no ballots, no scalar dependency chain), then
-// compact in place.  ~25k cycles for all 32 queries together versus ~4.4k per query for the
-// wave-cooperative prune above: used when several lists fill up at the same tile (always the case in
-// the first few hundred tokens of a range).  `mine` = this lane's list takes part.
-__device__ __forceinline__ void prune_all(uint64_t* cand_w, volatile uint32_t* cnt, volatile float* tau, int k,
-                                          int lane, bool mine) {
-  const int l31 = lane & 31, half = lane >> 5;
-  uint64_t* row = cand_w + l31 * STRIDE;
-  const uint32_t* hi32 = reinterpret_cast<const uint32_t*>(row) + 1;  // high (score) dword of entry j at [2j]
-  const int c = mine ? (int)cnt[l31] : 0;
-  const int j0 = half * 64, j1 = max(j0, min(c, j0 + 64));
-  DEVA_COMPILER_FENCE();
-  uint32_t T = 0;
-  for (int b = 31; b >= 0; --b) {
-    const uint32_t trial = T | (1u << b);
-    int n = 0;
-#pragma unroll 8
-    for (int j = j0; j < j1; ++j) n += (hi32[2 * j] >= trial) ? 1 : 0;
-    n += __shfl_xor(n, 32);
-    if (n >= k) T = trial;
-  }
-  int above = 0, ties = 0;
-#pragma unroll 8
-  for (int j = j0; j < j1; ++j) {
-    const uint32_t h = hi32[2 * j];
-    above += (h > T) ? 1 : 0;
-    ties += (h == T) ? 1 : 0;
-  }
-  above += __shfl_xor(above, 32);
-  ties += __shfl_xor(ties, 32);
-  const int need = k - above;
-  uint32_t L = 0;
-  if (__any(mine && ties > need)) {  // the k-th score is tied: break the tie on the index half
-    const bool tied = mine && ties > need;
-    for (int b = 31; b >= 0; --b) {
-      const uint32_t trial = L | (1u << b);
-      int n = 0;
-      for (int j = j0; j < j1; ++j) {
-        const uint64_t e = row[j];
-        n += ((uint32_t)(e >> 32) == T && (uint32_t)e >= trial) ? 1 : 0;
-      }
-      n += __shfl_xor(n, 32);
-      if (tied && n >= need) L = trial;
-    }
-  }
-  const uint64_t thr = ((uint64_t)T << 32) | L;
-  // in-place compaction of each half (write index <= read index), then the upper half moves down
-  int w = j0;
-  for (int j = j0; j < j1; ++j) {
-    const uint64_t e = row[j];
-    if (e >= thr) row[w++] = e;
-  }
-  const int kept = w - j0;
-  const int kept_lo = __shfl(kept, l31);  // survivors of the lower half
-  DEVA_COMPILER_FENCE();
-  if (half == 1 && kept_lo < 64)
-    for (int j = 0; j < kept; ++j) row[kept_lo + j] = row[64 + j];
-  DEVA_COMPILER_FENCE();
-  if (mine && half == 0 && c >= k) {
-    cnt[l31] = (uint32_t)k;
-    tau[l31] = from_orderable(T);
-  }
-  DEVA_COMPILER_FENCE();
-}
-
 struct AffArgs {
   const float* key_long;
   const float* shr_long;
@@ -259,12 +193,6 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
     {
       const uint32_t c_mine = cnt[l31];
       uint64_t need = __ballot(c_mine > (uint32_t)(CAP - TOKT)) & 0xffffffffull;
-      if (__popcll(need) >= 6) {
-        // many lists are about to overflow (start of a range): prune them together, and take along
-        // every list that is more than half full
-        prune_all(&s_cand[wave][0][0], cnt, tau, p.k, lane, c_mine > (uint32_t)(CAP / 2));
-        need = 0;
-      }
       while (need) {
         const int qq = __ffsll((unsigned long long)need) - 1;
         need &= need - 1;
@@ -333,9 +261,13 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
   }
 
   // ---- final prune of every over-full list; the (unsorted) best <= k of this range go to global memory
-  {
-    const uint32_t c_mine = cnt[l31];
-    if (__any(c_mine > (uint32_t)p.k)) prune_all(&s_cand[wave][0][0], cnt, tau, p.k, lane, c_mine > (uint32_t)p.k);
+  for (int qq = 0; qq < QT; ++qq) {
+    const uint32_t c = cnt[qq];
+    if (c > (uint32_t)p.k) {
+      prune_list(cand + qq * STRIDE, c, p.k, lane);
+      if (lane == 0) cnt[qq] = (uint32_t)p.k;
+      DEVA_COMPILER_FENCE();
+    }
   }
   const int nq = min(QT, p.hw - q0);
   uint64_t* dst = p.part + ((int64_t)split * p.hw + q0) * p.k;
