@@ -71,7 +71,12 @@ __device__ __forceinline__ uint64_t kth_largest(const uint64_t (&e)[E], int n_li
 #pragma unroll
     for (int i = 0; i < E; ++i)
       if (i < n_live) cnt += wave_count((uint32_t)(e[i] >> 32) >= trial);
-    if (cnt >= k) T = trial;
+    if (cnt >= k) {
+      T = trial;
+      // exactly k keys at or above the trial: it separates the top-k set, no need to resolve the
+      // remaining bits (typically reached after ~10 of the 32 steps)
+      if (cnt == k) return (uint64_t)T << 32;
+    }
   }
   int above = 0, ties = 0;
 #pragma unroll
