@@ -21,16 +21,11 @@
 // merges the per-range lists, applies exp/normalise and accumulates the usage counters.
 #include <math.h>
 
-#include <type_traits>
-
 #include "common.h"
 
 #pragma clang fp contract(off)
 
 namespace deva {
-#ifdef DEVA_AFF_PROFILE
-long long* g_aff_prof_ptr = nullptr;
-#endif
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -57,14 +52,6 @@ __device__ __forceinline__ uint64_t make_key(float score, uint32_t token) {
 }
 
 #define DEVA_COMPILER_FENCE() asm volatile("" ::: "memory")
-
-#ifdef DEVA_AFF_PROFILE
-#define PROF_T(v) const long long v = __builtin_readcyclecounter()
-#define PROF_ADD(slot, t1, t0) prof_acc[slot] += (t1) - (t0)
-#else
-#define PROF_T(v)
-#define PROF_ADD(slot, t1, t0)
-#endif
 
 __device__ __forceinline__ int wave_count(bool pred) { return __popcll(__ballot(pred)); }
 // number of set bits of a wave ballot below this lane
@@ -144,7 +131,6 @@ struct AffArgs {
   int tiles_per_split;
   int total_tiles;
   uint64_t* part;
-  long long* prof;  // DEVA_AFF_PROFILE builds only: [waves][4] cycle totals (prune, operand, mfma, epilogue)
 };
 
 __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs p) {
@@ -205,38 +191,28 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
   };
   if (t_begin < t_end) prefetch(t_begin);
 
-  // ---- software pipeline over token tiles: while the matrix pipe accumulates tile i (64 MFMAs into
-  // accumulator set i&1), the VALU turns the finished accumulators of tile i-1 into scores and
-  // threshold decisions in the shadow of those MFMAs (an MFMA occupies the pipe for 64 cycles, the
-  // wave keeps issuing independent instructions meanwhile); the candidate append that follows is
-  // straight-line code (rejected scores are written to the spare slot at the end of the list row).
-  f32x16 accA[2], accB[2];
-  float a_op[CK / 2];
-  float ms_prev = 0.0f, ms_cur = 0.0f;
-  float tau_l = -INFINITY;
-  float sc[16];
-  uint32_t pass = 0;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int n_base = tile * TOKT;
 
-  // prune lists that could overflow while one more tile (<= 32 candidates per query) is appended
-  auto prune_phase = [&]() {
-    const uint32_t c_mine = cnt[l31];
-    uint64_t need = __ballot(c_mine > (uint32_t)(CAP - TOKT)) & 0xffffffffull;
-    while (need) {
-      const int qq = __ffsll((unsigned long long)need) - 1;
-      need &= need - 1;
-      const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)c_mine, qq);
-      const uint64_t thr = prune_list(cand + qq * STRIDE, c, p.k, lane);
-      if (lane == 0) {
-        cnt[qq] = (uint32_t)p.k;
-        tau[qq] = from_orderable((uint32_t)(thr >> 32));
+    // ---- prune lists that could overflow during this tile (at most 32 appends per query per tile)
+    {
+      const uint32_t c_mine = cnt[l31];
+      uint64_t need = __ballot(c_mine > (uint32_t)(CAP - TOKT)) & 0xffffffffull;
+      while (need) {
+        const int qq = __ffsll((unsigned long long)need) - 1;
+        need &= need - 1;
+        const uint64_t thr = prune_list(cand + qq * STRIDE, cnt[qq], p.k, lane);
+        if (lane == 0) {
+          cnt[qq] = (uint32_t)p.k;
+          tau[qq] = from_orderable((uint32_t)(thr >> 32));
+        }
+        DEVA_COMPILER_FENCE();
       }
-      DEVA_COMPILER_FENCE();
     }
-    tau_l = tau[l31];
-  };
+    const float tau_l = tau[l31];
 
-  // operand of the tile that was prefetched (channel 2t + half of this lane's token) + next prefetch
-  auto take_operand = [&](int next_tile) {
+    // ---- this tile's operand: channel 2t + half of this lane's token, then start the next loads
+    float a_op[CK / 2];
 #pragma unroll
     for (int t = 0; t < CK / 2; ++t) {
       const float4 v = xbuf[t >> 1];
@@ -244,94 +220,49 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
       const float hi = (t & 1) ? v.w : v.y;
       a_op[t] = half ? hi : lo;
     }
-    ms_cur = ms_buf;
-    prefetch(next_tile);
-  };
+    const float ms_mine = ms_buf;
+    prefetch(min(tile + 1, t_end - 1));
 
-  // score of accumulator row r of the previous tile (query l31, token n_prev + (r&3) + 8*(r>>2) + 4*half)
-  auto score_row = [&](const f32x16& aA, const f32x16& aB, int r, int n_prev) {
-    const int j = (r & 3) + 8 * (r >> 2) + 4 * half;
-    const float ms = __shfl(ms_prev, j);
-    float v = (-aA[r] + 2.0f * aB[r]) - bsq;
-    v = v * ms * 0.125f;
-    sc[r] = v;
-    const bool ok = (n_prev + j < p.n_total) && (v >= tau_l);
-    pass |= ok ? (1u << r) : 0u;
-  };
-
-  // branch-free append of the passing scores of the previous tile
-  auto append_prev = [&](int n_prev) {
-    const uint32_t np = (uint32_t)__popc(pass);
-    uint32_t pos = __hip_atomic_fetch_add((uint32_t*)&s_cnt[wave][l31], np, __ATOMIC_RELAXED,
-                                          __HIP_MEMORY_SCOPE_WORKGROUP);
-    volatile uint64_t* row = cand + l31 * STRIDE;
+    f32x16 accA, accB;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int j = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const bool ok = pass & (1u << r);
-      row[ok ? pos : (uint32_t)CAP] = make_key(sc[r], (uint32_t)(n_prev + j));  // slot CAP = scratch
-      pos += ok ? 1u : 0u;
-    }
-    pass = 0;
-    DEVA_COMPILER_FENCE();
-  };
-
-  // MFMAs of the current tile into set P; with EPI the scores of the previous tile (set P^1) are
-  // computed between them
-  auto mfma_tile = [&](auto par, auto with_epi, int n_prev) {
-    constexpr int P = decltype(par)::value;
-    constexpr bool EPI = decltype(with_epi)::value;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      accA[P][r] = 0.0f;
-      accB[P][r] = 0.0f;
+      accA[r] = 0.0f;
+      accB[r] = 0.0f;
     }
 #pragma unroll
     for (int t = 0; t < CK / 2; ++t) {
       const float a = a_op[t];
-      accA[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(a * a, bqe[t], accA[P], 0, 0, 0);
-      accB[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bqk[t], accB[P], 0, 0, 0);
-      if (EPI && (t & 1)) score_row(accA[P ^ 1], accB[P ^ 1], t >> 1, n_prev);
+      accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a * a, bqe[t], accA, 0, 0, 0);
+      accB = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bqk[t], accB, 0, 0, 0);
     }
-  };
 
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using Yes = std::integral_constant<bool, true>;
-  using No = std::integral_constant<bool, false>;
-
-  if (t_begin < t_end) {
-    // tile 0 of the range: nothing to overlap yet
-    prune_phase();
-    take_operand(min(t_begin + 1, t_end - 1));
-    mfma_tile(I0{}, No{}, 0);
-    ms_prev = ms_cur;
-    int par = 1;
-    for (int tile = t_begin + 1; tile < t_end; ++tile, par ^= 1) {
-      const int n_prev = (tile - 1) * TOKT;
-      prune_phase();
-      take_operand(min(tile + 1, t_end - 1));
-      if (par) {
-        mfma_tile(I1{}, Yes{}, n_prev);
-      } else {
-        mfma_tile(I0{}, Yes{}, n_prev);
-      }
-      append_prev(n_prev);
-      ms_prev = ms_cur;
-    }
-    // drain: scores of the last tile
-    {
-      const int n_prev = (t_end - 1) * TOKT;
-      prune_phase();
-      if (par) {  // the last tile went into set par^1
+    // ---- scores of this lane: query l31, tokens n_base + (r&3) + 8*(r>>2) + 4*half
+    uint32_t pass = 0;
+    float sc[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) score_row(accA[0], accB[0], r, n_prev);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) score_row(accA[1], accB[1], r, n_prev);
-      }
-      append_prev(n_prev);
+    for (int r = 0; r < 16; ++r) {
+      const int j = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float ms = __shfl(ms_mine, j);
+      float v = (-accA[r] + 2.0f * accB[r]) - bsq;
+      v = v * ms * 0.125f;
+      sc[r] = v;
+      const bool ok = (n_base + j < p.n_total) && (v >= tau_l);
+      pass |= ok ? (1u << r) : 0u;
     }
+    const int np = __popc(pass);
+    if (np) {
+      uint32_t pos = __hip_atomic_fetch_add((uint32_t*)&s_cnt[wave][l31], (uint32_t)np, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_WORKGROUP);
+      volatile uint64_t* row = cand + l31 * STRIDE;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (pass & (1u << r)) {
+          const int j = (r & 3) + 8 * (r >> 2) + 4 * half;
+          row[pos++] = make_key(sc[r], (uint32_t)(n_base + j));
+        }
+      }
+    }
+    DEVA_COMPILER_FENCE();
   }
 
   // ---- final prune of every over-full list; the (unsorted) best <= k of this range go to global memory
@@ -487,12 +418,6 @@ __global__ __launch_bounds__(256) void readout_sparse_kernel(const int32_t* __re
 
 using namespace deva;
 
-#ifdef DEVA_AFF_PROFILE
-extern "C" int deva_aff_prof_read(long long* host, int n_waves) {
-  return (int)hipMemcpy(host, deva::g_aff_prof_ptr, sizeof(long long) * 4 * n_waves, hipMemcpyDeviceToHost);
-}
-#endif
-
 extern "C" int64_t deva_affinity_workspace(int hw, int k, int splits) { return (int64_t)splits * hw * k; }
 
 extern "C" int deva_affinity_default_splits(int n_total, int hw) {
@@ -534,15 +459,6 @@ extern "C" int deva_affinity_topk(const float* key_long, const float* shr_long, 
   a.total_tiles = (int)ceil_div(n_total, TOKT);
   a.tiles_per_split = (int)ceil_div(a.total_tiles, splits);
   a.part = part_keys;
-  a.prof = nullptr;
-#ifdef DEVA_AFF_PROFILE
-  {
-    static long long* g_prof = nullptr;
-    if (!g_prof) hipMalloc(&g_prof, sizeof(long long) * 4 * 65536);
-    a.prof = g_prof;
-    deva::g_aff_prof_ptr = g_prof;
-  }
-#endif
   dim3 grid((unsigned)ceil_div(hw, WAVES * QT), (unsigned)splits);
   hipLaunchKernelGGL(affinity_topk_kernel, grid, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
   return check_launch("deva_affinity_topk");
