@@ -221,6 +221,26 @@ int deva_similarity_dense(const float* key, const float* shr, const float* sel,
  * value / shrinkage readout (memory_manager.py:270-274) as a GEMM on the matrix cores. */
 int deva_softmax_columns(float* x, int n, int p, int ld, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Detection merging (match_and_merge / merge_by_iou, deva/inference/segment_merging.py:17-143;
+ * caller: DEVAInferenceCore.incorporate_detection, inference_core.py:137-198).
+ *
+ * deva_label_histogram: joint histogram of the propagated index mask `ours` (tmp ids 0..n_our, int64)
+ *   and the detection index mask `news` (arbitrary int64 ids; column j = position in new_ids, column
+ *   n_new = anything else): counts[t*(n_new+1)+j] += 1 per pixel (int32, must be zeroed by the caller).
+ *   Every intersection / area / union of _get_iou (segment_merging.py:17-22) is an entry or a row /
+ *   column sum of this matrix -- one device pass and one small copy instead of one sync per pair.
+ * deva_merge_paint: replays the area-ordered repaint (segment_merging.py:62-85): source t (propagated)
+ *   and source j (detection) each carry (order, label), order < 0 = not painted; a pixel takes the
+ *   label of the source painted last; the result is written as one-hot planes out[o][pixel] =
+ *   (label == out_ids[o])   (ObjectManager.make_one_hot, object_manager.py:133-141). */
+int deva_label_histogram(const int64_t* ours, const int64_t* news, const int64_t* new_ids, int n_our,
+                         int n_new, int64_t pixels, int32_t* counts, void* stream);
+int deva_merge_paint(const int64_t* ours, const int64_t* news, const int64_t* new_ids, int n_our,
+                     int n_new, const int32_t* our_order, const int64_t* our_label,
+                     const int32_t* new_order, const int64_t* new_label, const int64_t* out_ids,
+                     int n_out, int64_t pixels, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -214,6 +214,31 @@ def softmax_columns(x, p):
     return x
 
 
+def label_histogram(ours, news, new_ids, n_our):
+    n_new = new_ids.numel()
+    t = ours.reshape(-1).clone()
+    t[(t < 0) | (t > n_our)] = 0
+    col = torch.full_like(t, n_new)
+    for j in range(n_new):
+        col[news.reshape(-1) == new_ids[j]] = j
+    flat = torch.bincount(t * (n_new + 1) + col, minlength=(n_our + 1) * (n_new + 1))
+    return flat.reshape(n_our + 1, n_new + 1).int()
+
+
+def merge_paint(ours, news, new_ids, our_order, our_label, new_order, new_label, out_ids):
+    n_our, n_new = our_order.numel() - 1, new_ids.numel()
+    t = ours.clone()
+    t[(t < 0) | (t > n_our)] = 0
+    order = torch.where(t > 0, our_order.long()[t], torch.full_like(t, -1))
+    label = torch.where(order >= 0, our_label[t], torch.zeros_like(t))
+    for j in range(n_new):
+        sel = (news == new_ids[j]) & (new_order[j].long() >= order) & (new_order[j] >= 0)
+        order = torch.where(sel, new_order[j].long().expand_as(order), order)
+        label = torch.where(sel, new_label[j].expand_as(label), label)
+    planes = [((order >= 0) & (label == o)).float() for o in out_ids]
+    return torch.stack(planes, 0) if planes else torch.zeros((0, *ours.shape))
+
+
 def install(monkeypatch):
     """patch every public op of deva.hip.ops with its emulation"""
     for name in real.__all__ + ['require_hip']:

@@ -149,6 +149,41 @@ def gen_vos_example(net):
     print('vos example labels', labels, [tuple(p.shape) for p in outs])
 
 
+def _manager_state(om):
+    return dict(ids=[int(o.id) for o in om.obj_to_tmp_id], tmp=[int(t) for t in om.obj_to_tmp_id.values()],
+                poke=[int(o.poke_count) for o in om.obj_to_tmp_id],
+                cats=[[None if c is None else int(c) for c in o.category_ids] for o in om.obj_to_tmp_id],
+                isthing=[o.isthing for o in om.obj_to_tmp_id])
+
+
+def gen_merge():
+    """match_and_merge (segment_merging.py:89-143) stand-alone, normal and incremental mode"""
+    from deva.inference.object_info import ObjectInfo
+    from deva.inference.object_manager import ObjectManager
+    from deva.inference.segment_merging import match_and_merge
+    out = {}
+    for seed in (0, 1):
+        for incremental in (False, True):
+            ours, our_info, news, new_info = scenarios.merge_case(seed)
+            om = ObjectManager()
+            om.add_new_objects([ObjectInfo(**i) for i in our_info])
+            merged = match_and_merge(ours, news, om, [ObjectInfo(**i) for i in new_info],
+                                     incremental_mode=incremental)
+            out[f'seed{seed}_inc{int(incremental)}'] = dict(onehot=merged.to(torch.uint8), state=_manager_state(om))
+    torch.save(out, os.path.join(HERE, 'merge_cases.pt'))
+
+
+def gen_detection_e2e(net):
+    from deva.inference.object_info import ObjectInfo
+    sc = scenarios.DETECTION
+    outs, core = scenarios.run_detection_scenario(lambda cfg: DEVAInferenceCore(net, cfg), ObjectInfo, sc)
+    np.savez_compressed(os.path.join(HERE, 'e2e_detections.npz'),
+                        **{f'prob_sub_{t}': p[:, ::2, ::2].numpy() for t, p in enumerate(outs)},
+                        nchan=np.array([p.shape[0] for p in outs]),
+                        state=json.dumps(_manager_state(core.object_manager)))
+    print('detections: channels per frame', [p.shape[0] for p in outs], _manager_state(core.object_manager)['ids'])
+
+
 if __name__ == '__main__':
     cfg = synth.base_config()
     net, spec, sd = build_reference(cfg)
@@ -157,5 +192,7 @@ if __name__ == '__main__':
     gen_stages(net)
     gen_e2e(net)
     gen_vos_example(net)
+    gen_merge()
+    gen_detection_e2e(net)
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -61,3 +61,70 @@ def run_scenario(make_core: Callable[[Dict], object], sc: Dict, device: str = 'c
         if on_frame is not None:
             on_frame(t, core)
     return outs, core
+
+
+# ---------------------------------------------------------------------------------------------
+# detections + propagation (evaluation/eval_with_detections.py:280-297, "online" setting): an
+# image-level detection mask is merged every `every`-th frame, frames in between are propagated.
+DETECTION = dict(H=96, W=128, frames=13, every=4,
+                 cfg=dict(mem_every=2, max_missed_detection_count=1, max_num_objects=-1))
+
+
+def detection_mask(sc, t):
+    """index mask with ids 10 (drifting box), 20 (static box), 30 (only in the first detection),
+    40 (appears from the second detection on); plus their category / thing flags"""
+    H, W = sc['H'], sc['W']
+    m = torch.zeros(H, W, dtype=torch.long)
+    x = 8 + 2 * t
+    m[10:50, x:x + 40] = 10
+    m[55:90, 70:120] = 20
+    info = [dict(id=10, category_id=3, isthing=True), dict(id=20, category_id=7, isthing=False)]
+    if t == 0:
+        m[60:90, 5:35] = 30
+        info.append(dict(id=30, category_id=3, isthing=True))
+    else:
+        m[2:20, 90:125] = 40
+        info.append(dict(id=40, category_id=None, isthing=None))
+    return m, info
+
+
+def run_detection_scenario(make_core, make_info, sc, device='cpu'):
+    """make_info(id=..., category_id=..., isthing=...) builds the implementation's ObjectInfo"""
+    import numpy as np
+    np.random.seed(0)  # ObjectManager draws replacement ids from np.random on id collisions
+    cfg = synth.base_config(**sc['cfg'])
+    core = make_core(cfg)
+    stream = synth.FrameStream(sc['H'], sc['W'], seed=1)
+    outs = []
+    for t in range(sc['frames']):
+        img = stream.next().to(device)
+        if t % sc['every'] == 0:
+            m, info = detection_mask(sc, t)
+            p = core.incorporate_detection(img, m.to(device), [make_info(**i) for i in info])
+        else:
+            p = core.step(img, end=(t == sc['frames'] - 1))
+        outs.append(p.detach().float().cpu())
+    return outs, core
+
+
+def merge_case(seed):
+    """inputs of a stand-alone match_and_merge call: propagated tmp-id mask with 3 objects
+    (thing / stuff / untyped), detections that match, overlap too little, are new, or overlap an
+    object of another type"""
+    g = torch.Generator().manual_seed(seed)
+    H, W = 64, 80
+    ours = torch.zeros(H, W, dtype=torch.long)
+    ours[5:30, 5:35] = 1
+    ours[35:60, 10:45] = 2
+    ours[10:40, 50:75] = 3
+    our_info = [dict(id=11, category_id=1, isthing=True), dict(id=12, category_id=2, isthing=False),
+                dict(id=13, category_id=None, isthing=None)]
+    news = torch.zeros(H, W, dtype=torch.long)
+    dx = int(torch.randint(0, 4, (1,), generator=g))
+    news[6:30, 6 + dx:36 + dx] = 101    # thing, IoU > 0.5 with object 11
+    news[50:64, 10:30] = 102            # stuff, small overlap with object 12 -> new object
+    news[12:40, 52:76] = 103            # thing over the untyped object 13 -> no cross-type match, new
+    news[0:4, 60:80] = 104              # untyped, new
+    new_info = [dict(id=101, category_id=1, isthing=True), dict(id=102, category_id=2, isthing=False),
+                dict(id=103, category_id=5, isthing=True), dict(id=104, category_id=None, isthing=None)]
+    return ours, our_info, news, new_info

@@ -86,3 +86,26 @@ def test_similarity_dense_and_softmax_columns(nc, p):
     out = ops.conv2d(pc, to_dev(vals).reshape(1, nc, 1, 512)).view(p, 512)
     ref = want[:, :p].t() @ vals
     assert max_err(out, ref) <= 1e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize('h,w,n_our,n_new', [(64, 80, 3, 4), (480, 864, 8, 12), (17, 5, 0, 2), (33, 47, 5, 0)])
+def test_label_histogram_and_merge_paint(h, w, n_our, n_new):
+    g = torch.Generator().manual_seed(h + n_our)
+    ours = torch.randint(0, n_our + 1, (h, w), generator=g)
+    new_ids = (torch.randperm(5000, generator=g)[:n_new] + 300).long()
+    pick = torch.randint(0, n_new + 2, (h, w), generator=g)  # n_new -> background 0, n_new+1 -> unlisted id
+    table = torch.cat([new_ids, torch.tensor([0, 77777])])
+    news = table[pick]
+    want = emu_ops.label_histogram(ours, news, new_ids, n_our)
+    got = ops.label_histogram(to_dev(ours), to_dev(news), to_dev(new_ids), n_our)
+    assert torch.equal(got.cpu(), want)
+    assert int(want.sum()) == h * w
+    our_order = torch.randint(-1, 6, (n_our + 1,), generator=g).int()
+    our_label = torch.randint(1, 400, (n_our + 1,), generator=g)
+    new_order = torch.randint(-1, 6, (n_new,), generator=g).int()
+    new_label = torch.randint(1, 400, (n_new,), generator=g)
+    out_ids = torch.unique(torch.cat([our_label, new_label]))[:6]
+    want = emu_ops.merge_paint(ours, news, new_ids, our_order, our_label, new_order, new_label, out_ids)
+    got = ops.merge_paint(to_dev(ours), to_dev(news), to_dev(new_ids), to_dev(our_order), to_dev(our_label),
+                          to_dev(new_order), to_dev(new_label), to_dev(out_ids))
+    assert got.shape == want.shape and torch.equal(got.cpu(), want)

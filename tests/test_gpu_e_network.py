@@ -188,3 +188,23 @@ def test_480p_lockstep_teacher_forced(network, recipe_state_dict):
     P, _ = recipe_state_dict
     worst = lockstep.run(network, P, 480, 864, 2, 7, dev())
     print('lockstep 480p worst relative errors:', json.dumps({k: float(f'{v:.2e}') for k, v in worst.items()}))
+
+
+def test_detection_clip_against_reference_golden(network, golden_dir):
+    """incorporate_detection (match_and_merge on the histogram / paint kernels) + propagation, online
+    setting, against the reference's outputs and object-manager state"""
+    from deva.inference.inference_core import DEVAInferenceCore
+    from deva.inference.object_info import ObjectInfo
+    outs, core = scenarios.run_detection_scenario(lambda cfg: DEVAInferenceCore(network, cfg), ObjectInfo,
+                                                  scenarios.DETECTION, device=dev())
+    g = np.load(os.path.join(golden_dir, 'e2e_detections.npz'))
+    assert [p.shape[0] for p in outs] == g['nchan'].tolist()
+    om = core.object_manager
+    state = dict(ids=[int(o.id) for o in om.obj_to_tmp_id], tmp=[int(t) for t in om.obj_to_tmp_id.values()],
+                 poke=[int(o.poke_count) for o in om.obj_to_tmp_id],
+                 cats=[[None if c is None else int(c) for c in o.category_ids] for o in om.obj_to_tmp_id],
+                 isthing=[o.isthing for o in om.obj_to_tmp_id])
+    assert state == json.loads(str(g['state']))
+    errs = [float(np.abs(p[:, ::2, ::2].numpy() - g[f'prob_sub_{t}']).max()) for t, p in enumerate(outs)]
+    print('detections clip: max-abs prob err per frame', ['%.1e' % e for e in errs])
+    assert max(errs) <= 5e-3

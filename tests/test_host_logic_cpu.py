@@ -125,3 +125,43 @@ def test_no_cpu_fallback_in_product(recipe_state_dict):
     net = _network(recipe_state_dict)
     with pytest.raises(DevaHipError):
         net.encode_image(torch.zeros(1, 3, 32, 32))
+
+
+def _manager_state(om):
+    return dict(ids=[int(o.id) for o in om.obj_to_tmp_id], tmp=[int(t) for t in om.obj_to_tmp_id.values()],
+                poke=[int(o.poke_count) for o in om.obj_to_tmp_id],
+                cats=[[None if c is None else int(c) for c in o.category_ids] for o in om.obj_to_tmp_id],
+                isthing=[o.isthing for o in om.obj_to_tmp_id])
+
+
+def test_match_and_merge_matches_reference(emu, golden_dir):
+    """segment_merging.match_and_merge: same merged masks and the same object-manager side effects
+    as the reference (goldens generated by the reference itself)"""
+    from deva.inference.object_info import ObjectInfo
+    from deva.inference.object_manager import ObjectManager
+    from deva.inference.segment_merging import match_and_merge
+    gold = torch.load(os.path.join(golden_dir, 'merge_cases.pt'))
+    for seed in (0, 1):
+        for incremental in (False, True):
+            ours, our_info, news, new_info = scenarios.merge_case(seed)
+            om = ObjectManager()
+            om.add_new_objects([ObjectInfo(**i) for i in our_info])
+            merged = match_and_merge(ours, news, om, [ObjectInfo(**i) for i in new_info],
+                                     incremental_mode=incremental)
+            g = gold[f'seed{seed}_inc{int(incremental)}']
+            assert torch.equal(merged.to(torch.uint8), g['onehot'])
+            assert _manager_state(om) == g['state']
+
+
+def test_detection_clip_matches_reference(emu, golden_dir, recipe_state_dict):
+    """incorporate_detection + propagation (online setting) against the reference's outputs"""
+    from deva.inference.inference_core import DEVAInferenceCore
+    from deva.inference.object_info import ObjectInfo
+    net = _network(recipe_state_dict)
+    outs, core = scenarios.run_detection_scenario(lambda cfg: DEVAInferenceCore(net, cfg), ObjectInfo,
+                                                  scenarios.DETECTION)
+    g = np.load(os.path.join(golden_dir, 'e2e_detections.npz'))
+    assert [p.shape[0] for p in outs] == g['nchan'].tolist()
+    assert _manager_state(core.object_manager) == json.loads(str(g['state']))
+    worst = max(np.abs(p[:, ::2, ::2].numpy() - g[f'prob_sub_{t}']).max() for t, p in enumerate(outs))
+    assert worst <= 5e-3, worst

@@ -17,6 +17,7 @@ __all__ = ['PackedConv', 'pack_conv', 'conv2d', 'maxpool3x3s2', 'upsample2x_add'
            'aggregate', 'softmax_channels', 'upsample4x_softmax', 'cbam', 'gru_update',
            'affinity_topk', 'usage_update', 'readout_sparse', 'bank_append', 'bank_gather_rows',
            'bank_export', 'rank', 'rank_select', 'evict_select', 'similarity_dense', 'softmax_columns',
+           'label_histogram', 'merge_paint',
            'ACT_NONE', 'ACT_RELU', 'ACT_SIGMOID', 'ACT_SQUARE_PLUS_ONE']
 
 
@@ -381,3 +382,30 @@ def softmax_columns(x: torch.Tensor, p: int) -> torch.Tensor:
     n, ld = x.shape
     check(lib().deva_softmax_columns(_p(x), n, p, ld, _stream()), 'deva_softmax_columns')
     return x
+
+
+# ------------------------------------------------------------------------------------------ detection merging
+def label_histogram(ours: torch.Tensor, news: torch.Tensor, new_ids: torch.Tensor, n_our: int) -> torch.Tensor:
+    """joint histogram [n_our+1, n_new+1] (int32) of two int64 index masks; column n_new = unlisted ids"""
+    n_new = new_ids.numel()
+    counts = torch.zeros((n_our + 1, n_new + 1), dtype=torch.int32, device=ours.device)
+    check(lib().deva_label_histogram(_p(ours, torch.int64), _p(news, torch.int64),
+                                     _p(new_ids, torch.int64) if n_new else None, n_our, n_new, ours.numel(),
+                                     _p(counts, torch.int32), _stream()), 'deva_label_histogram')
+    return counts
+
+
+def merge_paint(ours: torch.Tensor, news: torch.Tensor, new_ids: torch.Tensor, our_order: torch.Tensor,
+                our_label: torch.Tensor, new_order: torch.Tensor, new_label: torch.Tensor,
+                out_ids: torch.Tensor) -> torch.Tensor:
+    """one-hot planes [n_out, *mask.shape] (fp32) of the area-ordered repaint"""
+    n_our, n_new, n_out = our_order.numel() - 1, new_ids.numel(), out_ids.numel()
+    out = _alloc((n_out, *ours.shape), ours.device)
+    if n_out:
+        check(lib().deva_merge_paint(_p(ours, torch.int64), _p(news, torch.int64),
+                                     _p(new_ids, torch.int64) if n_new else None, n_our, n_new,
+                                     _p(our_order, torch.int32), _p(our_label, torch.int64),
+                                     _p(new_order, torch.int32) if n_new else None,
+                                     _p(new_label, torch.int64) if n_new else None, _p(out_ids, torch.int64), n_out,
+                                     ours.numel(), _p(out), _stream()), 'deva_merge_paint')
+    return out
