@@ -236,6 +236,11 @@ int deva_softmax_columns(float* x, int n, int p, int ld, void* stream);
  *   (label == out_ids[o])   (ObjectManager.make_one_hot, object_manager.py:133-141). */
 int deva_label_histogram(const int64_t* ours, const int64_t* news, const int64_t* new_ids, int n_our,
                          int n_new, int64_t pixels, int32_t* counts, void* stream);
+/* index-mask relabelling out[i] = lut[in[i]] (0 outside 0..n-1): ObjectManager.tmp_to_obj_cls
+ * (object_manager.py:112-117, called in the timed region of evaluation/eval_vos.py:181) in one pass
+ * instead of one masked assignment per object */
+int deva_lut_remap(const int64_t* in, const int64_t* lut, int n, int64_t pixels, int64_t* out,
+                   void* stream);
 int deva_merge_paint(const int64_t* ours, const int64_t* news, const int64_t* new_ids, int n_our,
                      int n_new, const int32_t* our_order, const int64_t* our_label,
                      const int32_t* new_order, const int64_t* new_label, const int64_t* out_ids,

@@ -239,6 +239,11 @@ def merge_paint(ours, news, new_ids, our_order, our_label, new_order, new_label,
     return torch.stack(planes, 0) if planes else torch.zeros((0, *ours.shape))
 
 
+def lut_remap(mask, lut):
+    ok = (mask >= 0) & (mask < lut.numel())
+    return torch.where(ok, lut[mask.clamp(0, lut.numel() - 1)], torch.zeros_like(mask))
+
+
 def install(monkeypatch):
     """patch every public op of deva.hip.ops with its emulation"""
     for name in real.__all__ + ['require_hip']:

@@ -109,3 +109,15 @@ def test_label_histogram_and_merge_paint(h, w, n_our, n_new):
     got = ops.merge_paint(to_dev(ours), to_dev(news), to_dev(new_ids), to_dev(our_order), to_dev(our_label),
                           to_dev(new_order), to_dev(new_label), to_dev(out_ids))
     assert got.shape == want.shape and torch.equal(got.cpu(), want)
+
+
+def test_lut_remap_and_tmp_to_obj_cls():
+    from deva.inference.object_manager import ObjectManager
+    g = torch.Generator().manual_seed(5)
+    om = ObjectManager()
+    om.add_new_objects([7, 3, 250])
+    mask = torch.randint(0, 4, (37, 53), generator=g)
+    want = om.tmp_to_obj_cls(mask)               # host path
+    got = om.tmp_to_obj_cls(to_dev(mask))        # device path (deva_lut_remap)
+    assert torch.equal(got.cpu(), want)
+    assert set(want.unique().tolist()) <= {0, 7, 3, 250}

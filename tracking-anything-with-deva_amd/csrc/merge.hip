@@ -63,10 +63,30 @@ __global__ void merge_paint_kernel(const int64_t* __restrict__ ours, const int64
   }
 }
 
+// out[i] = lut[in[i]] for 0 <= in[i] < n, else 0  (ObjectManager.tmp_to_obj_cls, object_manager.py:112-117)
+__global__ void lut_remap_kernel(const int64_t* __restrict__ in, const int64_t* __restrict__ lut, int n,
+                                 int64_t pixels, int64_t* __restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < pixels; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = in[i];
+    out[i] = (v >= 0 && v < n) ? lut[v] : 0;
+  }
+}
+
 }  // namespace
 }  // namespace deva
 
 using namespace deva;
+
+extern "C" int deva_lut_remap(const int64_t* in, const int64_t* lut, int n, int64_t pixels, int64_t* out,
+                              void* stream) {
+  DEVA_REQUIRE(in && lut && out && n > 0 && pixels > 0, "deva_lut_remap: bad args");
+  int64_t blocks = ceil_div(pixels, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(lut_remap_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, lut, n, pixels,
+                     out);
+  return check_launch("deva_lut_remap");
+}
+
 
 extern "C" int deva_label_histogram(const int64_t* ours, const int64_t* news, const int64_t* new_ids, int n_our,
                                     int n_new, int64_t pixels, int32_t* counts, void* stream) {

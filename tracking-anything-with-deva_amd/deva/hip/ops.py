@@ -17,7 +17,7 @@ __all__ = ['PackedConv', 'pack_conv', 'conv2d', 'maxpool3x3s2', 'upsample2x_add'
            'aggregate', 'softmax_channels', 'upsample4x_softmax', 'cbam', 'gru_update',
            'affinity_topk', 'usage_update', 'readout_sparse', 'bank_append', 'bank_gather_rows',
            'bank_export', 'rank', 'rank_select', 'evict_select', 'similarity_dense', 'softmax_columns',
-           'label_histogram', 'merge_paint',
+           'label_histogram', 'merge_paint', 'lut_remap',
            'ACT_NONE', 'ACT_RELU', 'ACT_SIGMOID', 'ACT_SQUARE_PLUS_ONE']
 
 
@@ -408,4 +408,12 @@ def merge_paint(ours: torch.Tensor, news: torch.Tensor, new_ids: torch.Tensor, o
                                      _p(new_order, torch.int32) if n_new else None,
                                      _p(new_label, torch.int64) if n_new else None, _p(out_ids, torch.int64), n_out,
                                      ours.numel(), _p(out), _stream()), 'deva_merge_paint')
+    return out
+
+
+def lut_remap(mask: torch.Tensor, lut: torch.Tensor) -> torch.Tensor:
+    """int64 index mask -> lut[mask] (0 for values outside the table)"""
+    out = torch.empty_like(mask)
+    check(lib().deva_lut_remap(_p(mask, torch.int64), _p(lut, torch.int64), lut.numel(), mask.numel(),
+                               _p(out, torch.int64), _stream()), 'deva_lut_remap')
     return out

@@ -71,7 +71,15 @@ class ObjectManager:
 
     def tmp_to_obj_cls(self, mask) -> torch.Tensor:
         """tmp-id index mask -> object-id index mask"""
-        new_mask = torch.zeros_like(mask)
+        if mask.is_cuda and mask.dtype == torch.int64 and self.tmp_id_to_obj:
+            # one relabelling pass on the device instead of one masked assignment per object
+            from deva.hip import ops
+            table = [0] * (max(self.tmp_id_to_obj) + 1)
+            for tmp_id, obj in self.tmp_id_to_obj.items():
+                table[tmp_id] = int(obj.id)
+            lut = torch.tensor(table, dtype=torch.int64, device=mask.device)
+            return ops.lut_remap(mask.contiguous(), lut)
+        new_mask = torch.zeros_like(mask)  # host-side masks (e.g. in the result savers)
         for tmp_id, obj in self.tmp_id_to_obj.items():
             new_mask[mask == tmp_id] = obj.id
         return new_mask
