@@ -19,6 +19,12 @@ SHAPES = [  # name, cin, cout, k, batch, H, W
     ('up8_4 3x3 256->256 @272x480 x1', 256, 256, 3, 1, 272, 480),
     ('res 3x3 64->64 @272x480 x1', 64, 64, 3, 1, 272, 480),
     ('res 1x1 256->64 @272x480 x1', 256, 64, 1, 1, 272, 480),
+    ('fuser 3x3 1024->512 @30x54 x5', 1024, 512, 3, 5, 30, 54),
+    ('up16_8 3x3 512->256 @60x108 x5', 512, 256, 3, 5, 60, 108),
+    ('up16_8 3x3 256->256 @60x108 x5', 256, 256, 3, 5, 60, 108),
+    ('res 3x3 128->128 @136x240 x1', 128, 128, 3, 1, 136, 240),
+    ('res 3x3 256->256 @68x120 x1', 256, 256, 3, 1, 68, 120),
+    ('fuser 3x3 512->512 @68x120 x1', 512, 512, 3, 1, 68, 120),
     ('key 3x3 512->64 @30x54 x1', 512, 64, 3, 1, 30, 54),
     ('shrink 3x3 512->1 @30x54 x1', 512, 1, 3, 1, 30, 54),
     ('pred 3x3 256->1 @120x216 x5', 256, 1, 3, 5, 120, 216),

@@ -611,10 +611,10 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
     c.out = a.out;
     return launch_conv_cout1(c, st);
   }
-  // Tile choice: the largest tile that still yields >= ~2 workgroups per CU (256 CUs).  The small
-  // tiles run 32-deep K steps so the per-step address set-up and the barrier are amortised.
+  // Tile choice (all tiles run 32-deep K steps):
   const int64_t blocks128 = ceil_div(a.cout, 128) * ceil_div(a.n_total, 128);
   if (a.cout <= 32) return launch_tile<32, 128, 32, 1, 4>(a, st);
-  if (a.cout >= 128 && blocks128 >= 512) return launch_tile<128, 128, 32, 2, 4>(a, st);
+  // measured: the 8-wave 128x128 tile beats the 64x64 tile from ~64 tiles up (split-K tops the grid up)
+  if (a.cout >= 128 && blocks128 >= 64) return launch_tile<128, 128, 32, 2, 4>(a, st);
   return launch_tile<64, 64, 32, 2, 2>(a, st);
 }
