@@ -364,10 +364,10 @@ __global__ void usage_update_kernel(unsigned long long* __restrict__ usage_fix, 
 }
 
 // ------------------------------------------------------------------ sparse readout
-// block = 256 threads = 4 waves; tile = 32 queries x 256 channels.  A wave gathers the k value rows
-// of 8 queries (each lane a float4 of the 1-KiB row slab), accumulates in registers, and the tile
-// is transposed through LDS so the [cv][hw] output is written 128 B at a time.
-constexpr int RQ = 32;    // queries per block
+// block = 256 threads = 4 waves; tile = 8 queries x 256 channels.  A wave gathers the k value rows
+// of 2 queries (each lane a float4 of the 1-KiB row slab), accumulates in registers, and the tile
+// is transposed through LDS so each [cv][hw] output row is written as one 32-B segment.
+constexpr int RQ = 8;     // queries per block (small tiles: a 480p frame still yields ~400 workgroups)
 constexpr int RC = 256;   // channels per block
 
 __global__ __launch_bounds__(256) void readout_sparse_kernel(const int32_t* __restrict__ idx,
@@ -404,10 +404,10 @@ __global__ __launch_bounds__(256) void readout_sparse_kernel(const int32_t* __re
     tile[cl + 3][ql] = acc.w;
   }
   __syncthreads();
-  const int tq = threadIdx.x & 31;
-  const int tc = threadIdx.x >> 5;  // 0..7
+  const int tq = threadIdx.x % RQ;
+  const int tc = threadIdx.x / RQ;  // 0 .. 256/RQ - 1
   if (q0 + tq < hw) {
-    for (int c = tc; c < RC; c += 8) {
+    for (int c = tc; c < RC; c += 256 / RQ) {
       if (c0 + c < cv) out[(int64_t)(c0 + c) * hw + q0 + tq] = tile[c][tq];
     }
   }
