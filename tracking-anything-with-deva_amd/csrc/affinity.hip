@@ -34,7 +34,7 @@ constexpr int CK = 64;
 constexpr int QT = 32;            // queries per wave
 constexpr int CAP = 128;          // candidate slots per query (k <= 32 leaves >= 64 slots of slack)
 constexpr int STRIDE = CAP + 1;   // padded row (uint64 entries) to spread LDS banks
-constexpr int MAX_SPLITS = 16;    // splits * k <= 512 = 64 lanes x 8 keys in the merge kernel
+constexpr int MAX_SPLITS = 16;    // splits * CAP <= 2048 = 64 lanes x 32 keys in the merge kernel
 constexpr int WAVES = 4;
 constexpr int TOKT = 32;          // tokens per tile
 
@@ -265,27 +265,21 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
     DEVA_COMPILER_FENCE();
   }
 
-  // ---- final prune of every over-full list; the (unsorted) best <= k of this range go to global memory
-  for (int qq = 0; qq < QT; ++qq) {
-    const uint32_t c = cnt[qq];
-    if (c > (uint32_t)p.k) {
-      prune_list(cand + qq * STRIDE, c, p.k, lane);
-      if (lane == 0) cnt[qq] = (uint32_t)p.k;
-      DEVA_COMPILER_FENCE();
-    }
-  }
+  // ---- the candidate lists of this range go to global memory as they are (<= CAP keys per query, zero
+  // padded): the exact top-k selection over all ranges happens in the merge kernel, where one wave
+  // per query gives thousands of independent waves -- here it would run serially, 32 lists per wave
   const int nq = min(QT, p.hw - q0);
-  uint64_t* dst = p.part + ((int64_t)split * p.hw + q0) * p.k;
-  for (int e = lane; e < nq * p.k; e += 64) {
-    const int ql = e / p.k;
-    const int r = e - ql * p.k;
+  uint64_t* dst = p.part + ((int64_t)split * p.hw + q0) * CAP;
+  for (int e = lane; e < nq * CAP; e += 64) {
+    const int ql = e / CAP;
+    const int r = e - ql * CAP;
     dst[e] = ((uint32_t)r < cnt[ql]) ? cand[ql * STRIDE + r] : 0ull;
   }
 }
 
-// one wave per query: exact top-k of the splits*k candidates (8 keys per lane), sorted by rank
-// counting, then exp / normalise / usage
-constexpr int ME = 8;
+// one wave per query: exact top-k of the splits*CAP candidate slots (ME keys per lane), sorted by
+// rank counting, then exp / normalise / usage
+template <int ME>
 __global__ __launch_bounds__(256) void affinity_finalize_kernel(const uint64_t* __restrict__ part, int hw, int k,
                                                                 int splits, int32_t* __restrict__ idx,
                                                                 float* __restrict__ weight,
@@ -298,7 +292,7 @@ __global__ __launch_bounds__(256) void affinity_finalize_kernel(const uint64_t* 
   volatile uint64_t* unsorted = &s_buf[wave][0][0];
   volatile uint64_t* sorted = &s_buf[wave][1][0];
 
-  const int total = splits * k;
+  const int total = splits * CAP;
   const int n_live = (total + 63) >> 6;
   uint64_t e[ME];
 #pragma unroll
@@ -306,8 +300,8 @@ __global__ __launch_bounds__(256) void affinity_finalize_kernel(const uint64_t* 
     const int c = lane + 64 * i;
     uint64_t v = 0ull;
     if (c < total) {
-      const int sp = c / k;
-      v = part[((int64_t)sp * hw + q) * k + (c - sp * k)];
+      const int sp = c / CAP;
+      v = part[((int64_t)sp * hw + q) * CAP + (c - sp * CAP)];
     }
     e[i] = v;
   }
@@ -418,7 +412,10 @@ __global__ __launch_bounds__(256) void readout_sparse_kernel(const int32_t* __re
 
 using namespace deva;
 
-extern "C" int64_t deva_affinity_workspace(int hw, int k, int splits) { return (int64_t)splits * hw * k; }
+extern "C" int64_t deva_affinity_workspace(int hw, int k, int splits) {
+  (void)k;
+  return (int64_t)splits * hw * CAP;  // one zero-padded candidate list per (range, query)
+}
 
 extern "C" int deva_affinity_default_splits(int n_total, int hw) {
   // one 4-wave workgroup per CU is resident (132 KB of candidate lists): aim at ~256 workgroups
@@ -469,8 +466,13 @@ extern "C" int deva_affinity_finalize(const uint64_t* part_keys, int hw, int k, 
   DEVA_REQUIRE(part_keys && idx && weight && hw > 0, "deva_affinity_finalize: bad args");
   DEVA_REQUIRE(k >= 1 && k <= 32 && splits >= 1 && splits <= MAX_SPLITS,
                "deva_affinity_finalize: k/splits out of range");
-  hipLaunchKernelGGL(affinity_finalize_kernel, dim3((unsigned)ceil_div(hw, 4)), dim3(256), 0, (hipStream_t)stream,
-                     part_keys, hw, k, splits, idx, weight, (unsigned long long*)usage_fix);
+  if (splits * CAP <= 64 * 8) {
+    hipLaunchKernelGGL(affinity_finalize_kernel<8>, dim3((unsigned)ceil_div(hw, 4)), dim3(256), 0,
+                       (hipStream_t)stream, part_keys, hw, k, splits, idx, weight, (unsigned long long*)usage_fix);
+  } else {
+    hipLaunchKernelGGL(affinity_finalize_kernel<32>, dim3((unsigned)ceil_div(hw, 4)), dim3(256), 0,
+                       (hipStream_t)stream, part_keys, hw, k, splits, idx, weight, (unsigned long long*)usage_fix);
+  }
   return check_launch("deva_affinity_finalize");
 }
 
