@@ -32,8 +32,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int CK = 64;
 constexpr int QT = 32;            // queries per wave
-constexpr int CAP = 128;          // candidate slots per query (k <= 32 leaves >= 64 slots of slack)
-constexpr int STRIDE = CAP + 1;   // padded row (uint64 entries) to spread LDS banks
+constexpr int CAP = 128;          // candidate slots per (range, query) handed to the merge kernel
+// in-kernel candidate lists: 176 slots of 6 bytes (order-preserving score bits + 16-bit token offset
+// inside the range).  A range of up to ~1 000 tokens then never has to prune (k*(1+ln(n/k)) appends
+// expected), and the merge kernel does the only exact selection.
+constexpr int LCAP = 176;
+constexpr int LSTRIDE = LCAP + 1;  // odd row stride: spreads the LDS banks
 constexpr int MAX_SPLITS = 16;    // splits * CAP <= 2048 = 64 lanes x 32 keys in the merge kernel
 constexpr int WAVES = 4;
 constexpr int TOKT = 32;          // tokens per tile
@@ -100,18 +104,30 @@ __device__ __forceinline__ uint64_t kth_largest(const uint64_t (&e)[E], int n_li
   return ((uint64_t)T << 32) | L;
 }
 
-// prune one candidate list (wave-cooperative, c <= 128 entries, c >= k) to its exact best k
-// (unsorted); returns the k-th best key
-__device__ __forceinline__ uint64_t prune_list(volatile uint64_t* row, uint32_t c, int k, int lane) {
-  uint64_t e[2];
-  e[0] = ((uint32_t)lane < c) ? row[lane] : 0ull;
-  e[1] = ((uint32_t)lane + 64u < c) ? row[lane + 64] : 0ull;
-  const uint64_t thr = kth_largest<2>(e, 2, k);
-  const bool s0 = e[0] >= thr && e[0] != 0ull, s1 = e[1] >= thr && e[1] != 0ull;
-  const unsigned long long b0 = __ballot(s0), b1 = __ballot(s1);
+// prune one candidate list (wave-cooperative, c <= 192 entries, c >= k) to its exact best k
+// (unsorted); returns the k-th best key (score bits << 32 | 0xffff - token offset)
+__device__ __forceinline__ uint64_t prune_list(volatile uint32_t* sc, volatile uint16_t* tk, uint32_t c, int k,
+                                               int lane) {
+  uint64_t e[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const uint32_t j = (uint32_t)lane + 64u * i;
+    e[i] = (j < c) ? (((uint64_t)sc[j] << 32) | (uint64_t)(0xffffu - tk[j])) : 0ull;
+  }
+  const uint64_t thr = kth_largest<3>(e, 3, k);
   DEVA_COMPILER_FENCE();
-  if (s0) row[prefix_below(b0)] = e[0];
-  if (s1) row[__popcll(b0) + prefix_below(b1)] = e[1];
+  int base = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const bool keep = e[i] >= thr && e[i] != 0ull;
+    const unsigned long long b = __ballot(keep);
+    if (keep) {
+      const int w = base + prefix_below(b);
+      sc[w] = (uint32_t)(e[i] >> 32);
+      tk[w] = (uint16_t)(0xffffu - (uint32_t)(e[i] & 0xffffu));
+    }
+    base += __popcll(b);
+  }
   DEVA_COMPILER_FENCE();
   return thr;
 }
@@ -134,7 +150,8 @@ struct AffArgs {
 };
 
 __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs p) {
-  __shared__ uint64_t s_cand[WAVES][QT][STRIDE];
+  __shared__ uint32_t s_sc[WAVES][QT][LSTRIDE];  // candidate scores (order-preserving bits)
+  __shared__ uint16_t s_tk[WAVES][QT][LSTRIDE];  // candidate tokens (offset inside this range)
   __shared__ uint32_t s_cnt[WAVES][QT];
   __shared__ float s_tau[WAVES][QT];
 
@@ -146,7 +163,8 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
   if (q0 >= p.hw) return;  // whole wave idle (no block-level barrier is used in this kernel)
   const int split = blockIdx.y;
 
-  volatile uint64_t* cand = &s_cand[wave][0][0];
+  volatile uint32_t* csc = &s_sc[wave][0][0];
+  volatile uint16_t* ctk = &s_tk[wave][0][0];
   volatile uint32_t* cnt = &s_cnt[wave][0];
   volatile float* tau = &s_tau[wave][0];
 
@@ -176,6 +194,7 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
 
   const int t_begin = split * p.tiles_per_split;
   const int t_end = min(p.total_tiles, t_begin + p.tiles_per_split);
+  const int n_range0 = t_begin * TOKT;  // candidate tokens are stored as 16-bit offsets from here
 
   // key rows are software-prefetched one tile ahead: lane (l31, half) reads the whole 256-B row of
   // token n_base + l31 into xbuf while the matrix pipe works on the previous tile
@@ -197,11 +216,11 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
     // ---- prune lists that could overflow during this tile (at most 32 appends per query per tile)
     {
       const uint32_t c_mine = cnt[l31];
-      uint64_t need = __ballot(c_mine > (uint32_t)(CAP - TOKT)) & 0xffffffffull;
+      uint64_t need = __ballot(c_mine > (uint32_t)(LCAP - TOKT)) & 0xffffffffull;
       while (need) {
         const int qq = __ffsll((unsigned long long)need) - 1;
         need &= need - 1;
-        const uint64_t thr = prune_list(cand + qq * STRIDE, cnt[qq], p.k, lane);
+        const uint64_t thr = prune_list(csc + qq * LSTRIDE, ctk + qq * LSTRIDE, cnt[qq], p.k, lane);
         if (lane == 0) {
           cnt[qq] = (uint32_t)p.k;
           tau[qq] = from_orderable((uint32_t)(thr >> 32));
@@ -253,27 +272,47 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
     if (np) {
       uint32_t pos = __hip_atomic_fetch_add((uint32_t*)&s_cnt[wave][l31], (uint32_t)np, __ATOMIC_RELAXED,
                                             __HIP_MEMORY_SCOPE_WORKGROUP);
-      volatile uint64_t* row = cand + l31 * STRIDE;
+      volatile uint32_t* srow = csc + l31 * LSTRIDE;
+      volatile uint16_t* trow = ctk + l31 * LSTRIDE;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         if (pass & (1u << r)) {
           const int j = (r & 3) + 8 * (r >> 2) + 4 * half;
-          row[pos++] = make_key(sc[r], (uint32_t)(n_base + j));
+          srow[pos] = orderable(sc[r]);
+          trow[pos] = (uint16_t)(n_base - n_range0 + j);
+          ++pos;
         }
       }
     }
     DEVA_COMPILER_FENCE();
   }
 
-  // ---- the candidate lists of this range go to global memory as they are (<= CAP keys per query, zero
-  // padded): the exact top-k selection over all ranges happens in the merge kernel, where one wave
-  // per query gives thousands of independent waves -- here it would run serially, 32 lists per wave
+  // ---- the candidate lists of this range go to global memory as they are (zero padded to CAP keys per
+  // query): the exact top-k selection over all ranges happens in the merge kernel, where one wave per
+  // query gives thousands of independent waves -- here it would run serially, 32 lists per wave.
+  // Only a list that outgrew the CAP hand-over slots is pruned first.
+  {
+    const uint32_t c_mine = cnt[l31];
+    uint64_t need = __ballot(c_mine > (uint32_t)CAP) & 0xffffffffull;
+    while (need) {
+      const int qq = __ffsll((unsigned long long)need) - 1;
+      need &= need - 1;
+      prune_list(csc + qq * LSTRIDE, ctk + qq * LSTRIDE, cnt[qq], p.k, lane);
+      if (lane == 0) cnt[qq] = (uint32_t)p.k;
+      DEVA_COMPILER_FENCE();
+    }
+  }
   const int nq = min(QT, p.hw - q0);
   uint64_t* dst = p.part + ((int64_t)split * p.hw + q0) * CAP;
   for (int e = lane; e < nq * CAP; e += 64) {
     const int ql = e / CAP;
     const int r = e - ql * CAP;
-    dst[e] = ((uint32_t)r < cnt[ql]) ? cand[ql * STRIDE + r] : 0ull;
+    uint64_t key = 0ull;
+    if ((uint32_t)r < cnt[ql]) {
+      const uint32_t token = (uint32_t)n_range0 + (uint32_t)ctk[ql * LSTRIDE + r];
+      key = ((uint64_t)csc[ql * LSTRIDE + r] << 32) | (uint64_t)(~token);
+    }
+    dst[e] = key;
   }
 }
 
@@ -418,13 +457,14 @@ extern "C" int64_t deva_affinity_workspace(int hw, int k, int splits) {
 }
 
 extern "C" int deva_affinity_default_splits(int n_total, int hw) {
-  // one 4-wave workgroup per CU is resident (132 KB of candidate lists): aim at ~256 workgroups
+  // one 4-wave workgroup per CU is resident (133 KB of candidate lists): aim at ~256 workgroups
   const int qblocks = (int)ceil_div(hw, WAVES * QT);
   const int tiles = (int)ceil_div(n_total, TOKT);
   int s = (int)ceil_div(256, qblocks);
   if (s > tiles / 4) s = tiles / 4;  // keep >= 4 tiles (128 tokens) per range
   if (s > MAX_SPLITS) s = MAX_SPLITS;
   if (s < 1) s = 1;
+  while (s < MAX_SPLITS && ceil_div(tiles, s) > 2047) ++s;  // 16-bit token offsets inside a range
   return s;
 }
 
@@ -455,6 +495,9 @@ extern "C" int deva_affinity_topk(const float* key_long, const float* shr_long, 
   a.splits = splits;
   a.total_tiles = (int)ceil_div(n_total, TOKT);
   a.tiles_per_split = (int)ceil_div(a.total_tiles, splits);
+  DEVA_REQUIRE(a.tiles_per_split <= 2047,
+               "deva_affinity_topk: %d tokens per range exceed the 16-bit in-range token offset; use more splits",
+               a.tiles_per_split * TOKT);
   a.part = part_keys;
   dim3 grid((unsigned)ceil_div(hw, WAVES * QT), (unsigned)splits);
   hipLaunchKernelGGL(affinity_topk_kernel, grid, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
