@@ -106,7 +106,7 @@ __device__ __forceinline__ uint64_t kth_largest(const uint64_t (&e)[E], int n_li
 
 // prune one candidate list (wave-cooperative, c <= 192 entries, c >= k) to its exact best k
 // (unsorted); returns the k-th best key (score bits << 32 | 0xffff - token offset)
-__device__ __forceinline__ uint64_t prune_list(volatile uint32_t* sc, volatile uint16_t* tk, uint32_t c, int k,
+__device__ __forceinline__ uint64_t prune_list(uint32_t* sc, uint16_t* tk, uint32_t c, int k,
                                                int lane) {
   uint64_t e[3];
 #pragma unroll
@@ -163,10 +163,14 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
   if (q0 >= p.hw) return;  // whole wave idle (no block-level barrier is used in this kernel)
   const int split = blockIdx.y;
 
-  volatile uint32_t* csc = &s_sc[wave][0][0];
-  volatile uint16_t* ctk = &s_tk[wave][0][0];
-  volatile uint32_t* cnt = &s_cnt[wave][0];
-  volatile float* tau = &s_tau[wave][0];
+  // NB plain (non-volatile) LDS accesses: hipcc puts `s_waitcnt vmcnt(0)` next to every volatile
+  // access, which would drain the key-row prefetch at each list operation.  Program order on may-alias
+  // LDS locations plus the in-order LDS pipeline give the cross-lane visibility needed inside a wave;
+  // DEVA_COMPILER_FENCE() marks the hand-over points.
+  uint32_t* csc = &s_sc[wave][0][0];
+  uint16_t* ctk = &s_tk[wave][0][0];
+  uint32_t* cnt = &s_cnt[wave][0];
+  float* tau = &s_tau[wave][0];
 
   if (lane < QT) {
     cnt[lane] = 0;
@@ -272,8 +276,8 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
     if (np) {
       uint32_t pos = __hip_atomic_fetch_add((uint32_t*)&s_cnt[wave][l31], (uint32_t)np, __ATOMIC_RELAXED,
                                             __HIP_MEMORY_SCOPE_WORKGROUP);
-      volatile uint32_t* srow = csc + l31 * LSTRIDE;
-      volatile uint16_t* trow = ctk + l31 * LSTRIDE;
+      uint32_t* srow = csc + l31 * LSTRIDE;
+      uint16_t* trow = ctk + l31 * LSTRIDE;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         if (pass & (1u << r)) {
