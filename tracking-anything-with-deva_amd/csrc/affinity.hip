@@ -12,13 +12,15 @@
 //
 // Work decomposition: one wave owns 32 queries (the MFMA N dimension) and streams a range of
 // memory tokens in tiles of 32 (the MFMA M dimension); the query operand lives in registers for
-// the whole kernel, the key rows are read straight from the token-major bank (a 32x64 fp32 tile
-// per 8192 matrix-pipe cycles -- operand traffic is irrelevant here, the kernel is bound by the
-// fp32 MFMA rate).  Per query the wave keeps a candidate list in LDS: scores >= the running k-th
-// best are appended (rare once the threshold has settled: ~k*ln(N/k) appends per query in total),
-// and when a list could overflow it is pruned back to the best k by rank counting.
-// grid.y splits the bank into token ranges so small frames still fill 256 CUs; a second kernel
-// merges the per-range lists, applies exp/normalise and accumulates the usage counters.
+// the whole kernel, the key rows are read straight from the token-major bank and prefetched one
+// tile ahead (a 32x64 fp32 tile per 4096 matrix-pipe cycles -- operand traffic is irrelevant here,
+// the kernel is bound by the fp32 MFMA rate).  Per query the wave keeps a candidate list in LDS
+// (176 slots of 6 bytes): scores >= the running k-th best are appended (~k*(1+ln(n/k)) appends per
+// query over n tokens), and a list that could overflow is pruned back to its exact best k by a
+// ballot-driven bitwise bisection.  grid.y splits the bank into token ranges so small frames
+// still fill 256 CUs; the ranges hand over their lists as they are and a second kernel (one wave
+// per query) selects the exact top-k over all ranges, applies exp/normalise and accumulates the
+// usage counters.
 #include <math.h>
 
 #include "common.h"
@@ -50,10 +52,8 @@ __device__ __forceinline__ float from_orderable(uint32_t o) {
   const uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
   return __uint_as_float(u);
 }
-// larger key = better candidate: higher score first, then lower token index
-__device__ __forceinline__ uint64_t make_key(float score, uint32_t token) {
-  return ((uint64_t)orderable(score) << 32) | (uint64_t)(~token);
-}
+// 64-bit candidate keys handed to the merge kernel: order-preserving score bits << 32 | ~token index,
+// so a larger key is a better candidate (higher score first, then lower token index).
 
 #define DEVA_COMPILER_FENCE() asm volatile("" ::: "memory")
 
