@@ -24,7 +24,13 @@ Extra objects on the JSON line:
                 (SURVEY.md §8d asks for all three).
   cpu_baseline  the CPU oracle (port of the reference's PyTorch path) on the same workload, on this
                 box's host cores, for a bounded sample of frames.
-  extra         1080p / 10k-token long-term bank propagation FPS (BASELINE target line).
+  extra         1080p / 10k-token long-term bank propagation FPS (BASELINE target line) and the
+                4K / 50k-token bank FPS of configs[4] on this GPU.
+
+`--workload long4k` runs BASELINE configs[4] instead: ONE 2160x3840 clip with a 50 000-token
+long-term bank on N GPUs -- every rank steps the same clip (replicated bank), the memory read is
+sharded by query column with an RCCL all-gather of the read-out columns and an all-reduce of the
+usage counters (MemoryManager.shard_queries) -> "scaling": "strong".
 """
 import argparse
 import json
@@ -60,11 +66,13 @@ def make_clip(height, width, n_frames, seed, device):
     return [stream.next().to(device) for _ in range(n_frames)]
 
 
-def start_clip(net, cfg, frames, num_objects, device, lt_prefill=0):
+def start_clip(net, cfg, frames, num_objects, device, lt_prefill=0, shard=False):
     """annotated first frame (+ optional pre-filled long-term bank)"""
     from oracle import synth
     from deva.inference.inference_core import DEVAInferenceCore
     core = DEVAInferenceCore(net, cfg)
+    if shard:
+        core.memory.shard_queries()
     h, w = frames[0].shape[-2:]
     mask = synth.box_mask(h, w, num_objects).to(device)
     core.step(frames[0], mask, list(range(1, num_objects + 1)))
@@ -213,6 +221,47 @@ def whole_job_fps(steps_per_rank: int, world: int, elapsed: float) -> float:
     return world * steps_per_rank / elapsed
 
 
+def run_long4k(net, device, steps, warmup, seed, shard, dist):
+    """BASELINE configs[4]: one 4K clip, 1 object, 50 000-token long-term bank.  With `shard` the
+    memory read is partitioned by query column over the process group (every rank steps the clip)."""
+    from oracle import synth
+    cfg = synth.base_config(max_long_term_elements=50000)
+    n_frames = 1 + warmup + steps
+    frames = make_clip(2160, 3840, n_frames, seed=seed, device=device)
+    core = start_clip(net, cfg, frames, 1, device, lt_prefill=50000 - cfg['num_prototypes'], shard=shard)
+    for t in range(1, 1 + warmup):
+        core.step(frames[t])
+
+    def timed_steps():
+        for t in range(1 + warmup, n_frames):
+            core.step(frames[t])
+
+    elapsed = timed_region(timed_steps, dist, device)
+    mem = core.memory
+    bank = {'long': {b: mem.long_mem.size(b) for b in mem.long_mem.buckets},
+            'work': {b: mem.work_mem.size(b) for b in mem.work_mem.buckets}}
+    return steps / elapsed, bank
+
+
+def long4k(args, net, rank, world, device, dist):
+    """`--workload long4k`: strong scaling of ONE clip over the GPUs of the node"""
+    fps, bank = run_long4k(net, device, args.steps, args.warmup, seed=11, shard=dist is not None, dist=dist)
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'propagation FPS @4K (1 object, 50k-token long-term bank)',
+            'value': fps, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 / fps, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[4]: one synthetic 3840x2160 clip, 1 object, long-term memory '
+                                   'pre-filled to 50 000 tokens; bank replicated, memory read sharded by query column',
+                       'bank_tokens_at_end': bank,
+                       'parallelism': f'query-sharded memory read x{world} (all-gather read-out, all-reduce usage)'},
+        }))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -221,6 +270,7 @@ def main():
     ap.add_argument('--height', type=int, default=480)
     ap.add_argument('--width', type=int, default=854)
     ap.add_argument('--objects', type=int, default=5)
+    ap.add_argument('--workload', choices=['clips', 'long4k'], default='clips')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_extra', action='store_true')
     args = ap.parse_args()
@@ -238,6 +288,8 @@ def main():
 
     from oracle import synth
     net, sd = build_network(device)
+    if args.workload == 'long4k':
+        return long4k(args, net, rank, world, device, dist if distributed else None)
     cfg = synth.base_config(enable_long_term=False, enable_long_term_count_usage=False)
     n_frames = 1 + args.warmup + args.steps
     frames = make_clip(args.height, args.width, n_frames, seed=100 + rank, device=device)  # HBM resident
@@ -311,6 +363,11 @@ def main():
                 'note': 'BASELINE target line: 1920x1080 (padded 1088x1920), 1 object, long-term memory '
                         'pre-filled with 10 000 tokens + working memory, 10 propagated frames',
             }
+            del core2, f1080
+            fps4k, bank4k = run_long4k(net, device, steps=6, warmup=2, seed=11, shard=False, dist=None)
+            result['extra']['fps_4k_1obj_50k_longterm_bank'] = fps4k
+            result['extra']['note_4k'] = ('BASELINE configs[4] on one GPU: 3840x2160, 1 object, long-term memory '
+                                          f'pre-filled with 50 000 tokens, bank at end {bank4k}; 6 propagated frames')
         if not args.no_cpu_baseline and world == 1:
             n_cpu = 4
             frames_cpu = [f.cpu() for f in frames[:1 + n_cpu]]

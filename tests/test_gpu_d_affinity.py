@@ -138,3 +138,25 @@ def test_readout_two_segments_ragged():
     out = torch.empty(cv, hw, device=dev())
     ops.readout_sparse(to_dev(idx), to_dev(w), to_dev(vl), n_long, to_dev(vw), out)
     assert max_err(out, want) <= 1e-4
+
+
+def test_query_column_slices_are_bit_identical():
+    """the multi-GPU read shards the queries by column (MemoryManager.shard_queries): every column's
+    result must not depend on which other columns share the launch, and the fixed-point usage
+    counters of the shards must add up to the unsharded counters exactly"""
+    n, hw, k = 4000, 1000, 30
+    mk, ms, qk, qe = synth.affinity_inputs(n, hw, seed=77, key_scale=2.0)
+    idx, w, _ = _run(mk, ms, qk, qe, k, n_long=1500)
+    rows, shr = mk.t().contiguous(), ms.reshape(-1).contiguous()
+    kl, sl, kw, sw = to_dev(rows[:1500]), to_dev(shr[:1500]), to_dev(rows[1500:].contiguous()), to_dev(shr[1500:].contiguous())
+    full_fix = torch.zeros(n, dtype=torch.int64, device=dev())
+    ops.affinity_topk(kl, sl, 1500, kw, sw, n - 1500, to_dev(qk), to_dev(qe), k, full_fix)
+    for world in (2, 3, 8):
+        per = -(-hw // world)
+        fix = torch.zeros(n, dtype=torch.int64, device=dev())
+        for r in range(world):
+            lo, hi = r * per, min(hw, (r + 1) * per)
+            i_s, w_s = ops.affinity_topk(kl, sl, 1500, kw, sw, n - 1500, to_dev(qk[:, lo:hi].contiguous()),
+                                         to_dev(qe[:, lo:hi].contiguous()), k, fix)
+            assert torch.equal(i_s.cpu(), idx[lo:hi]) and torch.equal(w_s.cpu(), w[lo:hi]), (world, r)
+        assert torch.equal(fix, full_fix), world

@@ -208,3 +208,31 @@ def test_detection_clip_against_reference_golden(network, golden_dir):
     errs = [float(np.abs(p[:, ::2, ::2].numpy() - g[f'prob_sub_{t}']).max()) for t, p in enumerate(outs)]
     print('detections clip: max-abs prob err per frame', ['%.1e' % e for e in errs])
     assert max(errs) <= 5e-3
+
+
+def test_sharded_read_single_rank_group_is_identical(network):
+    """MemoryManager.shard_queries over a 1-rank RCCL group: the collective code path of the
+    multi-GPU read (all-gather of read-out columns, all-reduce of usage) must reproduce the plain
+    read bit for bit (the 2- and 3-rank splits run on CPU/gloo in tests/test_sharded_read_gloo.py)"""
+    import socket
+    import torch.distributed as dist
+    from deva.inference.inference_core import DEVAInferenceCore
+    net = network
+    sc = dict(scenarios.E2E['two_buckets'])
+    sc['frames'] = 20
+    plain, core_a = scenarios.run_scenario(lambda cfg: DEVAInferenceCore(net, cfg), sc, device=dev())
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
+    try:
+        def make(cfg):
+            c = DEVAInferenceCore(net, cfg)
+            c.memory.shard_queries()
+            return c
+        sharded, core_b = scenarios.run_scenario(make, sc, device=dev())
+    finally:
+        dist.destroy_process_group()
+    assert all(torch.equal(a, b) for a, b in zip(plain, sharded))
+    for b in core_a.memory.work_mem.buckets:
+        assert torch.equal(core_a.memory.work_mem.get_usage(b), core_b.memory.work_mem.get_usage(b))

@@ -18,7 +18,10 @@ def main():
     L = lib()
     st = torch.cuda.current_stream().cuda_stream
     g = torch.Generator().manual_seed(0)
-    for n, hw in SHAPES:
+    shapes = SHAPES
+    if os.environ.get('SHAPES'):  # e.g. SHAPES=1620x1620,6480x1620
+        shapes = [tuple(int(v) for v in t.split('x')) for t in os.environ['SHAPES'].split(',')]
+    for n, hw in shapes:
         if only and only != f'{n}x{hw}':
             continue
         key = torch.randn(n, 64, generator=g).to(dev)
@@ -30,10 +33,11 @@ def main():
         idx = torch.empty((hw, k), dtype=torch.int32, device=dev)
         w = torch.empty((hw, k), dtype=torch.float32, device=dev)
 
-        def run():
+        def run(fin=True):
             L.deva_affinity_topk(None, None, 0, key.data_ptr(), shr.data_ptr(), n, qk.data_ptr(), qe.data_ptr(), hw,
                                  k, splits, part.data_ptr(), st)
-            L.deva_affinity_finalize(part.data_ptr(), hw, k, splits, idx.data_ptr(), w.data_ptr(), None, st)
+            if fin:
+                L.deva_affinity_finalize(part.data_ptr(), hw, k, splits, idx.data_ptr(), w.data_ptr(), None, st)
 
         run()
         torch.cuda.synchronize()
@@ -44,9 +48,15 @@ def main():
         e.record()
         torch.cuda.synchronize()
         ms = s.elapsed_time(e) / iters
+        s.record()
+        for _ in range(iters):
+            run(False)
+        e.record()
+        torch.cuda.synchronize()
+        ms_topk = s.elapsed_time(e) / iters
         fl = 4.0 * 64 * n * hw
-        print(f'affinity N={n:6d} HW={hw:5d} splits={splits:2d}: {ms * 1e3:9.1f} us  {fl / ms / 1e9:6.1f} TFLOP/s '
-              f'({fl / 1e9:.1f} GF)')
+        print(f'affinity N={n:6d} HW={hw:5d} splits={splits:2d}: {ms * 1e3:9.1f} us (filter {ms_topk * 1e3:7.1f} us)  '
+              f'{fl / ms / 1e9:6.1f} TFLOP/s ({fl / 1e9:.1f} GF)')
 
 
 if __name__ == '__main__':

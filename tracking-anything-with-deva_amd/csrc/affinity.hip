@@ -468,6 +468,10 @@ extern "C" int deva_affinity_default_splits(int n_total, int hw) {
   if (s > tiles / 4) s = tiles / 4;  // keep >= 4 tiles (128 tokens) per range
   if (s > MAX_SPLITS) s = MAX_SPLITS;
   if (s < 1) s = 1;
+  // small banks (first memory frames of a clip): ranges of <= CAP tokens hand every score over without
+  // building a threshold or pruning (a prune round of 32 lists costs ~50 us, measured)
+  const int s_nofilter = (int)ceil_div(tiles, CAP / TOKT);
+  if (s_nofilter <= MAX_SPLITS && s_nofilter > s) s = s_nofilter;
   while (s < MAX_SPLITS && ceil_div(tiles, s) > 2047) ++s;  // 16-bit token offsets inside a range
   return s;
 }

@@ -15,6 +15,8 @@
 // v_mfma_f32_32x32x2_f32:  A: lane l holds A[i = l&31][k = l>>5],  B: B[k = l>>5][j = l&31],
 // D: reg r of lane l is D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
 #include "common.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace deva {
 
@@ -64,10 +66,13 @@ struct ConvArgs {
   int64_t res_bs;
   int act;
   float* out;
+  int variant;       // experiment selector (DEVA_CONV_VARIANT)
+  int no_row;        // debugging / A-B measurements: DEVA_CONV_NO_ROW=1 disables the row-reuse kernel
   int vec_ok;        // inputs are guard-banded + 'same' stride-1 geometry: 4-pixel vector gathers allowed
   int tiles_n, tiles_m;
   int64_t ws_elems;
   int splits;        // split-K factor (gridDim.y); > 1 writes raw partial sums to ws
+  int per_split;     // K steps per split
   float* ws;         // [splits][cout][n_total]
 };
 
@@ -75,7 +80,10 @@ struct ConvArgs {
 // MODE 0: 1x1 kernel with c0 a multiple of BK (source uniform per K step, K tail allowed);
 // MODE 1: k x k kernel with c0 and c0+c1 multiples of BK (tap and source uniform per K step);
 // MODE 2: anything (per-element decode: the 2/3/4-channel stems, odd channel splits).
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MODE, int SPREAD, int VEC>
+// ROW (3x3, pad 1, 32-channel-slab weights, VEC): the input rows of a (slab, dy) pair are staged ONCE,
+// unmasked and with one halo pixel either side, and serve the three dx taps with a column offset on
+// the LDS fragment read; the zero padding is applied per consumer pixel at that read.
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MODE, int SPREAD, int VEC, int ROW, int PF = 1, int PRIO = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 4 : 1) void conv_igemm_kernel(
     const ConvArgs p) {
   constexpr int THREADS = 64 * WAVES_M * WAVES_N;
@@ -88,7 +96,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
   constexpr int B_PT = BK / KG;                                 // scalar gathers per thread
 
   __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+  constexpr int BNP = ROW ? BN + 8 : BN;  // ROW: columns 3 .. BN+4 hold pixels n0-1 .. n0+BN
+  static_assert(ROW == 0 || (VEC == 1 && MODE == 1 && TN == 1), "row reuse builds on the vector gather");
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][BNP];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -165,6 +175,34 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
   f32x4 rbv[VEC ? B_V4 : 1];
   unsigned v_mask = 0;
 
+  // ---- ROW: halo pixel (n0-1 or n0+BN) of K row h_row, loaded by every thread (kept branch-free),
+  // stored by wave 0; 9-bit validity mask (bit dy*3+dx) of the pixel this lane consumes
+  const int h_side = tid & 1, h_row = (tid >> 1) & (BK - 1);
+  const float* hsrc0 = nullptr;
+  const float* hsrc1 = nullptr;
+  int h_pix = 0;
+  unsigned cmask = 0;
+  float rh = 0.0f;
+  const float* st_hptr = nullptr;
+  if (ROW) {
+    int nh = h_side ? n0 + BN : n0 - 1;
+    nh = min(max(nh, 0), p.n_total - 1);
+    const int b = nh / p.OHW;
+    h_pix = nh - b * p.OHW;
+    hsrc0 = p.in0 + (int64_t)b * p.bs0;
+    hsrc1 = p.in1 ? p.in1 + (int64_t)b * p.bs1 : p.in0;
+    const int n = n0 + wn0 + l31;
+    if (n < p.n_total) {
+      const int pix = n % p.OHW;
+      const int oh = pix / p.OW, ow = pix - oh * p.OW;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const bool ok = ((unsigned)(oh + t / 3 - 1) < (unsigned)p.H) && ((unsigned)(ow + t % 3 - 1) < (unsigned)p.W);
+        cmask |= ok ? (1u << t) : 0u;
+      }
+    }
+  }
+
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -212,7 +250,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
         iw += tap - dy * p.KW;
       }
       const bool first = cbase < p.c0;
-      if (VEC) {
+      if (ROW) {
+        // B comes from the row tile staged by stage_begin_row
+      } else if (VEC) {
         const int dy = ih - ih0 - p.pad, dx = iw - iw0 - p.pad;  // tap offset relative to the centre
         v_mask = 0;
 #pragma unroll
@@ -229,6 +269,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
                  (st_okp ? (ih * p.W + iw) : 0);
       }
     }
+  };
+
+  // ROW: pointers of the (slab, dy) row tile that starts at K step kg (its dx == 0 step)
+  auto stage_begin_row = [&](int kg) {
+    const int slab = kg / BK;
+    const int chunk = slab / 9;
+    const int dy = (slab - chunk * 9) / 3;
+    const int cbase = chunk * BK;
+    const bool first = cbase < p.c0;
+    const int64_t coff = (int64_t)(first ? cbase : cbase - p.c0) * p.HW;
+    const int shift = (dy - 1) * p.W;
+    st_ptr = (first ? vsrc0 : vsrc1) + coff + (v_pix0 + shift);
+    st_hptr = (first ? hsrc0 : hsrc1) + coff + (int64_t)h_row * p.HW + (h_pix + shift);
+    ok_b = 0;
   };
 
   // A: rows k0..k0+BK-1 of the packed weights, columns m0..m0+BM-1.  Loads are unconditional from a
@@ -275,7 +329,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
     }
   };
 
-  auto store_tiles = [&](int buf) {
+  auto store_a = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < A_V4; ++i) {
       const int e = tid + i * THREADS;
@@ -285,6 +339,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
         *reinterpret_cast<float4*>(&As[buf][kr][mc]) =
             (ok_a & (1u << i)) ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
+    }
+  };
+  auto store_b = [&](int buf) {
+    if (ROW) {
+#pragma unroll
+      for (int i = 0; i < B_V4; ++i) {
+        f32x4 v = rbv[i];
+        if (p.relu_in) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+        }
+        *reinterpret_cast<f32x4*>(&Bs[buf][vk + i * KGV][4 + 4 * vq]) = v;
+      }
+      if (tid < 64) Bs[buf][h_row][h_side ? BN + 4 : 3] = p.relu_in ? fmaxf(rh, 0.0f) : rh;
+      return;
     }
     if (VEC) {
 #pragma unroll
@@ -308,19 +377,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
       Bs[buf][bk_group + i * KG][bn_local] = (ok_b & (1u << i)) ? v : 0.0f;
     }
   };
+  auto store_tiles = [&](int buf) {
+    store_a(buf);
+    store_b(buf);
+  };
 
   constexpr int NKK = BK / 2;  // MFMA groups (k pairs) per K step
   // split-K: this workgroup accumulates K steps [ks0, ks0 + ksteps) of the layer
   int ks0 = 0, ksteps = (p.K + BK - 1) / BK;
   if (p.splits > 1) {
-    const int per = (ksteps + p.splits - 1) / p.splits;
+    const int per = p.per_split;
     ks0 = (int)blockIdx.y * per;
     ksteps = max(0, min(ksteps - ks0, per));
   }
   stage_begin(ks0 * BK);
 #pragma unroll
   for (int i = 0; i < A_V4; ++i) stage_a(i);
-  if (VEC) {
+  if (ROW) {
+    stage_begin_row(ks0 * BK);
+#pragma unroll
+    for (int i = 0; i < B_V4; ++i) stage_bv(i);
+    rh = *st_hptr;
+  } else if (VEC) {
 #pragma unroll
     for (int i = 0; i < B_V4; ++i) stage_bv(i);
   } else {
@@ -330,6 +408,67 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
   store_tiles(0);
   __syncthreads();
 
+  if (ROW) {
+    // K steps come in (slab, dy) groups of three dx taps (splits start on group boundaries); the loop
+    // is unrolled over dx so that the row-tile loads of the NEXT group sit in straight-line code of the
+    // dx == 0 step (a load under a branch would be followed by s_waitcnt vmcnt(0))
+    auto row_step = [&](int s, auto dxc) {
+      constexpr int DX = decltype(dxc)::value;
+      const int buf = s & 1;
+      const int gbuf = (s / 3) & 1;
+      const int tap = (ks0 + s) % 9;
+      const bool okc = (cmask >> tap) & 1u;
+      const int k_next = (s + 1 < ksteps) ? (ks0 + s + 1) * BK : 0;
+      const int kg_next = (s + 3 < ksteps) ? (ks0 + s + 3) * BK : 0;
+      const int col = wn0 + l31 + 3 + DX;
+      // operand fragments run PF k pairs ahead of the MFMAs that consume them
+      constexpr int NF = PF + 1;
+      float fa[NF][TM], fb[NF];
+#pragma unroll
+      for (int f = 0; f < PF; ++f) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[f][i] = As[buf][2 * f + half][wm0 + i * 32 + l31];
+        fb[f] = Bs[gbuf][2 * f + half][col];
+      }
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        if (kk + PF < NKK) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) fa[(kk + PF) % NF][i] = As[buf][2 * (kk + PF) + half][wm0 + i * 32 + l31];
+          fb[(kk + PF) % NF] = Bs[gbuf][2 * (kk + PF) + half][col];
+        }
+        const float bval = okc ? fb[kk % NF] : 0.0f;
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk % NF][i], bval, acc[i][0], 0, 0, 0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk == 0) {
+          stage_begin(k_next);
+          if (DX == 0) stage_begin_row(kg_next);
+        }
+#pragma unroll
+        for (int i = 0; i < A_V4; ++i)
+          if (i * (NKK / SPREAD) / A_V4 == kk) stage_a(i);
+        if (DX == 0) {
+#pragma unroll
+          for (int i = 0; i < B_V4; ++i)
+            if (i * (NKK / SPREAD) / B_V4 == kk) stage_bv(i);
+          if (kk == 1) rh = *st_hptr;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      store_a(buf ^ 1);
+      if (DX == 0) store_b(gbuf ^ 1);
+      __syncthreads();
+    };
+    for (int s = 0; s < ksteps; s += 3) {
+      row_step(s, std::integral_constant<int, 0>{});
+      row_step(s + 1, std::integral_constant<int, 1>{});
+      row_step(s + 2, std::integral_constant<int, 2>{});
+    }
+  } else {
   for (int s = 0; s < ksteps; ++s) {
     const int buf = s & 1;
     // the last step re-stages step 0 (valid addresses, result unused) instead of branching
@@ -371,6 +510,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
     }
     store_tiles(buf ^ 1);
     __syncthreads();
+  }
   }
 
   if (p.splits > 1) {
@@ -475,6 +615,9 @@ int launch_tile(const ConvArgs& a, hipStream_t st) {
   // split-K when the layer has too few tiles to fill the 256 CUs (small frames / single objects):
   // partial sums go to the caller's workspace, a second kernel reduces them deterministically
   const int ksteps_total = (int)ceil_div(a.K, BK);
+  const bool row = a.vec_ok && mode == 1 && a.KH == 3 && a.KW == 3 && a.pad == 1 &&
+                   a.k_layout == DEVA_KLAYOUT_CHUNK32 && BN / WAVES_N == 32 && !a.no_row;
+  p.per_split = ksteps_total;
   const int64_t blocks = (int64_t)p.tiles_m * p.tiles_n;
   p.splits = 1;
   if (a.ws && blocks < 256 && ksteps_total >= 8) {
@@ -484,31 +627,46 @@ int launch_tile(const ConvArgs& a, hipStream_t st) {
     const int64_t fit = a.ws_elems / ((int64_t)a.cout * a.n_total);
     if (sp > fit) sp = fit;
     if (sp >= 2) {
-      // every split must own at least one K step
-      const int per = (int)ceil_div(ksteps_total, sp);
+      // every split must own at least one K step (ROW: whole groups of three)
+      int per = (int)ceil_div(ksteps_total, sp);
+      if (row) per = (per + 2) / 3 * 3;
       sp = ceil_div(ksteps_total, per);
       p.splits = (int)sp;
+      p.per_split = per;
     }
+    if (p.splits < 2) p.splits = 1;
   }
   dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splits);
   const bool vec = a.vec_ok && mode != 2;
   if (mode == 0) {
     if (vec) {
-      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 0, SPREAD, 1>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
+      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 0, SPREAD, 1, 0>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
     } else {
-      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 0, SPREAD, 0>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
+      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 0, SPREAD, 0, 0>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
     }
   } else if (mode == 1) {
-    if (vec) {
-      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 1, SPREAD, 1>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
+    if (row) {
+      if constexpr (BN / WAVES_N == 32) {
+        if (a.variant == 1) {
+          hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 1, SPREAD, 1, 1, 2, 0>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
+        } else if (a.variant == 2) {
+          hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 1, SPREAD, 1, 1, 1, 1>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
+        } else if (a.variant == 3) {
+          hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 1, SPREAD, 1, 1, 2, 1>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
+        } else if (a.variant == 4) {
+          hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 1, 1, 1, 1, 1, 0>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
+        } else {
+          hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 1, SPREAD, 1, 1>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
+        }
+      }
+    } else if (vec) {
+      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 1, SPREAD, 1, 0>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
     } else {
-      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 1, SPREAD, 0>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
+      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 1, SPREAD, 0, 0>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
     }
   } else {
-    if (vec) {
-      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 1, SPREAD, 1>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
-    } else {
-      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 2, SPREAD, 0>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
+    {
+      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 2, SPREAD, 0, 0>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
     }
   }
   if (p.splits > 1) {
@@ -574,6 +732,17 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
               (int64_t)d->in_guard_elems >= (int64_t)d->pad * (a.W + 1) + 4)
                  ? 1
                  : 0;
+  static const int no_row = [] {
+    const char* e = getenv("DEVA_CONV_NO_ROW");
+    return (e && e[0] == '1') ? 1 : 0;
+  }();
+  a.no_row = no_row;
+  static const int variant = [] {
+    const char* e = getenv("DEVA_CONV_VARIANT");
+    return e ? atoi(e) : 0;
+  }();
+  a.variant = variant;
+  a.per_split = 0;
   a.splits = 1;
   a.ws = d->workspace;
   a.ws_elems = d->workspace ? d->workspace_elems : 0;

@@ -10,6 +10,12 @@ gfx950 kernels of libdeva_hip:
 * `add_memory` / `compress_features` / `consolidation`: appends are transpose-copies into the
   arenas; consolidation runs the dense potentiation step on device and performs the prototype
   value/shrinkage readouts as fp32-MFMA GEMMs.
+* `shard_queries(group)`: one clip on several GPUs (SURVEY.md §8e "replicate bank, shard queries").
+  Every rank steps the same clip and therefore holds an identical bank (all kernels are
+  deterministic, so the replicas never diverge); the memory read -- the only part of a frame that
+  splits -- is partitioned by query column: rank r matches and reads out columns [r*per, (r+1)*per),
+  the read-out columns are all-gathered and the fixed-point usage counters all-reduced (integer
+  sums: exact in any order).  Results are bit-identical to the unsharded read.
 """
 from typing import Dict, List, Optional, Tuple
 
@@ -51,6 +57,7 @@ class MemoryManager:
             self.long_mem = KeyValueMemoryStore(save_usage=self.count_long_term_usage)
 
         self._usage_fix: Optional[torch.Tensor] = None  # int64 fixed-point usage scratch, kept zeroed
+        self._shard_group = None  # torch.distributed group the memory read is sharded over
 
         self.config_stale = True
         self.engaged = False
@@ -77,35 +84,81 @@ class MemoryManager:
             self._usage_fix = torch.zeros(max(2 * n, 1 << 16), dtype=torch.int64, device=device)
         return self._usage_fix
 
+    def shard_queries(self, group=None) -> None:
+        """Partition every following `match_memory` by query column over `group` (default: the world
+        group).  All ranks of the group must step the same clip."""
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError('shard_queries: torch.distributed is not initialised')
+        self._shard_group = group if group is not None else dist.group.WORLD
+
+    def _shard_range(self, hw: int) -> Tuple[int, int, int, int]:
+        """-> (rank, world, columns per rank, first column of this rank)"""
+        import torch.distributed as dist
+        world = dist.get_world_size(self._shard_group)
+        rank = dist.get_rank(self._shard_group)
+        per = -(-hw // world)
+        return rank, world, per, rank * per
+
     def match_memory(self, query_key: torch.Tensor, selection: torch.Tensor) -> Dict[int, torch.Tensor]:
         """query_key, selection: 1 x C^k x H x W  ->  {object id: C^v x H x W readout}
         (memory_manager.py:91-169)"""
         assert query_key.shape[0] == 1
         h, w = query_key.shape[-2:]
-        qk = query_key[0].reshape(query_key.shape[1], h * w)
-        qe = selection[0].reshape(selection.shape[1], h * w)
+        hw = h * w
+        qk = query_key[0].reshape(query_key.shape[1], hw)
+        qe = selection[0].reshape(selection.shape[1], hw)
+        sharded = self._shard_group is not None
+        if sharded:
+            import torch.distributed as dist
+            rank, world, per, lo = self._shard_range(hw)
+            n_mine = max(0, min(hw, lo + per) - lo)
+            # this rank's query columns (an empty tail rank still matches one column: the kernels
+            # need hw >= 1; its result is discarded and its usage contribution masked below)
+            cols = slice(lo, lo + n_mine) if n_mine else slice(0, 1)
+            qk, qe = qk[:, cols].contiguous(), qe[:, cols].contiguous()
         readouts: Dict[int, torch.Tensor] = {}
         for bucket_id, bucket in self.work_mem.buckets.items():
             with_long = self.use_long_term and self.long_mem.engaged(bucket_id)
             n_long = self.long_mem.size(bucket_id) if with_long else 0
             n_work = self.work_mem.size(bucket_id)
+            count_usage = self.use_long_term and not (sharded and n_mine == 0)
             usage_fix = self._usage_scratch(n_long + n_work, qk.device) if self.use_long_term else None
             idx, weight = ops.affinity_topk(
                 self.long_mem.key_arena(bucket_id) if with_long else None,
                 self.long_mem.shrinkage_arena(bucket_id) if with_long else None, n_long,
                 self.work_mem.key_arena(bucket_id), self.work_mem.shrinkage_arena(bucket_id), n_work,
-                qk, qe, self.top_k, usage_fix)
+                qk, qe, self.top_k, usage_fix if count_usage else None)
             if self.use_long_term:
+                if sharded:
+                    dist.all_reduce(usage_fix[:n_long + n_work], op=dist.ReduceOp.SUM, group=self._shard_group)
                 # usage bookkeeping (memory_manager.py:128-152)
                 self.work_mem.apply_usage_fix(bucket_id, usage_fix, n_long)
                 if with_long:
                     self.long_mem.apply_usage_fix(bucket_id, usage_fix, 0)
-            for obj in bucket:
+            if not sharded:
+                for obj in bucket:
+                    obj_long = with_long and obj in self.long_mem
+                    out = torch.empty((self.CV, h, w), dtype=torch.float32, device=qk.device)
+                    ops.readout_sparse(idx, weight, self.long_mem.value_arena(obj) if obj_long else None,
+                                       n_long if obj_long else 0, self.work_mem.value_arena(obj), out)
+                    readouts[obj] = out
+                continue
+            # sharded: [objects, CV, per] column slabs of this rank -> all-gather -> [objects, CV, hw]
+            nq = qk.shape[1]
+            mine = torch.zeros((len(bucket), self.CV, per), dtype=torch.float32, device=qk.device)
+            for i, obj in enumerate(bucket):
                 obj_long = with_long and obj in self.long_mem
-                out = torch.empty((self.CV, h, w), dtype=torch.float32, device=qk.device)
+                out = torch.empty((self.CV, nq), dtype=torch.float32, device=qk.device)
                 ops.readout_sparse(idx, weight, self.long_mem.value_arena(obj) if obj_long else None,
                                    n_long if obj_long else 0, self.work_mem.value_arena(obj), out)
-                readouts[obj] = out
+                if n_mine:
+                    mine[i, :, :n_mine] = out
+            gathered = torch.empty((world * len(bucket), self.CV, per), dtype=torch.float32, device=qk.device)
+            dist.all_gather_into_tensor(gathered, mine, group=self._shard_group)  # rank-major concatenation
+            full = gathered.view(world, len(bucket), self.CV, per).permute(1, 2, 0, 3).reshape(len(bucket), self.CV, world * per)[:, :, :hw]
+            for i, obj in enumerate(bucket):
+                readouts[obj] = full[i].reshape(self.CV, h, w).contiguous()
         return readouts
 
     # ------------------------------------------------------------------ write
