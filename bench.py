@@ -346,6 +346,20 @@ def main():
             'gflop_per_frame': flops / len(extra_frames) / 1e9,
             'ms_in_kernel_per_frame': ms / len(extra_frames),
         }
+        # HBM traffic of the heaviest launch of that kernel (3x3 256->256 on the 1/4-resolution map), from
+        # the committed rocprofv3 --pmc passes (separate runs; FETCH_SIZE doubled per the gfx950 note of
+        # MI355X_MICROARCH.md).  `traffic` stays null: bench.py cannot collect PMC counters itself.
+        pmc = os.path.join(ROOT, 'profiles', 'pmc_r01', 'rowconv_per_launch.json')
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                d = json.load(f)
+            rd = [v for k, v in d.items() if k.startswith('hbm_read_bytes')][0]
+            wr = [v for k, v in d.items() if k.startswith('hbm_write_bytes')][0]
+            alg = [v for k, v in d.items() if k.startswith('algorithmic_bytes')][0]
+            result['roofline']['pmc_heaviest_launch'] = {
+                'source': 'profiles/pmc_r01/rowconv_per_launch.json', 'hbm_bytes': rd + wr, 'algorithmic_bytes': alg,
+                'mfma_util': d['mfma_util_frac'], 'l2_hit_rate': d['l2_hit_rate'],
+                'clock_adjusted_peak_tflops': d['clock_adjusted_peak_tflops']}
         result['affinity'] = affinity_microbench(device)
         if not args.no_extra:
             cfg_lt = synth.base_config()
