@@ -66,8 +66,6 @@ struct ConvArgs {
   int64_t res_bs;
   int act;
   float* out;
-  int variant;       // experiment selector (DEVA_CONV_VARIANT)
-  int no_row;        // debugging / A-B measurements: DEVA_CONV_NO_ROW=1 disables the row-reuse kernel
   int vec_ok;        // inputs are guard-banded + 'same' stride-1 geometry: 4-pixel vector gathers allowed
   int tiles_n, tiles_m;
   int64_t ws_elems;
@@ -83,7 +81,7 @@ struct ConvArgs {
 // ROW (3x3, pad 1, 32-channel-slab weights, VEC): the input rows of a (slab, dy) pair are staged ONCE,
 // unmasked and with one halo pixel either side, and serve the three dx taps with a column offset on
 // the LDS fragment read; the zero padding is applied per consumer pixel at that read.
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MODE, int SPREAD, int VEC, int ROW, int PF = 1, int PRIO = 0>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MODE, int SPREAD, int VEC, int ROW>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 4 : 1) void conv_igemm_kernel(
     const ConvArgs p) {
   constexpr int THREADS = 64 * WAVES_M * WAVES_N;
@@ -421,28 +419,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
       const int k_next = (s + 1 < ksteps) ? (ks0 + s + 1) * BK : 0;
       const int kg_next = (s + 3 < ksteps) ? (ks0 + s + 3) * BK : 0;
       const int col = wn0 + l31 + 3 + DX;
-      // operand fragments run PF k pairs ahead of the MFMAs that consume them
-      constexpr int NF = PF + 1;
-      float fa[NF][TM], fb[NF];
+      float fa[2][TM], fb[2];
 #pragma unroll
-      for (int f = 0; f < PF; ++f) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[f][i] = As[buf][2 * f + half][wm0 + i * 32 + l31];
-        fb[f] = Bs[gbuf][2 * f + half][col];
-      }
+      for (int i = 0; i < TM; ++i) fa[0][i] = As[buf][half][wm0 + i * 32 + l31];
+      fb[0] = Bs[gbuf][half][col];
 #pragma unroll
       for (int kk = 0; kk < NKK; ++kk) {
-        if (kk + PF < NKK) {
+        if (kk + 1 < NKK) {  // fragments of the next k pair, in flight during this pair's MFMAs
 #pragma unroll
-          for (int i = 0; i < TM; ++i) fa[(kk + PF) % NF][i] = As[buf][2 * (kk + PF) + half][wm0 + i * 32 + l31];
-          fb[(kk + PF) % NF] = Bs[gbuf][2 * (kk + PF) + half][col];
+          for (int i = 0; i < TM; ++i) fa[(kk + 1) & 1][i] = As[buf][2 * (kk + 1) + half][wm0 + i * 32 + l31];
+          fb[(kk + 1) & 1] = Bs[gbuf][2 * (kk + 1) + half][col];
         }
-        const float bval = okc ? fb[kk % NF] : 0.0f;
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        const float bval = okc ? fb[kk & 1] : 0.0f;  // zero padding, per consumer pixel and tap
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk % NF][i], bval, acc[i][0], 0, 0, 0);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
+          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][i], bval, acc[i][0], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (kk == 0) {
           stage_begin(k_next);
@@ -616,7 +607,7 @@ int launch_tile(const ConvArgs& a, hipStream_t st) {
   // partial sums go to the caller's workspace, a second kernel reduces them deterministically
   const int ksteps_total = (int)ceil_div(a.K, BK);
   const bool row = a.vec_ok && mode == 1 && a.KH == 3 && a.KW == 3 && a.pad == 1 &&
-                   a.k_layout == DEVA_KLAYOUT_CHUNK32 && BN / WAVES_N == 32 && !a.no_row;
+                   a.k_layout == DEVA_KLAYOUT_CHUNK32 && BN / WAVES_N == 32;
   p.per_split = ksteps_total;
   const int64_t blocks = (int64_t)p.tiles_m * p.tiles_n;
   p.splits = 1;
@@ -647,17 +638,7 @@ int launch_tile(const ConvArgs& a, hipStream_t st) {
   } else if (mode == 1) {
     if (row) {
       if constexpr (BN / WAVES_N == 32) {
-        if (a.variant == 1) {
-          hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 1, SPREAD, 1, 1, 2, 0>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
-        } else if (a.variant == 2) {
-          hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 1, SPREAD, 1, 1, 1, 1>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
-        } else if (a.variant == 3) {
-          hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 1, SPREAD, 1, 1, 2, 1>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
-        } else if (a.variant == 4) {
-          hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 1, 1, 1, 1, 1, 0>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
-        } else {
-          hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 1, SPREAD, 1, 1>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
-        }
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 1, SPREAD, 1, 1>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
       }
     } else if (vec) {
       hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 1, SPREAD, 1, 0>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
@@ -732,16 +713,6 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
               (int64_t)d->in_guard_elems >= (int64_t)d->pad * (a.W + 1) + 4)
                  ? 1
                  : 0;
-  static const int no_row = [] {
-    const char* e = getenv("DEVA_CONV_NO_ROW");
-    return (e && e[0] == '1') ? 1 : 0;
-  }();
-  a.no_row = no_row;
-  static const int variant = [] {
-    const char* e = getenv("DEVA_CONV_VARIANT");
-    return e ? atoi(e) : 0;
-  }();
-  a.variant = variant;
   a.per_split = 0;
   a.splits = 1;
   a.ws = d->workspace;
