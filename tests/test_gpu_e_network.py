@@ -190,6 +190,15 @@ def test_480p_lockstep_teacher_forced(network, recipe_state_dict):
     print('lockstep 480p worst relative errors:', json.dumps({k: float(f'{v:.2e}') for k, v in worst.items()}))
 
 
+def test_1080p_lockstep_teacher_forced(network, recipe_state_dict):
+    """The same at BASELINE's 1080p size (1088x1920 padded, 8 160 queries), one object, 3 frames:
+    the CPU oracle needs a few seconds per frame there, so the clip is short."""
+    import lockstep
+    P, _ = recipe_state_dict
+    worst = lockstep.run(network, P, 1088, 1920, 1, 3, dev())
+    print('lockstep 1080p worst relative errors:', json.dumps({k: float(f'{v:.2e}') for k, v in worst.items()}))
+
+
 def test_detection_clip_against_reference_golden(network, golden_dir):
     """incorporate_detection (match_and_merge on the histogram / paint kernels) + propagation, online
     setting, against the reference's outputs and object-manager state"""

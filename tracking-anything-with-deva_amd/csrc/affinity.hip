@@ -15,13 +15,23 @@
 // the whole kernel, the key rows are read straight from the token-major bank and prefetched one
 // tile ahead (a 32x64 fp32 tile per 4096 matrix-pipe cycles -- operand traffic is irrelevant here,
 // the kernel is bound by the fp32 MFMA rate).  Per query the wave keeps a candidate list in LDS
-// (176 slots of 6 bytes): scores >= the running k-th best are appended (~k*(1+ln(n/k)) appends per
-// query over n tokens), and a list that could overflow is pruned back to its exact best k by a
-// ballot-driven bitwise bisection.  grid.y splits the bank into token ranges so small frames
-// still fill 256 CUs; the ranges hand over their lists as they are and a second kernel (one wave
-// per query) selects the exact top-k over all ranges, applies exp/normalise and accumulates the
-// usage counters.
+// (176 slots of 6 bytes) with its length and threshold in registers: scores >= the running lower bound
+// of the k-th best are appended (~k*(1+ln(n/k)) appends per query over n tokens); a list that could
+// overflow is pruned to the entries >= the k-th largest of its 64 per-lane maxima (exact for the final
+// result, and the ballot-driven bisection runs over one key per lane).  grid.y splits the bank into
+// token ranges so small frames still fill 256 CUs; the ranges hand over their lists as they are and a
+// second kernel (one wave per query) selects the exact top-k over all ranges, applies exp/normalise
+// and accumulates the usage counters.
+//
+// Issue model that shaped the loop (tools/probe/README.md): VALU instructions do not overlap the
+// wave's own MFMAs, and only one wave per SIMD fits next to 136 KiB of lists -- so every VALU
+// instruction per tile is paid in full.  Hence: packed-fp32 scoring, rows filed only when some lane
+// passes (one ballot + one scalar branch per row otherwise), list positions from the ballot instead
+// of atomics, accumulators kept in VGPRs (-amdgpu-mfma-vgpr-form, see the Makefile), operand rows
+// loaded with a per-half-lane offset instead of being selected.
 #include <math.h>
+
+#include <type_traits>
 
 #include "common.h"
 
@@ -31,6 +41,9 @@ namespace deva {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef f32x4 f32x4_u __attribute__((aligned(4)));  // 16-B load from a dword-aligned address
 
 constexpr int CK = 64;
 constexpr int QT = 32;            // queries per wave
@@ -104,17 +117,23 @@ __device__ __forceinline__ uint64_t kth_largest(const uint64_t (&e)[E], int n_li
   return ((uint64_t)T << 32) | L;
 }
 
-// prune one candidate list (wave-cooperative, c <= 192 entries, c >= k) to its exact best k
-// (unsorted); returns the k-th best key (score bits << 32 | 0xffff - token offset)
-__device__ __forceinline__ uint64_t prune_list(uint32_t* sc, uint16_t* tk, uint32_t c, int k,
-                                               int lane) {
+// Prune one candidate list (wave-cooperative, 64 <= c <= 192 entries).  Threshold = the k-th largest of
+// the 64 per-lane maxima: at least k entries of the list are >= it, so nothing below it can belong to
+// the top-k -- the result stays exact while the bisection (what a prune costs) runs over one key per
+// lane instead of three.  Typically k .. 1.5k entries survive.  Returns the threshold key; *kept =
+// number of survivors (compacted to the front, unsorted).
+__device__ __forceinline__ uint64_t prune_list(uint32_t* sc, uint16_t* tk, uint32_t c, int k, int lane,
+                                               int* kept) {
   uint64_t e[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const uint32_t j = (uint32_t)lane + 64u * i;
     e[i] = (j < c) ? (((uint64_t)sc[j] << 32) | (uint64_t)(0xffffu - tk[j])) : 0ull;
   }
-  const uint64_t thr = kth_largest<3>(e, 3, k);
+  uint64_t m[1] = {e[0]};
+  m[0] = e[1] > m[0] ? e[1] : m[0];
+  m[0] = e[2] > m[0] ? e[2] : m[0];
+  const uint64_t thr = kth_largest<1>(m, 1, k);
   DEVA_COMPILER_FENCE();
   int base = 0;
 #pragma unroll
@@ -129,6 +148,7 @@ __device__ __forceinline__ uint64_t prune_list(uint32_t* sc, uint16_t* tk, uint3
     base += __popcll(b);
   }
   DEVA_COMPILER_FENCE();
+  *kept = base;
   return thr;
 }
 
@@ -152,8 +172,7 @@ struct AffArgs {
 __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs p) {
   __shared__ uint32_t s_sc[WAVES][QT][LSTRIDE];  // candidate scores (order-preserving bits)
   __shared__ uint16_t s_tk[WAVES][QT][LSTRIDE];  // candidate tokens (offset inside this range)
-  __shared__ uint32_t s_cnt[WAVES][QT];
-  __shared__ float s_tau[WAVES][QT];
+  __shared__ __attribute__((aligned(16))) float s_ms[WAVES][TOKT];  // shrinkage / 8 of the current tile
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -169,14 +188,9 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
   // DEVA_COMPILER_FENCE() marks the hand-over points.
   uint32_t* csc = &s_sc[wave][0][0];
   uint16_t* ctk = &s_tk[wave][0][0];
-  uint32_t* cnt = &s_cnt[wave][0];
-  float* tau = &s_tau[wave][0];
-
-  if (lane < QT) {
-    cnt[lane] = 0;
-    tau[lane] = -INFINITY;
-  }
-  DEVA_COMPILER_FENCE();
+  float* msl = &s_ms[wave][0];
+  uint32_t* srow = csc + l31 * LSTRIDE;
+  uint16_t* trow = ctk + l31 * LSTRIDE;
 
   // ---- query operand (registers, whole kernel).  MFMA t consumes channels 2t (lanes 0-31) and
   // 2t+1 (lanes 32-63): natural channel order in the accumulation chain.
@@ -195,57 +209,80 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
     bqk[t] = half ? (k1 * e1) : (k0 * e0);
   }
   const float bsq = ((bs[0] + bs[1]) + bs[2]) + bs[3];
+  const f32x2 bsq2 = {bsq, bsq};
 
   const int t_begin = split * p.tiles_per_split;
   const int t_end = min(p.total_tiles, t_begin + p.tiles_per_split);
   const int n_range0 = t_begin * TOKT;  // candidate tokens are stored as 16-bit offsets from here
 
-  // key rows are software-prefetched one tile ahead: lane (l31, half) reads the whole 256-B row of
-  // token n_base + l31 into xbuf while the matrix pipe works on the previous tile
-  float4 xbuf[CK / 4];
+  // ---- per-query state in registers (the same value in both half-lanes of a query): list length and
+  // the running lower bound of the k-th best score
+  uint32_t cnt = 0;
+  float tau = -INFINITY;
+
+  // Key rows are software-prefetched one tile ahead: lane (l31, half) reads the 256-B row of token
+  // n_base + l31 while the matrix pipe works on the previous tile.  Lanes of the upper half start one
+  // float later, so that x / z of every 16-B piece are exactly the channels 2t+half the lane feeds to
+  // the MFMAs -- no per-element select (VALU work does not overlap the wave's own MFMAs, every
+  // instruction saved here is time saved; tools/probe/README.md).  The last piece is read aligned
+  // (a shifted read would touch the next row) and selected.
+  f32x4 xbuf[CK / 4];
   float ms_buf;
   auto prefetch = [&](int tile) {
     const int n_mine = min(tile * TOKT + l31, p.n_total - 1);
     const float* krow = (n_mine < p.n_long) ? (p.key_long + (int64_t)n_mine * CK)
                                             : (p.key_work + (int64_t)(n_mine - p.n_long) * CK);
-    ms_buf = (n_mine < p.n_long) ? p.shr_long[n_mine] : p.shr_work[n_mine - p.n_long];
+    // 1/sqrt(CK) folded into the shrinkage: (x * ms) * 0.125 == x * (ms * 0.125) exactly
+    ms_buf = ((n_mine < p.n_long) ? p.shr_long[n_mine] : p.shr_work[n_mine - p.n_long]) * 0.125f;
+    const float* shifted = krow + half;
 #pragma unroll
-    for (int j = 0; j < CK / 4; ++j) xbuf[j] = reinterpret_cast<const float4*>(krow)[j];
+    for (int j = 0; j < CK / 4 - 1; ++j) xbuf[j] = *reinterpret_cast<const f32x4_u*>(shifted + 4 * j);
+    xbuf[CK / 4 - 1] = *reinterpret_cast<const f32x4*>(krow + CK - 4);
   };
   if (t_begin < t_end) prefetch(t_begin);
+
+  auto prune_over = [&](uint32_t limit) {
+    uint64_t need = __ballot(cnt > limit) & 0xffffffffull;
+    while (need) {
+      const int qq = __ffsll((unsigned long long)need) - 1;
+      need &= need - 1;
+      const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cnt, qq);
+      int kept;
+      const uint64_t thr = prune_list(csc + qq * LSTRIDE, ctk + qq * LSTRIDE, c, p.k, lane, &kept);
+      if (l31 == qq) {
+        cnt = (uint32_t)kept;
+        tau = from_orderable((uint32_t)(thr >> 32));
+      }
+    }
+  };
 
   for (int tile = t_begin; tile < t_end; ++tile) {
     const int n_base = tile * TOKT;
 
     // ---- prune lists that could overflow during this tile (at most 32 appends per query per tile)
-    {
-      const uint32_t c_mine = cnt[l31];
-      uint64_t need = __ballot(c_mine > (uint32_t)(LCAP - TOKT)) & 0xffffffffull;
-      while (need) {
-        const int qq = __ffsll((unsigned long long)need) - 1;
-        need &= need - 1;
-        const uint64_t thr = prune_list(csc + qq * LSTRIDE, ctk + qq * LSTRIDE, cnt[qq], p.k, lane);
-        if (lane == 0) {
-          cnt[qq] = (uint32_t)p.k;
-          tau[qq] = from_orderable((uint32_t)(thr >> 32));
-        }
-        DEVA_COMPILER_FENCE();
-      }
-    }
-    const float tau_l = tau[l31];
+    prune_over((uint32_t)(LCAP - TOKT));
 
     // ---- this tile's operand: channel 2t + half of this lane's token, then start the next loads
     float a_op[CK / 2];
 #pragma unroll
-    for (int t = 0; t < CK / 2; ++t) {
-      const float4 v = xbuf[t >> 1];
-      const float lo = (t & 1) ? v.z : v.x;
-      const float hi = (t & 1) ? v.w : v.y;
-      a_op[t] = half ? hi : lo;
+    for (int j = 0; j < CK / 4 - 1; ++j) {
+      a_op[2 * j] = xbuf[j][0];
+      a_op[2 * j + 1] = xbuf[j][2];
     }
-    const float ms_mine = ms_buf;
+    a_op[CK / 2 - 2] = half ? xbuf[CK / 4 - 1][1] : xbuf[CK / 4 - 1][0];
+    a_op[CK / 2 - 1] = half ? xbuf[CK / 4 - 1][3] : xbuf[CK / 4 - 1][2];
+    if (lane < TOKT) msl[lane] = ms_buf;
+    DEVA_COMPILER_FENCE();
     prefetch(min(tile + 1, t_end - 1));
 
+    float a_sq[CK / 2];
+#pragma unroll
+    for (int t = 0; t < CK / 2; t += 2) {
+      const f32x2 a2 = {a_op[t], a_op[t + 1]};
+      const f32x2 s2 = a2 * a2;
+      a_sq[t] = s2[0];
+      a_sq[t + 1] = s2[1];
+    }
     f32x16 accA, accB;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -254,39 +291,53 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
     }
 #pragma unroll
     for (int t = 0; t < CK / 2; ++t) {
-      const float a = a_op[t];
-      accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a * a, bqe[t], accA, 0, 0, 0);
-      accB = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bqk[t], accB, 0, 0, 0);
+      accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a_sq[t], bqe[t], accA, 0, 0, 0);
+      accB = __builtin_amdgcn_mfma_f32_32x32x2f32(a_op[t], bqk[t], accB, 0, 0, 0);
     }
 
-    // ---- scores of this lane: query l31, tokens n_base + (r&3) + 8*(r>>2) + 4*half
-    uint32_t pass = 0;
-    float sc[16];
+    // ---- scores of this lane: query l31, tokens n_base + (r&3) + 8*(r>>2) + 4*half, two accumulator
+    // rows per packed-fp32 instruction.  A row is filed only if some lane of the wave passes its
+    // threshold (about every other row once the thresholds have settled); the position in the list the
+    // two half-lanes of a query share comes from the ballot.
+    float4 ms4[4];  // scaled shrinkage in accumulator-row order: rows 4g..4g+3 <-> tokens 8g+4*half..+3
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int j = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const float ms = __shfl(ms_mine, j);
-      float v = (-accA[r] + 2.0f * accB[r]) - bsq;
-      v = v * ms * 0.125f;
-      sc[r] = v;
-      const bool ok = (n_base + j < p.n_total) && (v >= tau_l);
-      pass |= ok ? (1u << r) : 0u;
-    }
-    const int np = __popc(pass);
-    if (np) {
-      uint32_t pos = __hip_atomic_fetch_add((uint32_t*)&s_cnt[wave][l31], (uint32_t)np, __ATOMIC_RELAXED,
-                                            __HIP_MEMORY_SCOPE_WORKGROUP);
-      uint32_t* srow = csc + l31 * LSTRIDE;
-      uint16_t* trow = ctk + l31 * LSTRIDE;
+    for (int g = 0; g < 4; ++g) ms4[g] = *reinterpret_cast<const float4*>(&msl[8 * g + 4 * half]);
+    const int rows_left = p.n_total - n_base;  // >= TOKT except in the last tile of the bank
+    const uint32_t tok0 = (uint32_t)(n_base - n_range0 + 4 * half);
+    auto file_rows = [&](auto full) {
+      constexpr bool full_tile = decltype(full)::value;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (pass & (1u << r)) {
-          const int j = (r & 3) + 8 * (r >> 2) + 4 * half;
-          srow[pos] = orderable(sc[r]);
-          trow[pos] = (uint16_t)(n_base - n_range0 + j);
-          ++pos;
+      for (int r2 = 0; r2 < 8; ++r2) {
+        const f32x2 a2 = {accA[2 * r2], accA[2 * r2 + 1]};
+        const f32x2 b2 = {accB[2 * r2], accB[2 * r2 + 1]};
+        const float4 m4 = ms4[r2 >> 1];
+        const f32x2 m2 = (r2 & 1) ? f32x2{m4.z, m4.w} : f32x2{m4.x, m4.y};
+        f32x2 v2 = ((b2 + b2) - a2) - bsq2;  // == (-A + 2B) - bsq, every step correctly rounded
+        v2 = v2 * m2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int r = 2 * r2 + h;
+          const int j0 = (r & 3) + 8 * (r >> 2);  // + 4 * half
+          const float v = v2[h];
+          bool ok = v >= tau;
+          if (!full_tile) ok = ok && (j0 + 4 * half < rows_left);
+          const unsigned long long b = __ballot(ok);
+          if (b) {
+            const uint32_t ok_lo = (uint32_t)(b >> l31) & 1u, ok_hi = (uint32_t)(b >> (32 + l31)) & 1u;
+            if (ok) {
+              const uint32_t pos = cnt + (half ? ok_lo : 0u);
+              srow[pos] = orderable(v);
+              trow[pos] = (uint16_t)(tok0 + j0);
+            }
+            cnt += ok_lo + ok_hi;
+          }
         }
       }
+    };
+    if (rows_left >= TOKT) {
+      file_rows(std::true_type{});
+    } else {
+      file_rows(std::false_type{});
     }
     DEVA_COMPILER_FENCE();
   }
@@ -295,28 +346,22 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
   // query): the exact top-k selection over all ranges happens in the merge kernel, where one wave per
   // query gives thousands of independent waves -- here it would run serially, 32 lists per wave.
   // Only a list that outgrew the CAP hand-over slots is pruned first.
-  {
-    const uint32_t c_mine = cnt[l31];
-    uint64_t need = __ballot(c_mine > (uint32_t)CAP) & 0xffffffffull;
-    while (need) {
-      const int qq = __ffsll((unsigned long long)need) - 1;
-      need &= need - 1;
-      prune_list(csc + qq * LSTRIDE, ctk + qq * LSTRIDE, cnt[qq], p.k, lane);
-      if (lane == 0) cnt[qq] = (uint32_t)p.k;
-      DEVA_COMPILER_FENCE();
-    }
-  }
+  prune_over((uint32_t)CAP);
+  DEVA_COMPILER_FENCE();
   const int nq = min(QT, p.hw - q0);
   uint64_t* dst = p.part + ((int64_t)split * p.hw + q0) * CAP;
-  for (int e = lane; e < nq * CAP; e += 64) {
-    const int ql = e / CAP;
-    const int r = e - ql * CAP;
-    uint64_t key = 0ull;
-    if ((uint32_t)r < cnt[ql]) {
-      const uint32_t token = (uint32_t)n_range0 + (uint32_t)ctk[ql * LSTRIDE + r];
-      key = ((uint64_t)csc[ql * LSTRIDE + r] << 32) | (uint64_t)(~token);
+  for (int ql = 0; ql < nq; ++ql) {
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cnt, ql);
+#pragma unroll
+    for (int i = 0; i < CAP / 64; ++i) {
+      const uint32_t r = (uint32_t)lane + 64u * i;
+      uint64_t key = 0ull;
+      if (r < c) {
+        const uint32_t token = (uint32_t)n_range0 + (uint32_t)ctk[ql * LSTRIDE + r];
+        key = ((uint64_t)csc[ql * LSTRIDE + r] << 32) | (uint64_t)(~token);
+      }
+      dst[(int64_t)ql * CAP + r] = key;
     }
-    dst[e] = key;
   }
 }
 
