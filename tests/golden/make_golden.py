@@ -184,7 +184,30 @@ def gen_detection_e2e(net):
     print('detections: channels per frame', [p.shape[0] for p in outs], _manager_state(core.object_manager)['ids'])
 
 
+def gen_alignment(net):
+    """spatial_alignment (consensus_associated.py:16-69): project a 2-object segmentation of one
+    frame onto the next frame of the voting window; plus the keyframe projection of
+    find_consensus_with_established_association (:82-160) on three frames"""
+    from deva.inference.consensus_associated import find_consensus_with_established_association, spatial_alignment
+    from deva.inference.image_feature_store import ImageFeatureStore
+    cfg = synth.base_config()
+    sc = scenarios.ALIGNMENT
+    frames, masks = scenarios.alignment_inputs(sc)
+    store = ImageFeatureStore(net, no_warning=True)
+    out = spatial_alignment(0, frames[0], masks[0], 1, frames[1], net, store, cfg)
+    store2 = ImageFeatureStore(net, no_warning=True)
+    key_ti, consensus = find_consensus_with_established_association(
+        [0, 1, 2], [f.clone() for f in frames], [m.clone() for m in masks], net, store2, cfg)
+    torch.save(dict(aligned=out.clone(), keyframe=int(key_ti), consensus=consensus.clone()),
+               os.path.join(HERE, 'alignment.pt'))
+
+
 if __name__ == '__main__':
+    only = os.environ.get('ONLY')
+    if only == 'alignment':
+        net, _, _ = build_reference(synth.base_config())
+        gen_alignment(net)
+        sys.exit(0)
     cfg = synth.base_config()
     net, spec, sd = build_reference(cfg)
     gen_spec(spec, sd)
@@ -194,5 +217,6 @@ if __name__ == '__main__':
     gen_vos_example(net)
     gen_merge()
     gen_detection_e2e(net)
+    gen_alignment(net)
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -128,3 +128,22 @@ def merge_case(seed):
     new_info = [dict(id=101, category_id=1, isthing=True), dict(id=102, category_id=2, isthing=False),
                 dict(id=103, category_id=5, isthing=True), dict(id=104, category_id=None, isthing=None)]
     return ours, our_info, news, new_info
+
+
+# ---------------------------------------------------------------------------------------------
+# semi-online voting window: spatial alignment of per-frame segmentations onto a keyframe
+# (deva/inference/consensus_associated.py)
+ALIGNMENT = dict(H=96, W=128, nobj=2, frames=3)
+
+
+def alignment_inputs(sc):
+    """three coherent frames and a soft 2-object segmentation for each (boxes that drift a little)"""
+    stream = synth.FrameStream(sc['H'], sc['W'], seed=8)
+    frames = [stream.next() for _ in range(sc['frames'])]
+    masks = []
+    for t in range(sc['frames']):
+        m = torch.zeros(sc['nobj'], sc['H'], sc['W'])
+        m[0, 10 + 2 * t:50 + 2 * t, 12 + 3 * t:60 + 3 * t] = 0.9 - 0.1 * t
+        m[1, 40:90, 70 - 2 * t:120 - 2 * t] = 0.8
+        masks.append(m)
+    return frames, masks

@@ -245,3 +245,17 @@ def test_sharded_read_single_rank_group_is_identical(network):
     assert all(torch.equal(a, b) for a, b in zip(plain, sharded))
     for b in core_a.memory.work_mem.buckets:
         assert torch.equal(core_a.memory.work_mem.get_usage(b), core_b.memory.work_mem.get_usage(b))
+
+
+def test_spatial_alignment_against_reference_golden(network, golden_dir):
+    """semi-online voting window (SURVEY.md §8f #2): one-frame fused memory read + decoder"""
+    from deva.inference.consensus_associated import spatial_alignment
+    from deva.inference.image_feature_store import ImageFeatureStore
+    g = torch.load(os.path.join(golden_dir, 'alignment.pt'))
+    frames, masks = scenarios.alignment_inputs(scenarios.ALIGNMENT)
+    store = ImageFeatureStore(network, no_warning=True)
+    out = spatial_alignment(0, frames[0].to(dev()), masks[0].to(dev()), 1, frames[1].to(dev()), network, store,
+                            synth.base_config())
+    err = max_err(out, g['aligned'])
+    print(f'spatial_alignment max abs err {err:.3e}')
+    assert out.shape == g['aligned'].shape and err <= 1e-3
