@@ -48,6 +48,14 @@ CASES += [
 ]
 
 
+# single output channel on a large guard-banded map: the row-reusing VALU kernel (conv_cout1.hip); the
+# unguarded variants of the same cases run on the MFMA tile
+CASES += [
+    ('pred_rows_big', 96, 0, 1, 3, 1, 1, 2, 96, 128, False, True, 'none', ops.ACT_NONE, True, False),
+    ('pred_rows_cat_res', 32, 40, 1, 3, 1, 1, 3, 76, 84, True, False, 'full', ops.ACT_SIGMOID, True, False),
+]
+
+
 def _guarded(x):
     """the tensor inside a NaN-filled buffer with ops.GUARD floats on either side: what ops._alloc
     returns, with poison in the guard bands so that any unmasked over-read shows up as NaN"""

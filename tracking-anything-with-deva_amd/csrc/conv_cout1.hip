@@ -99,7 +99,116 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const Cout1Args p) {
   }
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef f32x4 f32x4_u __attribute__((aligned(4)));  // 4 consecutive pixels, dword-aligned only
+
+// 3x3 / stride 1 / pad 1 on a large map (the 256->1 mask-logit head at 1/4 resolution: 0.6 GFLOP over
+// 130 MB of input -- HBM-bound, 31/32 of an MFMA tile would be padding).  A thread owns 4 consecutive
+// output pixels of a row; per channel and input row it reads the 6 pixels ow-1 .. ow+4 with two
+// dword-aligned 16-B loads (guard-banded tensors, like the vector gather of conv_igemm) and applies the
+// three taps of that row from registers: 6 loads per 36 MACs, 24 loads in flight.  The four waves of a
+// block take every fourth channel (weights from LDS, broadcast reads: the channel is wave-uniform);
+// partial sums meet in LDS.  Needs OW % 4 == 0 and readable guard bands of W + 8 floats.
+__global__ __launch_bounds__(256) void conv3x3_cout1_rows_kernel(const Cout1Args p) {
+  __shared__ f32x4 red[4][64];
+  const int lane = threadIdx.x & 63;
+  const int cg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // channel group = wave
+  const int strips = p.n_total >> 2;
+  const int sidx = blockIdx.x * 64 + lane;
+  const bool s_ok = sidx < strips;
+  const int n = (s_ok ? sidx : 0) * 4;
+  const int b = n / p.OHW;
+  const int pix = n - b * p.OHW;
+  const int oh = pix / p.OW, ow = pix - oh * p.OW;
+  const float* src0 = p.in0 + (int64_t)b * p.bs0 + pix;
+  const float* src1 = (p.in1 ? p.in1 + (int64_t)b * p.bs1 : p.in0) + pix;
+  const bool left = ow > 0, right = ow + 4 < p.W;
+  const bool up = oh > 0, down = oh + 1 < p.H;
+  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+
+  // weights of the one output channel, [channel][tap] in LDS (uniform addresses: broadcast reads)
+  extern __shared__ float wsm[];
+  for (int i = threadIdx.x; i < p.ctot * 9; i += 256) {
+    const int c = i / 9, t = i - c * 9;
+    const int k = (p.k_layout == DEVA_KLAYOUT_CHUNK32) ? (((c >> 5) * 9 + t) * 32 + (c & 31)) : (t * p.ctot + c);
+    wsm[i] = p.w[(int64_t)k * p.cout_pad];
+  }
+  __syncthreads();
+  // out-of-image rows contribute nothing: their taps are zeroed, their (clamped) reads are harmless
+  const float u = up ? 1.0f : 0.0f, d = down ? 1.0f : 0.0f;
+  const int o_up = up ? -p.W : 0, o_dn = down ? p.W : 0;
+
+  constexpr int U = 4;  // channels in flight per thread: 24 independent 16-B loads
+  for (int c0 = cg; c0 < p.ctot; c0 += 4 * U) {  // wave-uniform channels cg, cg+4, ...
+    f32x4 a[U][3], e[U][3];
+    bool live[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const int c = c0 + 4 * q;
+      live[q] = c < p.ctot;
+      const int cc = live[q] ? c : cg;
+      const float* sp = (cc < p.c0) ? (src0 + (int64_t)cc * p.HW) : (src1 + (int64_t)(cc - p.c0) * p.HW);
+      a[q][0] = *reinterpret_cast<const f32x4_u*>(sp + o_up - 1);  // ow-1 .. ow+2
+      e[q][0] = *reinterpret_cast<const f32x4_u*>(sp + o_up + 3);  // ow+3 .. ow+6 (the last two are not used)
+      a[q][1] = *reinterpret_cast<const f32x4_u*>(sp - 1);
+      e[q][1] = *reinterpret_cast<const f32x4_u*>(sp + 3);
+      a[q][2] = *reinterpret_cast<const f32x4_u*>(sp + o_dn - 1);
+      e[q][2] = *reinterpret_cast<const f32x4_u*>(sp + o_dn + 3);
+    }
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const int c = live[q] ? c0 + 4 * q : cg;
+      const float lv = live[q] ? 1.0f : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float rs = (r == 0 ? u : (r == 2 ? d : 1.0f)) * lv;
+        const float w0 = wsm[c * 9 + 3 * r] * rs, w1 = wsm[c * 9 + 3 * r + 1] * rs, w2 = wsm[c * 9 + 3 * r + 2] * rs;
+        f32x4 x = a[q][r], y = e[q][r];
+        if (p.relu_in) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) x[i] = fmaxf(x[i], 0.0f);
+          y[0] = fmaxf(y[0], 0.0f);
+          y[1] = fmaxf(y[1], 0.0f);
+        }
+        const float x0 = left ? x[0] : 0.0f, x5 = right ? y[1] : 0.0f;
+        acc[0] += w0 * x0 + w1 * x[1] + w2 * x[2];
+        acc[1] += w0 * x[1] + w1 * x[2] + w2 * x[3];
+        acc[2] += w0 * x[2] + w1 * x[3] + w2 * y[0];
+        acc[3] += w0 * x[3] + w1 * y[0] + w2 * x5;
+      }
+    }
+  }
+  red[cg][lane] = acc;
+  __syncthreads();
+  if (cg == 0 && s_ok) {
+    f32x4 v = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    const f32x4 r = p.res ? *reinterpret_cast<const f32x4*>(p.res + (int64_t)b * p.res_bs + pix) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float x = v[i];
+      if (p.bias) x += p.bias[0];
+      if (p.res) x += r[i];
+      if (p.act == DEVA_ACT_RELU) {
+        x = fmaxf(x, 0.0f);
+      } else if (p.act == DEVA_ACT_SIGMOID) {
+        x = sigmoidf_(x);
+      } else if (p.act == DEVA_ACT_SQUARE_PLUS_ONE) {
+        x = x * x + 1.0f;
+      }
+      v[i] = x;
+    }
+    *reinterpret_cast<f32x4*>(p.out + (int64_t)b * p.OHW + pix) = v;
+  }
+}
+
 }  // namespace
+
+int launch_conv3x3_cout1_rows(const Cout1Args& a, hipStream_t st) {
+  const int strips = a.n_total / 4;
+  hipLaunchKernelGGL(conv3x3_cout1_rows_kernel, dim3((unsigned)ceil_div(strips, 64)), dim3(256),
+                     sizeof(float) * 9 * (size_t)a.ctot, st, a);
+  return check_launch("deva_conv2d(cout=1, 3x3 rows)");
+}
 
 int launch_conv_cout1(const Cout1Args& a, hipStream_t st) {
   const int K = a.KH * a.KW * a.ctot;

@@ -40,6 +40,7 @@ struct Cout1Args {
   float* out;
 };
 int launch_conv_cout1(const Cout1Args& a, hipStream_t st);
+int launch_conv3x3_cout1_rows(const Cout1Args& a, hipStream_t st);
 
 namespace {
 
@@ -719,9 +720,12 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
   a.ws_elems = d->workspace ? d->workspace_elems : 0;
 
   hipStream_t st = (hipStream_t)stream;
-  // single output channel on a small map (shrinkage head, CBAM gate): VALU dot product (conv_cout1.hip);
-  // large maps stay on the MFMA tile, which is faster there despite the 31 padded rows
-  if (a.cout == 1 && a.K <= 12288 && a.n_total < 16384) {
+  // single output channel: VALU kernels (conv_cout1.hip) -- a dot product per pixel on small maps
+  // (shrinkage head, CBAM gate), a row-reusing 3x3 kernel on large guard-banded maps (mask-logit head);
+  // anything else stays on the MFMA tile
+  const bool rows3x3 = a.cout == 1 && a.vec_ok && a.KH == 3 && a.KW == 3 && a.pad == 1 && a.OW % 4 == 0 &&
+                       a.n_total >= 16384 && a.ctot <= 1024 && (int64_t)d->in_guard_elems >= a.W + 8;
+  if (rows3x3 || (a.cout == 1 && a.K <= 12288 && a.n_total < 16384)) {
     Cout1Args c;
     c.in0 = a.in0;
     c.in1 = a.in1;
@@ -749,6 +753,7 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
     c.res_bs = a.res_bs;
     c.act = a.act;
     c.out = a.out;
+    if (rows3x3) return launch_conv3x3_cout1_rows(c, st);
     return launch_conv_cout1(c, st);
   }
   // Tile choice (all tiles run 32-deep K steps):
