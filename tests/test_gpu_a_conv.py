@@ -105,3 +105,30 @@ def test_conv_rejects_cpu_tensors():
     pc = ops.pack_conv(torch.zeros(32, 16, 1, 1))
     with pytest.raises(Exception):
         ops.conv2d(pc, torch.zeros(1, 16, 4, 4))
+
+
+@pytest.mark.parametrize('cin,cout,k,h,w', [(1024, 256, 1, 30, 54), (256, 256, 3, 30, 54), (512, 64, 3, 30, 54),
+                                             (256, 1024, 1, 30, 54)])
+def test_split_k_is_deterministic(cin, cout, k, h, w):
+    """Layers with few output tiles accumulate K ranges in parallel workgroups and a second kernel adds
+    the partial sums in split order: every repetition must reproduce the first result bit for bit, with
+    other split-K layers using the same workspace in between."""
+    g = torch.Generator().manual_seed(cin + cout + k)
+    wgt = rand(g, cout, cin, k, k, scale=(2.0 / (cin * k * k))**0.5)
+    b = rand(g, cout, scale=0.1)
+    pc = to_dev(ops.pack_conv(wgt, b))
+    x = ops._alloc((1, cin, h, w), dev())
+    x.copy_(rand(g, 1, cin, h, w))
+    other_pc = to_dev(ops.pack_conv(rand(g, 128, 512, 1, 1, scale=0.05)))
+    other_x = to_dev(rand(g, 1, 512, 16, 16))
+    want = emu_ops.conv2d(ops.pack_conv(wgt, b), x.cpu(), None, stride=1, pad=k // 2, act=ops.ACT_RELU)
+    first = ops.conv2d(pc, x, pad=k // 2, act=ops.ACT_RELU).clone()
+    assert max_err(first, want) <= 2e-5 * max(1.0, want.abs().max().item())
+    outs = []
+    for it in range(300):
+        outs.append(ops.conv2d(pc, x, pad=k // 2, act=ops.ACT_RELU))
+        if it % 3 == 0:
+            ops.conv2d(other_pc, other_x)
+    torch.cuda.synchronize()
+    bad = sum(int(not torch.equal(o, first)) for o in outs)
+    assert bad == 0, f'{bad} of 300 repetitions differ from the first result'
