@@ -202,8 +202,36 @@ def gen_alignment(net):
                os.path.join(HERE, 'alignment.pt'))
 
 
+def gen_api_surface():
+    """public methods (name -> parameter list with defaults) of the classes on the drop-in boundary,
+    read off the reference with inspect"""
+    import inspect
+    from deva.inference.image_feature_store import ImageFeatureStore
+    from deva.inference.kv_memory_store import KeyValueMemoryStore
+    from deva.inference.object_info import ObjectInfo
+    from deva.inference.object_manager import ObjectManager
+    out = {}
+    for cls in (DEVA, DEVAInferenceCore, MemoryManager, KeyValueMemoryStore, ObjectManager, ObjectInfo, ImageFeatureStore):
+        methods = {}
+        for name, fn in inspect.getmembers(cls, predicate=inspect.isfunction):
+            if fn.__qualname__.split('.')[0] != cls.__name__:
+                continue  # inherited from nn.Module / object
+            if name.startswith('_') and name not in ('__init__', '_segment', '_add_memory'):
+                continue
+            sig = inspect.signature(fn)
+            methods[name] = [[p.name, str(p.kind), None if p.default is inspect._empty else repr(p.default)]
+                             for p in sig.parameters.values()]
+        props = [n for n, v in inspect.getmembers(cls) if isinstance(v, property)]
+        out[cls.__name__] = dict(methods=methods, properties=props)
+    with open(os.path.join(HERE, 'api_surface.json'), 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
 if __name__ == '__main__':
     only = os.environ.get('ONLY')
+    if only == 'api':
+        gen_api_surface()
+        sys.exit(0)
     if only == 'alignment':
         net, _, _ = build_reference(synth.base_config())
         gen_alignment(net)
@@ -218,5 +246,6 @@ if __name__ == '__main__':
     gen_merge()
     gen_detection_e2e(net)
     gen_alignment(net)
+    gen_api_surface()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -218,3 +218,40 @@ def test_established_association_consensus_through_the_overlay(emu, golden_dir, 
             pkg.__path__.remove(d)
         for name in [n for n in sys.modules if n.startswith('deva.model.memory_utils') or n.endswith('_reference_consensus_associated')]:
             del sys.modules[name]
+
+
+def test_api_surface_matches_reference(golden_dir):
+    """drop-in boundary: every public method / property of the reference's classes on
+    the path exists here with the same parameter names, kinds and defaults (read off the reference with
+    inspect by tests/golden/make_golden.py)"""
+    import inspect
+    from deva.inference.image_feature_store import ImageFeatureStore
+    from deva.inference.inference_core import DEVAInferenceCore
+    from deva.inference.kv_memory_store import KeyValueMemoryStore
+    from deva.inference.memory_manager import MemoryManager
+    from deva.inference.object_info import ObjectInfo
+    from deva.inference.object_manager import ObjectManager
+    from deva.model.network import DEVA
+    with open(os.path.join(golden_dir, 'api_surface.json')) as f:
+        ref = json.load(f)
+    mine = {c.__name__: c for c in (DEVA, DEVAInferenceCore, MemoryManager, KeyValueMemoryStore, ObjectManager,
+                                    ObjectInfo, ImageFeatureStore)}
+    problems = []
+    for cname, spec in ref.items():
+        cls = mine[cname]
+        for prop in spec['properties']:
+            if not isinstance(inspect.getattr_static(cls, prop, None), property):
+                problems.append(f'{cname}.{prop}: property missing')
+        for mname, params in spec['methods'].items():
+            fn = inspect.getattr_static(cls, mname, None)
+            if fn is None:
+                problems.append(f'{cname}.{mname}: missing')
+                continue
+            sig = inspect.signature(getattr(cls, mname))
+            got = [[p.name, str(p.kind), None if p.default is inspect._empty else repr(p.default)]
+                   for p in sig.parameters.values()]
+            # extra keyword-only parameters with defaults are allowed (e.g. token_major=False)
+            core = [g for g in got if not (g[1] == 'KEYWORD_ONLY' and g[2] is not None and g[0] not in [p[0] for p in params])]
+            if core != params:
+                problems.append(f'{cname}.{mname}: {core} != {params}')
+    assert not problems, '\\n'.join(problems)

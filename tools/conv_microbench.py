@@ -29,6 +29,11 @@ SHAPES = [  # name, cin, cout, k, batch, H, W
     ('shrink 3x3 512->1 @30x54 x1', 512, 1, 3, 1, 30, 54),
     ('pred 3x3 256->1 @120x216 x5', 256, 1, 3, 5, 120, 216),
     ('res 1x1 256->1024 @30x54 x1', 256, 1024, 1, 1, 30, 54),
+    ('res 1x1 512->128 @60x108 x1', 512, 128, 1, 1, 60, 108),
+    ('res 1x1 128->512 @60x108 x1', 128, 512, 1, 1, 60, 108),
+    ('res 1x1 64->256 @120x216 x1', 64, 256, 1, 1, 120, 216),
+    ('res 3x3 64->64 @120x216 x1', 64, 64, 3, 1, 120, 216),
+    ('res 3x3 128->128 @60x108 x1', 128, 128, 3, 1, 60, 108),
 ]
 
 
@@ -36,6 +41,9 @@ def main():
     iters = int(os.environ.get('ITERS', 5))
     only = os.environ.get('ONLY')
     dev = torch.device('cuda:0')
+    if os.environ.get('NOSPLIT'):  # A/B: no split-K workspace
+        tiny = torch.zeros(1, device=dev)
+        ops._workspace = lambda device: tiny
     g = torch.Generator().manual_seed(0)
     for name, cin, cout, k, b, h, w in SHAPES:
         if only and only not in name:
