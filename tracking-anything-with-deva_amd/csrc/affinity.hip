@@ -282,14 +282,6 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
     DEVA_COMPILER_FENCE();
     prefetch(tile_at(min(it + 1, n_my - 1)));
 
-    float a_sq[CK / 2];
-#pragma unroll
-    for (int t = 0; t < CK / 2; t += 2) {
-      const f32x2 a2 = {a_op[t], a_op[t + 1]};
-      const f32x2 s2 = a2 * a2;
-      a_sq[t] = s2[0];
-      a_sq[t + 1] = s2[1];
-    }
     f32x16 accA, accB;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -298,8 +290,9 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
     }
 #pragma unroll
     for (int t = 0; t < CK / 2; ++t) {
-      accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a_sq[t], bqe[t], accA, 0, 0, 0);
-      accB = __builtin_amdgcn_mfma_f32_32x32x2f32(a_op[t], bqk[t], accB, 0, 0, 0);
+      const float a = a_op[t];
+      accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a * a, bqe[t], accA, 0, 0, 0);
+      accB = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bqk[t], accB, 0, 0, 0);
     }
 
     // ---- scores of this lane: query l31, tokens n_base + (r&3) + 8*(r>>2) + 4*half, two accumulator
