@@ -223,6 +223,15 @@ def gen_api_surface():
                              for p in sig.parameters.values()]
         props = [n for n, v in inspect.getmembers(cls) if isinstance(v, property)]
         out[cls.__name__] = dict(methods=methods, properties=props)
+    # command-line surface of the evaluation drivers (eval_args.py:7-43)
+    from argparse import ArgumentParser
+    from deva.inference.eval_args import add_common_eval_args
+    parser = ArgumentParser()
+    add_common_eval_args(parser)
+    out['eval_args'] = {a.dest: dict(flags=a.option_strings, default=a.default, nargs=a.nargs,
+                                     type=None if a.type is None else a.type.__name__,
+                                     switch=type(a).__name__ == '_StoreTrueAction')
+                        for a in parser._actions if a.dest != 'help'}
     with open(os.path.join(HERE, 'api_surface.json'), 'w') as f:
         json.dump(out, f, indent=1, sort_keys=True)
 

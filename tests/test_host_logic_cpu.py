@@ -237,6 +237,16 @@ def test_api_surface_matches_reference(golden_dir):
     mine = {c.__name__: c for c in (DEVA, DEVAInferenceCore, MemoryManager, KeyValueMemoryStore, ObjectManager,
                                     ObjectInfo, ImageFeatureStore)}
     problems = []
+    # command-line flags the unchanged drivers parse (names, defaults, types, switches)
+    from argparse import ArgumentParser
+    from deva.inference.eval_args import add_common_eval_args
+    parser = ArgumentParser()
+    add_common_eval_args(parser)
+    got_args = {a.dest: dict(flags=a.option_strings, default=a.default, nargs=a.nargs,
+                             type=None if a.type is None else a.type.__name__,
+                             switch=type(a).__name__ == '_StoreTrueAction')
+                for a in parser._actions if a.dest != 'help'}
+    assert got_args == ref.pop('eval_args')
     for cname, spec in ref.items():
         cls = mine[cname]
         for prop in spec['properties']:

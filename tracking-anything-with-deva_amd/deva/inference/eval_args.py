@@ -1,50 +1,56 @@
-"""Common evaluation flags and model construction (interface of deva/inference/eval_args.py:7-71)."""
+"""Command-line surface shared by the evaluation drivers and construction of the HIP network
+(interface of deva/inference/eval_args.py:7-71: `add_common_eval_args`, `get_model_and_config`).
+
+The flags are data here: one table row per flag (name, type or None for a switch, default, help),
+so that the surface the drivers rely on can be read -- and checked against the reference -- at a
+glance."""
 from argparse import ArgumentParser
+from typing import Dict, Tuple
 
 import torch
 
-from deva.model.network import DEVA
+# (flag, type | None = store_true switch, default, help)
+_FLAGS = (
+    ('model', str, './saves/DEVA-propagation.pth', 'checkpoint with the 420 propagation tensors'),
+    ('output', str, None, 'where the driver writes its results'),
+    ('save_all', None, False, 'Save all frames'),
+    ('amp', None, False, 'accepted for compatibility; the HIP path always computes in fp32'),
+    # network widths (C^k, C^v, pixel feature)
+    ('key_dim', int, 64, None),
+    ('value_dim', int, 512, None),
+    ('pix_feat_dim', int, 512, None),
+    # memory schedule (XMem notation)
+    ('disable_long_term', None, False, 'working memory only'),
+    ('max_mid_term_frames', int, 10, 'T_max in XMem, decrease to save memory'),
+    ('min_mid_term_frames', int, 5, 'T_min in XMem, decrease to save memory'),
+    ('max_long_term_elements', int, 10000, 'LT_max in XMem, increase if objects disappear for a long time'),
+    ('num_prototypes', int, 128, 'P in XMem'),
+    ('top_k', int, 30, 'memory tokens in the softmax support of a query'),
+    ('mem_every', int, 5, 'r in XMem. Increase to improve running speed.'),
+    ('chunk_size', int, -1, 'Number of objects to process in parallel as a batch; -1 for unlimited. '
+                            'Set to a small number to save memory.'),
+    ('size', int, 480, 'Resize the shorter side to this size. -1 to use original resolution. '),
+)
 
 
-def add_common_eval_args(parser: ArgumentParser):
-    parser.add_argument('--model', default='./saves/DEVA-propagation.pth')
-    parser.add_argument('--output', default=None)
-    parser.add_argument('--save_all', action='store_true', help='Save all frames')
-    parser.add_argument('--amp', action='store_true')
-
-    # model dimensions
-    parser.add_argument('--key_dim', type=int, default=64)
-    parser.add_argument('--value_dim', type=int, default=512)
-    parser.add_argument('--pix_feat_dim', type=int, default=512)
-
-    # long-term memory
-    parser.add_argument('--disable_long_term', action='store_true')
-    parser.add_argument('--max_mid_term_frames', type=int, default=10,
-                        help='T_max in XMem, decrease to save memory')
-    parser.add_argument('--min_mid_term_frames', type=int, default=5,
-                        help='T_min in XMem, decrease to save memory')
-    parser.add_argument('--max_long_term_elements', type=int, default=10000,
-                        help='LT_max in XMem, increase if objects disappear for a long time')
-    parser.add_argument('--num_prototypes', type=int, default=128, help='P in XMem')
-
-    parser.add_argument('--top_k', type=int, default=30)
-    parser.add_argument('--mem_every', type=int, default=5,
-                        help='r in XMem. Increase to improve running speed.')
-    parser.add_argument('--chunk_size', type=int, default=-1,
-                        help='Number of objects to process in parallel as a batch; -1 for unlimited. '
-                        'Set to a small number to save memory.')
-    parser.add_argument('--size', type=int, default=480,
-                        help='Resize the shorter side to this size. -1 to use original resolution. ')
+def add_common_eval_args(parser: ArgumentParser) -> None:
+    for flag, kind, default, doc in _FLAGS:
+        if kind is None:
+            parser.add_argument(f'--{flag}', action='store_true', help=doc)
+        elif kind is str:
+            parser.add_argument(f'--{flag}', default=default, help=doc)
+        else:
+            parser.add_argument(f'--{flag}', type=kind, default=default, help=doc)
 
 
-def get_model_and_config(parser: ArgumentParser):
+def get_model_and_config(parser: ArgumentParser) -> Tuple['torch.nn.Module', Dict, object]:
+    """-> (network on the current HIP device in eval mode, config dict, parsed args)"""
+    from deva.model.network import DEVA
     args = parser.parse_args()
-    config = vars(args)
-    config['enable_long_term'] = not config['disable_long_term']
-
+    config = dict(vars(args), enable_long_term=not args.disable_long_term)
     network = DEVA(config).cuda().eval()
-    if args.model is not None:
-        network.load_weights(torch.load(args.model))
-    else:
+    if args.model is None:
         print('No model loaded.')
+    else:
+        network.load_weights(torch.load(args.model))
     return network, config, args

@@ -1,33 +1,47 @@
-"""Per-frame image feature cache (interface of deva/inference/image_feature_store.py:7-48)."""
+"""Per-frame cache of everything the key encoder produces (interface of
+deva/inference/image_feature_store.py:7-48).
+
+Several consumers of one frame -- the propagation step, the spatial alignments of a voting window,
+the external processors -- ask for its multi-scale features and its key / shrinkage / selection;
+the encoder runs on the first request only.  Entries live until `delete(index)`; a store that dies
+non-empty warns, like the reference, because every entry pins ~100 MB of activations at 1080p."""
 import warnings
-from typing import Iterable, Tuple
+from typing import Dict, Iterable, NamedTuple, Tuple
 
 import torch
 
 
-class ImageFeatureStore:
-    """Caches (multi-scale features, key feature, key, shrinkage, selection) per frame index so the
-    encoder runs once per frame even when several consumers need it.  Callers must `delete`."""
+class _FrameFeatures(NamedTuple):
+    ms_features: Iterable[torch.Tensor]  # f16, f8, f4
+    pix_feat: torch.Tensor
+    key: torch.Tensor
+    shrinkage: torch.Tensor
+    selection: torch.Tensor
 
+
+class ImageFeatureStore:
     def __init__(self, network, no_warning: bool = False):
         self.network = network
-        self._store = {}
         self.no_warning = no_warning
+        self._store: Dict[int, _FrameFeatures] = {}
 
     def _encode_feature(self, index: int, image: torch.Tensor) -> None:
-        ms_features, feat = self.network.encode_image(image)
-        key, shrinkage, selection = self.network.transform_key(feat)
-        self._store[index] = (ms_features, feat, key, shrinkage, selection)
+        multi_scale, pix_feat = self.network.encode_image(image)
+        self._store[index] = _FrameFeatures(multi_scale, pix_feat, *self.network.transform_key(pix_feat))
+
+    def _entry(self, index: int, image: torch.Tensor) -> _FrameFeatures:
+        try:
+            return self._store[index]
+        except KeyError:
+            self._encode_feature(index, image)
+            return self._store[index]
 
     def get_ms_features(self, index, image) -> Iterable[torch.Tensor]:
-        if index not in self._store:
-            self._encode_feature(index, image)
-        return self._store[index][0]
+        return self._entry(index, image).ms_features
 
     def get_key(self, index, image) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-        if index not in self._store:
-            self._encode_feature(index, image)
-        return self._store[index][2:]
+        e = self._entry(index, image)
+        return e.key, e.shrinkage, e.selection
 
     def delete(self, index) -> None:
         self._store.pop(index, None)
@@ -36,5 +50,5 @@ class ImageFeatureStore:
         return len(self._store)
 
     def __del__(self):
-        if len(self._store) > 0 and not self.no_warning:
+        if self._store and not self.no_warning:
             warnings.warn(f'Leaking {self._store.keys()} in the image feature store')
