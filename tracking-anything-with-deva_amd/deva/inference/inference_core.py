@@ -104,101 +104,97 @@ class DEVAInferenceCore:
             self.image_feature_store.delete(f.ti)
         self.frame_buffer = []
 
+    # ------------------------------------------------------------------ shared frame plumbing
+    def _begin_frame(self, image: torch.Tensor, image_ti_override):
+        """advance the clock, pad the frame to a multiple of 16 and fetch (or compute) its features:
+        -> (frame index used for the feature cache, 1*3*H'*W' image, ms_features, key, shrinkage, selection)"""
+        self.curr_ti += 1
+        frame_ti = image_ti_override if image_ti_override is not None else self.curr_ti
+        padded, self.pad = pad_divide_by(image, 16)
+        batch = padded.unsqueeze(0)
+        store = self.image_feature_store
+        return (frame_ti, batch, store.get_ms_features(frame_ti, batch), *store.get_key(frame_ti, batch))
+
     # ------------------------------------------------------------------ detections
     def incorporate_detection(self, image: torch.Tensor, new_mask: torch.Tensor,
                               segments_info: List[ObjectInfo], *, image_ti_override: bool = None,
                               forward_mask: torch.Tensor = None, incremental: bool = False) -> torch.Tensor:
-        """merge an image-level detection into the propagated state (inference_core.py:137-198)"""
+        """merge an image-level detection into the propagated state (inference_core.py:137-198):
+        propagate (unless the caller did), match detected segments with tracked objects by IoU, retire
+        objects that went unseen for too long, and commit the merged masks as a memory frame"""
         from deva.inference.segment_merging import match_and_merge
-        self.curr_ti += 1
-        image_ti = self.curr_ti if image_ti_override is None else image_ti_override
-
-        image, self.pad = pad_divide_by(image, 16)
+        frame_ti, batch, ms_features, key, shrinkage, selection = self._begin_frame(image, image_ti_override)
         new_mask, _ = pad_divide_by(new_mask, 16)
-        image = image.unsqueeze(0)
-        ms_features = self.image_feature_store.get_ms_features(image_ti, image)
-        key, shrinkage, selection = self.image_feature_store.get_key(image_ti, image)
 
         if forward_mask is None:
-            if self.memory.engaged:
-                forward_mask = torch.argmax(self._segment(key, selection, ms_features), dim=0)
-            else:
-                forward_mask = torch.zeros_like(new_mask)
+            forward_mask = (torch.argmax(self._segment(key, selection, ms_features), dim=0)
+                            if self.memory.engaged else torch.zeros_like(new_mask))
 
-        merged_mask = match_and_merge(forward_mask, new_mask, self.object_manager, segments_info,
-                                      max_num_objects=self.max_num_objects, incremental_mode=incremental)
-        purged, tmp_keep_idx, obj_keep_idx = self.object_manager.purge_inactive_objects(
+        merged = match_and_merge(forward_mask, new_mask, self.object_manager, segments_info,
+                                 max_num_objects=self.max_num_objects, incremental_mode=incremental)
+        anything_purged, tmp_kept, obj_kept = self.object_manager.purge_inactive_objects(
             self.max_missed_detection_count)
-        if purged:
-            self.memory.purge_except(obj_keep_idx)
-            merged_mask = merged_mask[[i - 1 for i in tmp_keep_idx]]
+        if anything_purged:
+            self.memory.purge_except(obj_kept)
+            merged = merged[[t - 1 for t in tmp_kept]]  # tmp ids are 1-based channel numbers
 
-        self.last_mask = merged_mask.unsqueeze(0).type_as(key)
-        self._add_memory(image, ms_features, self.last_mask, key, shrinkage, selection)
-        pred_prob_with_bg = self.network.aggregate(self.last_mask[0], dim=0)
-        self.image_feature_store.delete(image_ti)
-        return unpad(pred_prob_with_bg, self.pad)
+        self.last_mask = merged.unsqueeze(0).type_as(key)
+        self._add_memory(batch, ms_features, self.last_mask, key, shrinkage, selection)
+        self.image_feature_store.delete(frame_ti)
+        return unpad(self.network.aggregate(self.last_mask[0], dim=0), self.pad)
 
     # ------------------------------------------------------------------ propagation
+    def _blend_annotation(self, prediction: torch.Tensor, mask: torch.Tensor, objects: List[int],
+                          new_tmp_ids: List[int], hard_mask: bool) -> torch.Tensor:
+        """an annotation that covers only some objects on top of the propagated prediction
+        ((no+1)*H*W): annotated pixels win, channels of newly introduced objects are appended
+        (inference_core.py:251-272, including its channel indexing)"""
+        fg = prediction[1:]
+        annotated = (mask > 0) if hard_mask else (mask.max(0) > 0.5)
+        fg[:, annotated] = 0
+        appended = []
+        for pos, tmp_id in enumerate(new_tmp_ids):
+            channel = (mask == objects[pos]).type_as(fg) if hard_mask else mask[tmp_id]
+            if tmp_id < fg.shape[0]:
+                fg[tmp_id + 1] = channel
+            else:
+                appended.append(channel.unsqueeze(0))
+        return torch.cat([fg, *appended], dim=0)
+
     def step(self, image: torch.Tensor, mask: torch.Tensor = None, objects: Optional[List[int]] = None, *,
              hard_mask: bool = True, end: bool = False, image_ti_override: bool = None,
              delete_buffer: bool = True) -> torch.Tensor:
-        """
-        image: 3*H*W (ImageNet-normalised)
-        mask: H*W index mask, or len(objects)*H*W soft masks (hard_mask=False), or None
-        objects: object ids in mask order; None (soft masks only) means 1..mask.shape[0]
-        end: last frame of the sequence -- skip memory/sensory updates
-        returns (num_objects+1)*H*W probabilities, channel 0 = background  (inference_core.py:200-290)
-        """
-        if objects is None and mask is not None:
+        """One frame (inference_core.py:200-290).
+
+        image: 3*H*W, ImageNet-normalised.  mask: H*W index mask, or len(objects)*H*W soft masks with
+        hard_mask=False, or None to propagate only.  objects: ids in mask order (None with soft masks
+        means 1..mask.shape[0]).  end: last frame of the sequence -- nothing is written to the memories.
+        Returns (num_objects+1)*H*W probabilities at the input size, channel 0 = background."""
+        annotated = mask is not None
+        if annotated and objects is None:
             assert not hard_mask
             objects = list(range(1, mask.shape[0] + 1))
 
-        self.curr_ti += 1
-        image_ti = self.curr_ti if image_ti_override is None else image_ti_override
+        frame_ti, batch, ms_features, key, shrinkage, selection = self._begin_frame(image, image_ti_override)
+        due = self.curr_ti - self.last_mem_ti >= self.mem_every
+        commit = (annotated or due) and not end
+        # propagate unless the annotation covers every object known so far
+        om = self.object_manager
+        propagate = (not annotated) or (om.num_obj > 0 and not om.has_all(objects))
 
-        image, self.pad = pad_divide_by(image, 16)
-        image = image.unsqueeze(0)
-
-        is_mem_frame = ((self.curr_ti - self.last_mem_ti >= self.mem_every) or (mask is not None)) and (not end)
-        # segment when no mask is given, or when the given mask does not cover every known object
-        need_segment = (mask is None) or (not self.object_manager.has_all(objects)
-                                          and self.object_manager.num_obj > 0)
-
-        ms_features = self.image_feature_store.get_ms_features(image_ti, image)
-        key, shrinkage, selection = self.image_feature_store.get_key(image_ti, image)
-
-        if need_segment:
-            pred_prob_with_bg = self._segment(key, selection, ms_features, update_sensory=not end)
-
-        if mask is not None:
-            new_tmp_ids, _ = self.object_manager.add_new_objects(objects)
+        prob = self._segment(key, selection, ms_features, update_sensory=not end) if propagate else None
+        if annotated:
+            new_tmp_ids, _ = om.add_new_objects(objects)
             mask, _ = pad_divide_by(mask, 16)
-            if need_segment:
-                # merge the prediction with the (partial) input mask; input pixels win
-                fg = pred_prob_with_bg[1:]
-                if hard_mask:
-                    fg[:, mask > 0] = 0
-                else:
-                    fg[:, mask.max(0) > 0.5] = 0
-                extra = []
-                for mask_id, tmp_id in enumerate(new_tmp_ids):
-                    this_mask = (mask == objects[mask_id]).type_as(fg) if hard_mask else mask[tmp_id]
-                    if tmp_id >= fg.shape[0]:
-                        extra.append(this_mask.unsqueeze(0))
-                    else:
-                        fg[tmp_id + 1] = this_mask  # reference indexing (inference_core.py:268-270)
-                mask = torch.cat([fg, *extra], dim=0)
+            if propagate:
+                mask = self._blend_annotation(prob, mask, objects, new_tmp_ids, hard_mask)
             elif hard_mask:
-                mask = torch.stack([mask == obj for obj in objects], dim=0)  # index mask -> one-hot
-            pred_prob_with_bg = ops.softmax_channels(self.network.aggregate(mask, dim=0))
+                mask = torch.stack([mask == o for o in objects], dim=0)  # index mask -> one-hot
+            prob = ops.softmax_channels(self.network.aggregate(mask, dim=0))
 
-        self.last_mask = pred_prob_with_bg[1:].unsqueeze(0)
-
-        if is_mem_frame:
-            self._add_memory(image, ms_features, self.last_mask, key, shrinkage, selection)
-
+        self.last_mask = prob[1:].unsqueeze(0)
+        if commit:
+            self._add_memory(batch, ms_features, self.last_mask, key, shrinkage, selection)
         if delete_buffer:
-            self.image_feature_store.delete(image_ti)
-
-        return unpad(pred_prob_with_bg, self.pad)
+            self.image_feature_store.delete(frame_ti)
+        return unpad(prob, self.pad)
