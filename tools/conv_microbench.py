@@ -34,6 +34,8 @@ SHAPES = [  # name, cin, cout, k, batch, H, W
     ('res 1x1 64->256 @120x216 x1', 64, 256, 1, 1, 120, 216),
     ('res 3x3 64->64 @120x216 x1', 64, 64, 3, 1, 120, 216),
     ('res 3x3 128->128 @60x108 x1', 128, 128, 3, 1, 60, 108),
+    ('stem 7x7s2 3->64 @480x864 x1', 3, 64, 7, 1, 480, 864),
+    ('stem 7x7s2 4->64 @480x864 x5', 4, 64, 7, 5, 480, 864),
 ]
 
 
@@ -54,16 +56,17 @@ def main():
         x.copy_(torch.randn(b, cin, h, w, generator=g))
         if os.environ.get('UNGUARDED'):
             x = x.clone()
-        out = ops.conv2d(pc, x, pad=k // 2)
+        stride = 2 if name.startswith('stem') else 1
+        out = ops.conv2d(pc, x, pad=k // 2, stride=stride)
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         for _ in range(iters):
-            ops.conv2d(pc, x, pad=k // 2, out=out)
+            ops.conv2d(pc, x, pad=k // 2, stride=stride, out=out)
         e.record()
         torch.cuda.synchronize()
         ms = s.elapsed_time(e) / iters
-        fl = 2.0 * cin * cout * k * k * b * h * w
+        fl = 2.0 * cin * cout * k * k * b * (h // stride) * (w // stride)
         print(f'{name:40s} {ms * 1e3:9.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s  ({fl / 1e9:.1f} GF)')
 
 

@@ -98,6 +98,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
   constexpr int BNP = ROW ? BN + 8 : BN;  // ROW: columns 3 .. BN+4 hold pixels n0-1 .. n0+BN
   static_assert(ROW == 0 || (VEC == 1 && MODE == 1 && TN == 1), "row reuse builds on the vector gather");
   __shared__ __attribute__((aligned(16))) float Bs[2][BK][BNP];
+  constexpr int KTAB = 1024;  // MODE 2: k -> (channel | dy << 16 | dx << 24)
+  __shared__ unsigned s_ktab[MODE == 2 ? KTAB : 1];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -106,6 +108,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
   const int wn0 = (wave % WAVES_N) * WN;
   const int l31 = lane & 31;
   const int half = lane >> 5;
+  const bool ktab_ok = MODE == 2 && p.K <= KTAB && p.ctot < 65536 && p.KH < 256 && p.KW < 256;
+  if (MODE == 2 && ktab_ok) {
+    for (int k = tid; k < p.K; k += THREADS) {
+      const int tap = k / p.ctot;
+      const int dy = tap / p.KW;
+      s_ktab[k] = (unsigned)(k - tap * p.ctot) | ((unsigned)dy << 16) | ((unsigned)(tap - dy * p.KW) << 24);
+    }
+    __syncthreads();
+  }
 
   // Tile order: cout tiles fastest (the workgroups sharing one pixel tile run together), and an
   // XCD-aware remap -- hardware places workgroup b on XCD b % 8, so XCD x gets a CONTIGUOUS range
@@ -309,12 +320,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
   auto stage_b = [&](int i) {
     const int ci = bk_group + i * KG;  // row within this K step
     if (MODE == 2) {
-      // generic per-element decode of k -> (tap, channel, source): 2/3/4-channel stems, odd splits
+      // generic per-element decode of k -> (tap, channel, source): 2/3/4-channel stems, odd splits.
+      // The two integer divisions come from a table built once per workgroup (the staging of these
+      // layers is VALU-bound); layers with more than KTAB k values divide.
       const int k = st_k0 + ci;
-      const int tap = k / p.ctot;
-      const int c = k - tap * p.ctot;
-      const int dy = tap / p.KW;
-      const int ih = ih0 + dy, iw = iw0 + (tap - dy * p.KW);
+      int c, dy, dx;
+      if (ktab_ok) {
+        const unsigned e = s_ktab[min(k, KTAB - 1)];
+        c = (int)(e & 0xffffu);
+        dy = (int)((e >> 16) & 0xffu);
+        dx = (int)(e >> 24);
+      } else {
+        const int tap = k / p.ctot;
+        c = k - tap * p.ctot;
+        dy = tap / p.KW;
+        dx = tap - dy * p.KW;
+      }
+      const int ih = ih0 + dy, iw = iw0 + dx;
       const bool ok = n_ok && (k < p.K) && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
       const bool first = ok ? (c < p.c0) : true;
       const float* sp = first ? src0 : src1;
