@@ -361,6 +361,14 @@ def main():
                 'mfma_util': d['mfma_util_frac'], 'l2_hit_rate': d['l2_hit_rate'],
                 'clock_adjusted_peak_tflops': d['clock_adjusted_peak_tflops']}
         result['affinity'] = affinity_microbench(device)
+        pmc_aff = os.path.join(ROOT, 'profiles', 'pmc_r01', 'affinity_per_launch.json')
+        if os.path.exists(pmc_aff):
+            with open(pmc_aff) as f:
+                d = json.load(f)['10k']
+            result['affinity']['pmc'] = {'source': 'profiles/pmc_r01/affinity_per_launch.json', 'mfma_util': d['mfma_util_frac'],
+                                         'valu_instructions_per_tile': d['per_wave_per_tile']['SQ_INSTS_VALU'],
+                                         'mfma_instructions_per_tile': d['per_wave_per_tile']['SQ_INSTS_MFMA'],
+                                         'l2_hit_rate': d['l2_hit_rate']}
         if not args.no_extra:
             cfg_lt = synth.base_config()
             f1080 = make_clip(1080, 1920, 12, seed=7, device=device)

@@ -202,6 +202,12 @@ def gen_alignment(net):
                os.path.join(HERE, 'alignment.pt'))
 
 
+def gen_edge(net):
+    out = scenarios.run_edge_cases(lambda cfg: DEVAInferenceCore(net, cfg))
+    torch.save(out, os.path.join(HERE, 'edge_cases.pt'))
+    print({k: (tuple(v.shape), float(v.float().max())) for k, v in out.items()})
+
+
 def gen_api_surface():
     """public methods (name -> parameter list with defaults) of the classes on the drop-in boundary,
     read off the reference with inspect"""
@@ -238,6 +244,10 @@ def gen_api_surface():
 
 if __name__ == '__main__':
     only = os.environ.get('ONLY')
+    if only == 'edge':
+        net, _, _ = build_reference(synth.base_config())
+        gen_edge(net)
+        sys.exit(0)
     if only == 'api':
         gen_api_surface()
         sys.exit(0)
@@ -255,6 +265,7 @@ if __name__ == '__main__':
     gen_merge()
     gen_detection_e2e(net)
     gen_alignment(net)
+    gen_edge(net)
     gen_api_surface()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -147,3 +147,60 @@ def alignment_inputs(sc):
         m[1, 40:90, 70 - 2 * t:120 - 2 * t] = 0.8
         masks.append(m)
     return frames, masks
+
+
+# ---------------------------------------------------------------------------------------------
+# API edge paths of DEVAInferenceCore (inference_core.py:55-113,137-290): warnings instead of
+# exceptions, soft-mask annotation, feature-cache control, detection rounds without segments
+EDGE = dict(H=80, W=112)
+
+
+def run_edge_cases(make_core, device='cpu'):
+    """Returns {name: tensor or list} of everything observable; identical calls are made on the
+    reference (golden generator), on the package with emulated ops (CPU) and on the GPU."""
+    import warnings
+    H, W = EDGE['H'], EDGE['W']
+    stream = synth.FrameStream(H, W, seed=21)
+    frames = [stream.next().to(device) for _ in range(6)]
+    out = {}
+
+    # 1. propagating before anything was annotated: a RuntimeWarning and an all-zero 1*H*W map
+    core = make_core(synth.base_config())
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        p = core.step(frames[0])
+    out['no_memory_prob'] = p.detach().float().cpu()
+    out['no_memory_warned'] = torch.tensor(float(any(issubclass(x.category, RuntimeWarning) for x in w)))
+
+    # 2. soft (probability) masks, objects implied by the channel order; last frame with end=True
+    core = make_core(synth.base_config(mem_every=2))
+    soft = torch.zeros(2, H, W)
+    soft[0, 8:40, 10:60] = 0.85
+    soft[1, 30:70, 50:100] = 0.7
+    seq = [core.step(frames[0], soft.to(device), hard_mask=False)]
+    seq += [core.step(frames[t]) for t in (1, 2, 3)]
+    seq.append(core.step(frames[4], end=True))
+    out['soft_seq'] = torch.stack([s.detach().float().cpu() for s in seq])
+    out['soft_ids'] = torch.tensor(core.object_manager.all_obj_ids)
+    out['soft_work_size'] = torch.tensor(core.memory.work_mem.size(0))
+
+    # 3. feature-cache control: an overridden cache index survives the step when asked to
+    core = make_core(synth.base_config())
+    m = synth.box_mask(H, W, 2).to(device)
+    core.step(frames[0], m, [1, 2], image_ti_override=77, delete_buffer=False)
+    out['cache_len_kept'] = torch.tensor(len(core.image_feature_store))
+    core.image_feature_store.delete(77)
+    out['cache_len_after_delete'] = torch.tensor(len(core.image_feature_store))
+    core.step(frames[1])
+    out['cache_len_default'] = torch.tensor(len(core.image_feature_store))
+
+    # 4. a detection round without any segment on an empty tracker: "Empty object mask!" and a
+    # background-only answer; the tracker stays empty
+    core = make_core(synth.base_config(max_missed_detection_count=1, max_num_objects=-1))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        p = core.incorporate_detection(frames[0], torch.zeros(H, W, dtype=torch.long, device=device), [])
+    out['empty_detection_prob'] = p.detach().float().cpu()
+    out['empty_detection_warned'] = torch.tensor(float(any('Empty object mask' in str(x.message) for x in w)))
+    out['empty_detection_objects'] = torch.tensor(core.object_manager.num_obj)
+    return out

@@ -259,3 +259,14 @@ def test_spatial_alignment_against_reference_golden(network, golden_dir):
     err = max_err(out, g['aligned'])
     print(f'spatial_alignment max abs err {err:.3e}')
     assert out.shape == g['aligned'].shape and err <= 1e-3
+
+
+def test_edge_paths_against_reference_golden(network, golden_dir):
+    """API edge paths (no memory yet, soft masks, cache control, empty detection round)"""
+    from deva.inference.inference_core import DEVAInferenceCore
+    got = scenarios.run_edge_cases(lambda cfg: DEVAInferenceCore(network, cfg), device=dev())
+    g = torch.load(os.path.join(golden_dir, 'edge_cases.pt'))
+    assert got.keys() == g.keys()
+    for k in g:
+        assert got[k].shape == g[k].shape, k
+        assert max_err(got[k].float(), g[k].float()) <= 1e-3 * max(1.0, g[k].float().abs().max().item()), k

@@ -265,3 +265,19 @@ def test_api_surface_matches_reference(golden_dir):
             if core != params:
                 problems.append(f'{cname}.{mname}: {core} != {params}')
     assert not problems, '\\n'.join(problems)
+
+
+def _check_edge_cases(got, g, tol):
+    assert got.keys() == g.keys()
+    for k in g:
+        assert got[k].shape == g[k].shape, k
+        assert (got[k].float() - g[k].float()).abs().max().item() <= tol * max(1.0, g[k].float().abs().max().item()), k
+
+
+def test_edge_paths_match_reference(emu, golden_dir, recipe_state_dict):
+    """warnings instead of exceptions, soft-mask annotation, feature-cache control, a detection round
+    without segments: same observable behaviour as the reference (tests/scenarios.py:run_edge_cases)"""
+    from deva.inference.inference_core import DEVAInferenceCore
+    net = _network(recipe_state_dict)
+    got = scenarios.run_edge_cases(lambda cfg: DEVAInferenceCore(net, cfg))
+    _check_edge_cases(got, torch.load(os.path.join(golden_dir, 'edge_cases.pt')), 1e-3)
