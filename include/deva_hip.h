@@ -108,7 +108,8 @@ int deva_area_downsample(const float* in, float* out, int64_t planes, int height
 
 /* DEVA.aggregate (network.py:33-40) over `num` object planes of `pixels` each:
  * p = apply_sigmoid ? sigmoid(in) : in;  out[0] = logit(clamp(prod(1-p)));  out[i+1] = logit(clamp(p_i)).
- * in may be fp32 or (in_is_u8 != 0) uint8/bool one-hot planes (inference_core.py:273-277). */
+ * in may be fp32 or (in_is_u8 != 0) uint8/bool one-hot planes (inference_core.py:273-277).
+ * num == 0 (nothing tracked yet) is allowed, in may then be NULL: out is the background-only plane. */
 int deva_aggregate(const void* in, int in_is_u8, int apply_sigmoid, float* out, int num,
                    int64_t pixels, void* stream);
 

@@ -56,6 +56,12 @@ def test_aggregate_and_softmax(no):
     _check('softmax_channels', ops.softmax_channels(to_dev(agg)), emu_ops.softmax_channels(agg), 2e-6)
 
 
+def test_aggregate_without_objects():
+    """nothing tracked yet (empty detection round, inference_core.py:196): background-only logits"""
+    empty = torch.zeros(0, 24, 33)
+    _check('aggregate_empty', ops.aggregate(to_dev(empty)), emu_ops.aggregate(empty), 2e-6)
+
+
 @pytest.mark.parametrize('c,h,w', [(3, 6, 8), (6, 24, 32), (1, 1, 1), (2, 5, 3)])
 def test_upsample4x_softmax(c, h, w):
     x = rand(torch.Generator().manual_seed(5), c, h, w, scale=5.0)

@@ -324,7 +324,8 @@ extern "C" int deva_area_downsample(const float* in, float* out, int64_t planes,
 
 extern "C" int deva_aggregate(const void* in, int in_is_u8, int apply_sigmoid, float* out, int num,
                               int64_t pixels, void* stream) {
-  DEVA_REQUIRE(in && out && num >= 0 && pixels > 0, "deva_aggregate: bad args");
+  // num == 0 (no object yet, inference_core.py:67-70 / :196) yields the background-only map; `in` may be NULL then
+  DEVA_REQUIRE((in || num == 0) && out && num >= 0 && pixels > 0, "deva_aggregate: bad args");
   if (in_is_u8) {
     hipLaunchKernelGGL(aggregate_kernel<true>, grid_for(pixels), dim3(TPB), 0, (hipStream_t)stream, in,
                        apply_sigmoid, out, num, pixels);

@@ -213,9 +213,14 @@ def area_downsample(x: torch.Tensor, factor: int) -> torch.Tensor:
 def aggregate(prob: torch.Tensor, apply_sigmoid: bool = False) -> torch.Tensor:
     """[no, ...] object probabilities (fp32, or uint8/bool one-hot) -> [no+1, ...] logits"""
     no = prob.shape[0]
-    pixels = prob.numel() // max(no, 1)
+    pixels = 1
+    for d in prob.shape[1:]:
+        pixels *= int(d)
     is_u8 = prob.dtype in (torch.uint8, torch.bool)
-    if is_u8:
+    if no == 0:  # nothing tracked yet: background-only logits
+        require_hip(prob.device, 'aggregate')
+        src = None
+    elif is_u8:
         src = _p(prob.view(torch.uint8) if prob.dtype == torch.bool else prob, torch.uint8, 'prob')
     else:
         src = _p(prob, name='prob')
