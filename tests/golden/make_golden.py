@@ -203,7 +203,8 @@ def gen_alignment(net):
 
 
 def gen_edge(net):
-    out = scenarios.run_edge_cases(lambda cfg: DEVAInferenceCore(net, cfg))
+    from deva.inference.object_info import ObjectInfo
+    out = scenarios.run_edge_cases(lambda cfg: DEVAInferenceCore(net, cfg), make_info=ObjectInfo)
     torch.save(out, os.path.join(HERE, 'edge_cases.pt'))
     print({k: (tuple(v.shape), float(v.float().max())) for k, v in out.items()})
 

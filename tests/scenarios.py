@@ -155,9 +155,10 @@ def alignment_inputs(sc):
 EDGE = dict(H=80, W=112)
 
 
-def run_edge_cases(make_core, device='cpu'):
+def run_edge_cases(make_core, device='cpu', make_info=None):
     """Returns {name: tensor or list} of everything observable; identical calls are made on the
-    reference (golden generator), on the package with emulated ops (CPU) and on the GPU."""
+    reference (golden generator), on the package with emulated ops (CPU) and on the GPU.
+    make_info(id=..., category_id=..., isthing=...) builds the implementation's ObjectInfo."""
     import warnings
     H, W = EDGE['H'], EDGE['W']
     stream = synth.FrameStream(H, W, seed=21)
@@ -203,4 +204,32 @@ def run_edge_cases(make_core, device='cpu'):
     out['empty_detection_prob'] = p.detach().float().cpu()
     out['empty_detection_warned'] = torch.tensor(float(any('Empty object mask' in str(x.message) for x in w)))
     out['empty_detection_objects'] = torch.tensor(core.object_manager.num_obj)
+
+    # 5. every tracked object disappears: two detected objects, then detection rounds that see nothing
+    # (max_missed_detection_count=1) until the tracker and its memories are empty; propagation
+    # afterwards is the "no memory" case again, and a new detection starts over
+    if make_info is not None:
+        core = make_core(synth.base_config(max_missed_detection_count=1, max_num_objects=-1, mem_every=2))
+        det = torch.zeros(H, W, dtype=torch.long)
+        det[10:40, 10:50] = 5
+        det[45:75, 60:105] = 9
+        info = lambda: [make_info(id=5, category_id=1, isthing=True), make_info(id=9, category_id=2, isthing=True)]
+        nothing = torch.zeros(H, W, dtype=torch.long, device=device)
+        seq, counts = [], []
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            seq.append(core.incorporate_detection(frames[0], det.to(device), info()))
+            counts.append(core.object_manager.num_obj)
+            seq.append(core.step(frames[1]))
+            for t in (2, 3, 4):
+                seq.append(core.incorporate_detection(frames[t], nothing, []))
+                counts.append(core.object_manager.num_obj)
+            engaged = core.memory.engaged
+            seq.append(core.step(frames[5]))
+            seq.append(core.incorporate_detection(frames[5], det.to(device), info()))
+            counts.append(core.object_manager.num_obj)
+        for i, p in enumerate(seq):
+            out[f'vanish_{i}'] = p.detach().float().cpu()
+        out['vanish_counts'] = torch.tensor(counts)
+        out['vanish_engaged_after_purge'] = torch.tensor(float(engaged))
     return out

@@ -264,7 +264,8 @@ def test_spatial_alignment_against_reference_golden(network, golden_dir):
 def test_edge_paths_against_reference_golden(network, golden_dir):
     """API edge paths (no memory yet, soft masks, cache control, empty detection round)"""
     from deva.inference.inference_core import DEVAInferenceCore
-    got = scenarios.run_edge_cases(lambda cfg: DEVAInferenceCore(network, cfg), device=dev())
+    from deva.inference.object_info import ObjectInfo
+    got = scenarios.run_edge_cases(lambda cfg: DEVAInferenceCore(network, cfg), device=dev(), make_info=ObjectInfo)
     g = torch.load(os.path.join(golden_dir, 'edge_cases.pt'))
     assert got.keys() == g.keys()
     for k in g:

@@ -279,5 +279,6 @@ def test_edge_paths_match_reference(emu, golden_dir, recipe_state_dict):
     without segments: same observable behaviour as the reference (tests/scenarios.py:run_edge_cases)"""
     from deva.inference.inference_core import DEVAInferenceCore
     net = _network(recipe_state_dict)
-    got = scenarios.run_edge_cases(lambda cfg: DEVAInferenceCore(net, cfg))
+    from deva.inference.object_info import ObjectInfo
+    got = scenarios.run_edge_cases(lambda cfg: DEVAInferenceCore(net, cfg), make_info=ObjectInfo)
     _check_edge_cases(got, torch.load(os.path.join(golden_dir, 'edge_cases.pt')), 1e-3)
