@@ -271,3 +271,17 @@ def test_edge_paths_against_reference_golden(network, golden_dir):
     for k in g:
         assert got[k].shape == g[k].shape, k
         assert max_err(got[k].float(), g[k].float()) <= 1e-3 * max(1.0, g[k].float().abs().max().item()), k
+
+
+def test_chunked_objects_clip_matches_unchunked(network):
+    """--chunk_size 2 with five objects (3 chunks, the last one ragged) through encode_mask / segment:
+    the same clip as the unchunked run up to fp32 summation-order noise (the split-K factor of a
+    layer depends on its batch)"""
+    from deva.inference.inference_core import DEVAInferenceCore
+    sc = dict(scenarios.E2E['five_obj'])
+    plain, _ = scenarios.run_scenario(lambda cfg: DEVAInferenceCore(network, cfg), sc, device=dev())
+    sc_chunked = dict(sc, cfg=dict(sc['cfg'], chunk_size=2))
+    chunked, _ = scenarios.run_scenario(lambda cfg: DEVAInferenceCore(network, cfg), sc_chunked, device=dev())
+    worst = max(max_err(a, b) for a, b in zip(chunked, plain))
+    print(f'chunk_size=2 vs unchunked: max abs prob difference {worst:.3e}')
+    assert worst <= 1e-3
