@@ -243,6 +243,12 @@ int deva_label_histogram(const int64_t* ours, const int64_t* news, const int64_t
  * instead of one masked assignment per object */
 int deva_lut_remap(const int64_t* in, const int64_t* lut, int n, int64_t pixels, int64_t* out,
                    void* stream);
+/* Output tail in one pass (evaluation/eval_vos.py:170-181 + result_utils.py:98-102 +
+ * object_manager.py:112-117): bilinear resize of the [channels][height][width] probabilities to
+ * (out_height, out_width) with F.interpolate(align_corners=False) arithmetic when the size differs,
+ * argmax over channels (first maximum), then out = lut ? lut[argmax] (0 beyond n_lut) : argmax. */
+int deva_index_mask(const float* prob, int channels, int height, int width, int out_height,
+                    int out_width, const int64_t* lut, int n_lut, int64_t* out, void* stream);
 int deva_merge_paint(const int64_t* ours, const int64_t* news, const int64_t* new_ids, int n_our,
                      int n_new, const int32_t* our_order, const int64_t* our_label,
                      const int32_t* new_order, const int64_t* new_label, const int64_t* out_ids,

@@ -244,6 +244,14 @@ def lut_remap(mask, lut):
     return torch.where(ok, lut[mask.clamp(0, lut.numel() - 1)], torch.zeros_like(mask))
 
 
+def index_mask(prob, size=None, lut=None):
+    import torch.nn.functional as F
+    if size is not None and tuple(size) != tuple(prob.shape[-2:]):
+        prob = F.interpolate(prob.unsqueeze(1), tuple(size), mode='bilinear', align_corners=False)[:, 0]
+    idx = torch.argmax(prob, dim=0)
+    return idx if lut is None else lut_remap(idx, lut)
+
+
 def install(monkeypatch):
     """patch every public op of deva.hip.ops with its emulation"""
     for name in real.__all__ + ['require_hip']:

@@ -121,3 +121,26 @@ def test_lut_remap_and_tmp_to_obj_cls():
     got = om.tmp_to_obj_cls(to_dev(mask))        # device path (deva_lut_remap)
     assert torch.equal(got.cpu(), want)
     assert set(want.unique().tolist()) <= {0, 7, 3, 250}
+
+
+@pytest.mark.parametrize('c,h,w,size', [(3, 40, 56, None), (6, 480, 864, (1080, 1920)), (2, 33, 47, (97, 61)),
+                                        (4, 96, 128, (48, 64)), (1, 8, 8, (20, 20))])
+def test_index_mask_resize_argmax_lut(c, h, w, size):
+    """fused output tail vs F.interpolate(bilinear, align_corners=False) -> argmax -> table on the CPU;
+    a differing label is tolerated only where the two best resized probabilities tie to 1e-6"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(c * 1000 + h)
+    prob = torch.softmax(torch.randn(c, h, w, generator=g) * 2, dim=0)
+    prob[:, :3, :5] = 1.0 / c  # exact ties: the first maximum must win
+    lut = torch.tensor([0] + [100 + 7 * i for i in range(1, c)], dtype=torch.int64)
+    got = ops.index_mask(to_dev(prob), size, to_dev(lut)).cpu()
+    res = prob if size is None else F.interpolate(prob.unsqueeze(1), size, mode='bilinear', align_corners=False)[:, 0]
+    want = lut[torch.argmax(res, dim=0)]
+    assert got.shape == want.shape and got.dtype == torch.int64
+    diff = got != want
+    if diff.any():
+        top2 = res.topk(min(2, c), dim=0)[0]
+        margin = (top2[0] - top2[-1])[diff]
+        assert margin.max().item() <= 1e-6, f'{int(diff.sum())} labels differ with a decisive margin'
+    if size is None:  # no table: plain argmax, ties -> channel 0
+        assert int(ops.index_mask(to_dev(prob)).cpu()[:3, :5].abs().sum()) == 0

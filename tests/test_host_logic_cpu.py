@@ -282,3 +282,16 @@ def test_edge_paths_match_reference(emu, golden_dir, recipe_state_dict):
     from deva.inference.object_info import ObjectInfo
     got = scenarios.run_edge_cases(lambda cfg: DEVAInferenceCore(net, cfg), make_info=ObjectInfo)
     _check_edge_cases(got, torch.load(os.path.join(golden_dir, 'edge_cases.pt')), 1e-3)
+
+
+def test_prob_to_obj_cls_equals_the_drivers_tail(emu):
+    """ObjectManager.prob_to_obj_cls == argmax -> tmp_to_obj_cls (and the resized variant)"""
+    import torch.nn.functional as F
+    from deva.inference.object_manager import ObjectManager
+    om = ObjectManager()
+    om.add_new_objects([7, 3, 12])
+    g = torch.Generator().manual_seed(2)
+    prob = torch.softmax(torch.randn(4, 30, 44, generator=g), dim=0)
+    assert torch.equal(om.prob_to_obj_cls(prob), om.tmp_to_obj_cls(torch.argmax(prob, dim=0)))
+    big = F.interpolate(prob.unsqueeze(1), (60, 90), mode='bilinear', align_corners=False)[:, 0]
+    assert torch.equal(om.prob_to_obj_cls(prob, (60, 90)), om.tmp_to_obj_cls(torch.argmax(big, dim=0)))

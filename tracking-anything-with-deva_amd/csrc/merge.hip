@@ -72,6 +72,52 @@ __global__ void lut_remap_kernel(const int64_t* __restrict__ in, const int64_t* 
   }
 }
 
+// Output tail (evaluation/eval_vos.py:170-181, result_utils.py:98-102, object_manager.py:112-117):
+// out[y][x] = lut[ argmax_c resize(prob)[c][y][x] ] in one pass -- F.interpolate(mode='bilinear',
+// align_corners=False) of every channel to (oh, ow) when the size differs, first-maximum argmax, and the
+// tmp-id -> object-id table.  The (no+1)*H*W fp32 probabilities never leave the device; the host
+// copies H*W labels.  Bilinear arithmetic follows ATen's upsample_bilinear2d: source coordinate
+// scale*(dst+0.5)-0.5 clamped at 0, neighbour index clamped at the border, rows blended after columns.
+__global__ void index_mask_kernel(const float* __restrict__ prob, int channels, int h, int w, int oh, int ow,
+                                  float scale_y, float scale_x, const int64_t* __restrict__ lut, int n_lut,
+                                  int64_t* __restrict__ out) {
+  const int64_t total = (int64_t)oh * ow;
+  const int64_t plane = (int64_t)h * w;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int y = (int)(i / ow), x = (int)(i - (int64_t)y * ow);
+    int best = 0;
+    if (oh == h && ow == w) {
+      float bv = prob[i];
+      for (int c = 1; c < channels; ++c) {
+        const float v = prob[(int64_t)c * plane + i];
+        if (v > bv) {
+          bv = v;
+          best = c;
+        }
+      }
+    } else {
+      const float sy = fmaxf(scale_y * ((float)y + 0.5f) - 0.5f, 0.0f);
+      const float sx = fmaxf(scale_x * ((float)x + 0.5f) - 0.5f, 0.0f);
+      const int y0 = min((int)sy, h - 1), x0 = min((int)sx, w - 1);
+      const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+      const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
+      const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+      float bv = -INFINITY;
+      for (int c = 0; c < channels; ++c) {
+        const float* pc = prob + (int64_t)c * plane;
+        const float top = lx0 * pc[(int64_t)y0 * w + x0] + lx1 * pc[(int64_t)y0 * w + x1];
+        const float bot = lx0 * pc[(int64_t)y1 * w + x0] + lx1 * pc[(int64_t)y1 * w + x1];
+        const float v = ly0 * top + ly1 * bot;
+        if (v > bv) {
+          bv = v;
+          best = c;
+        }
+      }
+    }
+    out[i] = lut ? ((best < n_lut) ? lut[best] : 0) : (int64_t)best;
+  }
+}
+
 }  // namespace
 }  // namespace deva
 
@@ -114,4 +160,19 @@ extern "C" int deva_merge_paint(const int64_t* ours, const int64_t* news, const 
   hipLaunchKernelGGL(merge_paint_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ours, news, new_ids,
                      n_our, n_new, our_order, our_label, new_order, new_label, out_ids, n_out, pixels, out);
   return check_launch("deva_merge_paint");
+}
+
+extern "C" int deva_index_mask(const float* prob, int channels, int height, int width, int out_height,
+                               int out_width, const int64_t* lut, int n_lut, int64_t* out, void* stream) {
+  using namespace deva;
+  DEVA_REQUIRE(prob && out && channels > 0 && height > 0 && width > 0 && out_height > 0 && out_width > 0,
+               "deva_index_mask: bad args");
+  DEVA_REQUIRE(!lut || n_lut > 0, "deva_index_mask: empty table");
+  const int64_t total = (int64_t)out_height * out_width;
+  int64_t blocks = ceil_div(total, 256);
+  if (blocks > 65535) blocks = 65535;
+  hipLaunchKernelGGL(index_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, prob, channels,
+                     height, width, out_height, out_width, (float)height / (float)out_height,
+                     (float)width / (float)out_width, lut, n_lut, out);
+  return check_launch("deva_index_mask");
 }

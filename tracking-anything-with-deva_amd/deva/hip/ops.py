@@ -17,7 +17,7 @@ __all__ = ['PackedConv', 'pack_conv', 'conv2d', 'maxpool3x3s2', 'upsample2x_add'
            'aggregate', 'softmax_channels', 'upsample4x_softmax', 'cbam', 'gru_update',
            'affinity_topk', 'usage_update', 'readout_sparse', 'bank_append', 'bank_gather_rows',
            'bank_export', 'rank', 'rank_select', 'evict_select', 'similarity_dense', 'softmax_columns',
-           'label_histogram', 'merge_paint', 'lut_remap',
+           'label_histogram', 'merge_paint', 'lut_remap', 'index_mask',
            'ACT_NONE', 'ACT_RELU', 'ACT_SIGMOID', 'ACT_SQUARE_PLUS_ONE']
 
 
@@ -421,4 +421,17 @@ def lut_remap(mask: torch.Tensor, lut: torch.Tensor) -> torch.Tensor:
     out = torch.empty_like(mask)
     check(lib().deva_lut_remap(_p(mask, torch.int64), _p(lut, torch.int64), lut.numel(), mask.numel(),
                                _p(out, torch.int64), _stream()), 'deva_lut_remap')
+    return out
+
+
+def index_mask(prob: torch.Tensor, size: Optional[Tuple[int, int]] = None,
+               lut: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[C,H,W] probabilities -> int64 [OH,OW] labels: bilinear resize to `size` (align_corners=False)
+    if it differs from (H,W), argmax over C, then lut[argmax] if a table is given"""
+    c, h, w = prob.shape
+    oh, ow = (h, w) if size is None else (int(size[0]), int(size[1]))
+    out = torch.empty((oh, ow), dtype=torch.int64, device=prob.device)
+    n = 0 if lut is None else lut.numel()
+    check(lib().deva_index_mask(_p(prob, name='prob'), c, h, w, oh, ow, _p(lut, torch.int64), n, _p(out, torch.int64),
+                                _stream()), 'deva_index_mask')
     return out

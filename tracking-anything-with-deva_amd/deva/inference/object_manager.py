@@ -69,16 +69,26 @@ class ObjectManager:
             self.delete_object(gone)
         return len(gone) > 0, tmp_keep, obj_keep
 
+    def _tmp_to_obj_table(self, device) -> torch.Tensor:
+        table = [0] * (max(self.tmp_id_to_obj, default=0) + 1)
+        for tmp_id, obj in self.tmp_id_to_obj.items():
+            table[tmp_id] = int(obj.id)
+        return torch.tensor(table, dtype=torch.int64, device=device)
+
+    def prob_to_obj_cls(self, prob: torch.Tensor, size=None) -> torch.Tensor:
+        """(no+1)*H*W probabilities of `DEVAInferenceCore.step` -> object-id index mask, optionally at
+        another resolution: the drivers' F.interpolate(bilinear) -> argmax -> tmp_to_obj_cls tail
+        (eval_vos.py:170-181, result_utils.py:98-102) as one kernel, so that H*W labels leave the
+        device instead of (no+1)*H*W floats (SURVEY.md 8f #3; not part of the reference's interface)"""
+        from deva.hip import ops
+        return ops.index_mask(prob.contiguous(), size, self._tmp_to_obj_table(prob.device))
+
     def tmp_to_obj_cls(self, mask) -> torch.Tensor:
         """tmp-id index mask -> object-id index mask"""
         if mask.is_cuda and mask.dtype == torch.int64 and self.tmp_id_to_obj:
             # one relabelling pass on the device instead of one masked assignment per object
             from deva.hip import ops
-            table = [0] * (max(self.tmp_id_to_obj) + 1)
-            for tmp_id, obj in self.tmp_id_to_obj.items():
-                table[tmp_id] = int(obj.id)
-            lut = torch.tensor(table, dtype=torch.int64, device=mask.device)
-            return ops.lut_remap(mask.contiguous(), lut)
+            return ops.lut_remap(mask.contiguous(), self._tmp_to_obj_table(mask.device))
         new_mask = torch.zeros_like(mask)  # host-side masks (e.g. in the result savers)
         for tmp_id, obj in self.tmp_id_to_obj.items():
             new_mask[mask == tmp_id] = obj.id
