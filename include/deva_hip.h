@@ -106,6 +106,15 @@ int deva_upsample2x_add(const float* in, const float* skip, float* out, int batc
 int deva_area_downsample(const float* in, float* out, int64_t planes, int height, int width,
                          int factor, void* stream);
 
+/* Input head in one pass: uint8 [height][width][3] frame (device memory) -> fp32 [3][out_height][out_width],
+ * (u/255 - mean)/std per channel and, when the size differs, the resize of the readers:
+ * antialias != 0: transforms.Resize(..., BILINEAR, antialias=True) (deva/inference/data/video_reader.py:139-144,
+ * detection_video_reader.py:63-71); antialias == 0: F.interpolate(bilinear, align_corners=False)
+ * (deva/inference/demo_utils.py:10-19).  mean3 / std3 are HOST pointers to three floats. */
+int deva_input_head(const unsigned char* image_hwc, int height, int width, const float* mean3,
+                    const float* std3, int antialias, float* out, int out_height, int out_width,
+                    void* stream);
+
 /* DEVA.aggregate (network.py:33-40) over `num` object planes of `pixels` each:
  * p = apply_sigmoid ? sigmoid(in) : in;  out[0] = logit(clamp(prod(1-p)));  out[i+1] = logit(clamp(p_i)).
  * in may be fp32 or (in_is_u8 != 0) uint8/bool one-hot planes (inference_core.py:273-277).

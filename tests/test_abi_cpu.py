@@ -31,7 +31,7 @@ def library():
 
 def test_header_symbols_are_exported(library):
     names = _declared()
-    assert len(names) >= 32
+    assert len(names) >= 33
     for n in names:
         assert hasattr(library, n), f'{n} declared in include/deva_hip.h but not exported'
 

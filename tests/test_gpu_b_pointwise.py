@@ -91,3 +91,20 @@ def test_gru(b, c, h, w):
     g = torch.Generator().manual_seed(7)
     v, hh = rand(g, b, 3 * c, h, w, scale=2.0), rand(g, b, c, h, w)
     _check('gru', ops.gru_update(to_dev(v), to_dev(hh)), emu_ops.gru_update(v, hh), 2e-6)
+
+
+@pytest.mark.parametrize('h,w,size,aa', [(720, 1280, (480, 853), True), (1080, 1920, (480, 853), True),
+                                         (2160, 3840, (480, 853), True), (240, 320, (480, 640), True),
+                                         (720, 1280, (480, 853), False), (97, 131, (50, 203), True),
+                                         (480, 854, None, True)])
+def test_input_head(h, w, size, aa):
+    """uint8 HWC -> normalised, (antialias-)resized CHW vs torchvision's tensor pipeline restated with
+    torch (ToTensor + Normalize + F.interpolate(bilinear, antialias))"""
+    g = torch.Generator().manual_seed(h + w)
+    img = torch.randint(0, 256, (h, w, 3), generator=g, dtype=torch.uint8)
+    # smooth it a little so that neighbouring pixels correlate like in a photograph
+    img = ((img.float() + img.float().roll(1, 0) + img.float().roll(1, 1)) / 3).round().to(torch.uint8)
+    want = emu_ops.input_head(img, size, antialias=aa)
+    got = ops.input_head(to_dev(img), size, antialias=aa)
+    assert tuple(got.shape) == tuple(want.shape)
+    _check(f'input_head {h}x{w}->{size} aa={aa}', got, want, 3e-6)

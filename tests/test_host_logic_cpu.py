@@ -295,3 +295,15 @@ def test_prob_to_obj_cls_equals_the_drivers_tail(emu):
     assert torch.equal(om.prob_to_obj_cls(prob), om.tmp_to_obj_cls(torch.argmax(prob, dim=0)))
     big = F.interpolate(prob.unsqueeze(1), (60, 90), mode='bilinear', align_corners=False)[:, 0]
     assert torch.equal(om.prob_to_obj_cls(prob, (60, 90)), om.tmp_to_obj_cls(torch.argmax(big, dim=0)))
+
+
+def test_frame_to_network_input_shapes(emu, monkeypatch):
+    """host side of the device input head: size rule of the readers (shorter side -> min_side)"""
+    import numpy as np
+    from deva.utils import tensor_utils as TU
+    monkeypatch.setattr(torch.Tensor, 'cuda', lambda self, *a, **k: self)
+    monkeypatch.setattr(torch.Tensor, 'is_cuda', property(lambda self: True))
+    frame = np.random.RandomState(0).randint(0, 256, (72, 128, 3), dtype=np.uint8)
+    out = TU.frame_to_network_input(frame, 48)
+    assert tuple(out.shape) == (3, 48, 85) and out.dtype == torch.float32
+    assert tuple(TU.frame_to_network_input(frame).shape) == (3, 72, 128)

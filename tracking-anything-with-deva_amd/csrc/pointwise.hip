@@ -287,6 +287,84 @@ __global__ void gru_update_kernel(const float* __restrict__ values, const float*
   }
 }
 
+// ------------------------------------------------------------------ input head
+// uint8 HWC frame -> normalised fp32 CHW at the network's input size, in one pass
+// (deva/inference/data/video_reader.py:139-144 = ToTensor + Normalize + Resize(antialias=True);
+// deva/inference/demo_utils.py:10-19 = the same with plain bilinear).  The normalisation goes through
+// a 3 x 256 table in LDS with torchvision's arithmetic ((u/255 - mean)/std in fp32); the resize follows
+// ATen: antialias -> separable triangle filter of _upsample_bilinear2d_aa (support = scale when
+// shrinking, weights normalised per output index, columns before rows, each 1-D sum accumulated in
+// tap order); otherwise the 2-tap bilinear of upsample_bilinear2d (align_corners=False).
+struct HeadArgs {
+  const unsigned char* img;
+  int h, w, oh, ow, antialias;
+  float mean[3], stdv[3];
+  float* out;
+};
+
+__device__ __forceinline__ float tri(float x) { return fmaxf(0.0f, 1.0f - fabsf(x)); }
+
+// [first, first+size) source indices and their weights for output index i (ATen
+// _compute_indices_min_size_weights_aa); at most MAXT taps
+constexpr int MAXT = 24;
+__device__ __forceinline__ void aa_taps(int i, int in, float scale, int& first, int& size, float (&wgt)[MAXT]) {
+  const float support = scale >= 1.0f ? scale : 1.0f;
+  const float invscale = scale >= 1.0f ? 1.0f / scale : 1.0f;
+  const float center = scale * ((float)i + 0.5f);
+  first = max((int)(center - support + 0.5f), 0);
+  size = min(min((int)(center + support + 0.5f), in) - first, MAXT);
+  float total = 0.0f;
+  for (int j = 0; j < size; ++j) {
+    wgt[j] = tri(((float)(j + first) - center + 0.5f) * invscale);
+    total += wgt[j];
+  }
+  if (total != 0.0f)
+    for (int j = 0; j < size; ++j) wgt[j] /= total;
+}
+
+__global__ void input_head_kernel(const HeadArgs p) {
+  __shared__ float lut[3][256];
+  for (int i = threadIdx.x; i < 768; i += blockDim.x) {
+    const int c = i >> 8, u = i & 255;
+    lut[c][u] = ((float)u / 255.0f - p.mean[c]) / p.stdv[c];
+  }
+  __syncthreads();
+  const float sy = (float)p.h / (float)p.oh, sx = (float)p.w / (float)p.ow;
+  const int64_t total = (int64_t)p.oh * p.ow;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int y = (int)(i / p.ow), x = (int)(i - (int64_t)y * p.ow);
+    float r[3];
+    if (p.oh == p.h && p.ow == p.w) {
+      const unsigned char* px = p.img + ((int64_t)y * p.w + x) * 3;
+      for (int c = 0; c < 3; ++c) r[c] = lut[c][px[c]];
+    } else if (p.antialias) {
+      int y0, ny, x0, nx;
+      float wy[MAXT], wx[MAXT];
+      aa_taps(y, p.h, sy, y0, ny, wy);
+      aa_taps(x, p.w, sx, x0, nx, wx);
+      r[0] = r[1] = r[2] = 0.0f;
+      for (int j = 0; j < ny; ++j) {
+        const unsigned char* row = p.img + ((int64_t)(y0 + j) * p.w + x0) * 3;
+        float hsum[3] = {lut[0][row[0]] * wx[0], lut[1][row[1]] * wx[0], lut[2][row[2]] * wx[0]};
+        for (int t = 1; t < nx; ++t)
+          for (int c = 0; c < 3; ++c) hsum[c] += lut[c][row[3 * t + c]] * wx[t];
+        for (int c = 0; c < 3; ++c) r[c] = (j == 0) ? hsum[c] * wy[0] : r[c] + hsum[c] * wy[j];
+      }
+    } else {
+      const float fy = fmaxf(sy * ((float)y + 0.5f) - 0.5f, 0.0f), fx = fmaxf(sx * ((float)x + 0.5f) - 0.5f, 0.0f);
+      const int y0 = min((int)fy, p.h - 1), x0 = min((int)fx, p.w - 1);
+      const int y1 = y0 + (y0 < p.h - 1 ? 1 : 0), x1 = x0 + (x0 < p.w - 1 ? 1 : 0);
+      const float ly1 = fy - (float)y0, lx1 = fx - (float)x0, ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+      for (int c = 0; c < 3; ++c) {
+        const float a = lut[c][p.img[((int64_t)y0 * p.w + x0) * 3 + c]], b = lut[c][p.img[((int64_t)y0 * p.w + x1) * 3 + c]];
+        const float d = lut[c][p.img[((int64_t)y1 * p.w + x0) * 3 + c]], e = lut[c][p.img[((int64_t)y1 * p.w + x1) * 3 + c]];
+        r[c] = ly0 * (lx0 * a + lx1 * b) + ly1 * (lx0 * d + lx1 * e);
+      }
+    }
+    for (int c = 0; c < 3; ++c) p.out[(int64_t)c * total + i] = r[c];
+  }
+}
+
 }  // namespace
 }  // namespace deva
 
@@ -396,4 +474,29 @@ extern "C" int deva_gru_update(const float* values, const float* h, float* new_h
   hipLaunchKernelGGL(gru_update_kernel, grid_for(total), dim3(TPB), 0, (hipStream_t)stream, values, h, new_h, total,
                      channels, hw);
   return check_launch("deva_gru_update");
+}
+
+extern "C" int deva_input_head(const unsigned char* image_hwc, int height, int width, const float* mean3,
+                               const float* std3, int antialias, float* out, int out_height, int out_width,
+                               void* stream) {
+  using namespace deva;
+  DEVA_REQUIRE(image_hwc && mean3 && std3 && out && height > 0 && width > 0 && out_height > 0 && out_width > 0,
+               "deva_input_head: bad args");
+  // the antialias filter holds at most 24 taps per axis: shrink factors up to 11
+  DEVA_REQUIRE(!antialias || ((float)height / out_height <= 11.0f && (float)width / out_width <= 11.0f),
+               "deva_input_head: shrink factor above 11 is not supported with antialias");
+  HeadArgs a;
+  a.img = image_hwc;
+  a.h = height;
+  a.w = width;
+  a.oh = out_height;
+  a.ow = out_width;
+  a.antialias = antialias;
+  for (int c = 0; c < 3; ++c) {
+    a.mean[c] = mean3[c];
+    a.stdv[c] = std3[c];
+  }
+  a.out = out;
+  hipLaunchKernelGGL(input_head_kernel, grid_for((int64_t)out_height * out_width), dim3(TPB), 0, (hipStream_t)stream, a);
+  return check_launch("deva_input_head");
 }

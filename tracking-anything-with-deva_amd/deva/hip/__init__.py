@@ -71,6 +71,8 @@ SIGNATURES = {
     'deva_softmax_columns': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     'deva_label_histogram': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p]),
     'deva_lut_remap': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
+    'deva_input_head': (c_int, [c_void_p, c_int, c_int, POINTER(c_float), POINTER(c_float), c_int, c_void_p, c_int, c_int,
+                                c_void_p]),
     'deva_index_mask': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     'deva_merge_paint': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_int, c_int64, c_void_p, c_void_p]),

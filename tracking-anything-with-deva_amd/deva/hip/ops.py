@@ -17,7 +17,7 @@ __all__ = ['PackedConv', 'pack_conv', 'conv2d', 'maxpool3x3s2', 'upsample2x_add'
            'aggregate', 'softmax_channels', 'upsample4x_softmax', 'cbam', 'gru_update',
            'affinity_topk', 'usage_update', 'readout_sparse', 'bank_append', 'bank_gather_rows',
            'bank_export', 'rank', 'rank_select', 'evict_select', 'similarity_dense', 'softmax_columns',
-           'label_histogram', 'merge_paint', 'lut_remap', 'index_mask',
+           'label_histogram', 'merge_paint', 'lut_remap', 'index_mask', 'input_head',
            'ACT_NONE', 'ACT_RELU', 'ACT_SIGMOID', 'ACT_SQUARE_PLUS_ONE']
 
 
@@ -434,4 +434,23 @@ def index_mask(prob: torch.Tensor, size: Optional[Tuple[int, int]] = None,
     n = 0 if lut is None else lut.numel()
     check(lib().deva_index_mask(_p(prob, name='prob'), c, h, w, oh, ow, _p(lut, torch.int64), n, _p(out, torch.int64),
                                 _stream()), 'deva_index_mask')
+    return out
+
+
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def input_head(image_u8: torch.Tensor, size: Optional[Tuple[int, int]] = None, *, antialias: bool = True,
+               mean=IMAGENET_MEAN, std=IMAGENET_STD) -> torch.Tensor:
+    """uint8 [H,W,3] frame on the device -> normalised fp32 [3,OH,OW] (ToTensor + Normalize + Resize)"""
+    import ctypes
+    if image_u8.dtype != torch.uint8 or image_u8.dim() != 3 or image_u8.shape[2] != 3:
+        raise DevaHipError('input_head: expects a uint8 [H, W, 3] frame')
+    h, w = image_u8.shape[:2]
+    oh, ow = (h, w) if size is None else (int(size[0]), int(size[1]))
+    out = _alloc((3, oh, ow), image_u8.device)
+    m = (ctypes.c_float * 3)(*mean)
+    sd = (ctypes.c_float * 3)(*std)
+    check(lib().deva_input_head(_p(image_u8, torch.uint8, 'image'), h, w, m, sd, int(antialias), _p(out), oh, ow,
+                                _stream()), 'deva_input_head')
     return out

@@ -21,3 +21,22 @@ def unpad(img: torch.Tensor, pad: Iterable[int]) -> torch.Tensor:
     left, right, top, bottom = pad
     h, w = img.shape[-2:]
     return img[..., top:h - bottom, left:w - right]
+
+
+def frame_to_network_input(image_u8, min_side: int = -1, *, antialias: bool = True) -> torch.Tensor:
+    """Device-side input head (not part of the reference's interface): a decoded
+    uint8 H*W*3 frame (numpy array or tensor) -> ImageNet-normalised fp32 3*H'*W' on the HIP device with
+    the shorter side resized to `min_side` (<= 0: original size), in one kernel.  antialias=True is the
+    dataset readers' transform (video_reader.py:139-144), antialias=False the demo's
+    `get_input_frame_for_deva` (demo_utils.py:10-19).  Only the uint8 frame crosses PCIe."""
+    from deva.hip import ops
+    if not torch.is_tensor(image_u8):
+        image_u8 = torch.from_numpy(image_u8)
+    if not image_u8.is_cuda:
+        image_u8 = image_u8.cuda()
+    h, w = image_u8.shape[:2]
+    size = None
+    if min_side > 0:
+        scale = min_side / min(h, w)
+        size = (int(h * scale), int(w * scale))
+    return ops.input_head(image_u8.contiguous(), size, antialias=antialias)
