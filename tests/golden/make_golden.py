@@ -202,6 +202,18 @@ def gen_alignment(net):
                os.path.join(HERE, 'alignment.pt'))
 
 
+def gen_read_memory(net):
+    """DEVA.read_memory (network.py:72-92): dense full-softmax read, B=2, 2 objects, T=3 memory frames"""
+    g = torch.Generator().manual_seed(31)
+    B, no, T, h, w = 2, 2, 3, 5, 7
+    args = dict(query_key=torch.randn(B, 64, h, w, generator=g), query_selection=torch.rand(B, 64, h, w, generator=g),
+                memory_key=torch.randn(B, 64, T, h, w, generator=g), memory_shrinkage=torch.rand(B, 1, T, h, w, generator=g) + 1,
+                memory_value=torch.randn(B, no, 512, T, h, w, generator=g))
+    out = net.read_memory(**args)
+    torch.save(dict(args=args, out=out.clone()), os.path.join(HERE, 'read_memory.pt'))
+    print('read_memory', tuple(out.shape), float(out.abs().max()))
+
+
 def gen_edge(net):
     from deva.inference.object_info import ObjectInfo
     out = scenarios.run_edge_cases(lambda cfg: DEVAInferenceCore(net, cfg), make_info=ObjectInfo)
@@ -245,6 +257,10 @@ def gen_api_surface():
 
 if __name__ == '__main__':
     only = os.environ.get('ONLY')
+    if only == 'read_memory':
+        net, _, _ = build_reference(synth.base_config())
+        gen_read_memory(net)
+        sys.exit(0)
     if only == 'edge':
         net, _, _ = build_reference(synth.base_config())
         gen_edge(net)
@@ -267,6 +283,7 @@ if __name__ == '__main__':
     gen_detection_e2e(net)
     gen_alignment(net)
     gen_edge(net)
+    gen_read_memory(net)
     gen_api_surface()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -285,3 +285,12 @@ def test_chunked_objects_clip_matches_unchunked(network):
     worst = max(max_err(a, b) for a, b in zip(chunked, plain))
     print(f'chunk_size=2 vs unchunked: max abs prob difference {worst:.3e}')
     assert worst <= 1e-3
+
+
+def test_read_memory_against_reference_golden(network, golden_dir):
+    """DEVA.read_memory (dense, full softmax) on the dense-similarity / column-softmax / GEMM kernels"""
+    g = torch.load(os.path.join(golden_dir, 'read_memory.pt'))
+    out = network.read_memory(**{k: v.to(dev()) for k, v in g['args'].items()})
+    err = max_err(out, g['out'])
+    print(f'read_memory max abs err {err:.3e}')
+    assert out.shape == g['out'].shape and err <= 1e-4 * max(1.0, g['out'].abs().max().item())

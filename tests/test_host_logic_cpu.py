@@ -307,3 +307,12 @@ def test_frame_to_network_input_shapes(emu, monkeypatch):
     out = TU.frame_to_network_input(frame, 48)
     assert tuple(out.shape) == (3, 48, 85) and out.dtype == torch.float32
     assert tuple(TU.frame_to_network_input(frame).shape) == (3, 72, 128)
+
+
+def test_read_memory_matches_reference(emu, golden_dir, recipe_state_dict):
+    """DEVA.read_memory, the dense training-time read of the public module interface"""
+    net = _network(recipe_state_dict)
+    g = torch.load(os.path.join(golden_dir, 'read_memory.pt'))
+    out = net.read_memory(**g['args'])
+    assert out.shape == g['out'].shape
+    assert (out - g['out']).abs().max().item() <= 1e-4 * max(1.0, g['out'].abs().max().item())

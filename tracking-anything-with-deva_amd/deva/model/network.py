@@ -84,9 +84,44 @@ class DEVA(nn.Module):
         new_h = sens[0] if len(sens) == 1 else torch.cat(sens, 0)
         return value.unsqueeze(0), new_h.unsqueeze(0)
 
-    def read_memory(self, query_key, query_selection, memory_key, memory_shrinkage, memory_value):
-        raise NotImplementedError('read_memory is the training-time dense read (network.py:72-92); '
-                                  'inference reads through MemoryManager.match_memory')
+    def read_memory(self, query_key: torch.Tensor, query_selection: torch.Tensor, memory_key: torch.Tensor,
+                    memory_shrinkage: torch.Tensor, memory_value: torch.Tensor) -> torch.Tensor:
+        """network.py:72-92, the dense (full-softmax) read used at training time; inference reads
+        through `MemoryManager.match_memory`.  query_key / query_selection [B,CK,H,W]; memory_key
+        [B,CK,T,H,W]; memory_shrinkage [B,1,T,H,W]; memory_value [B,no,CV,T,H,W] -> [B,no,CV,H,W].
+        Per batch element: dense similarity of all memory tokens against the HW queries, column
+        softmax with max subtraction, read-out as an fp32-MFMA GEMM (the consolidation kernels)."""
+        B, no, cv = memory_value.shape[:3]
+        ck, (h, w) = query_key.shape[1], query_key.shape[-2:]
+        hw = h * w
+        n = memory_key[0, 0].numel()
+        dev = query_key.device
+        out = torch.empty((B, no, cv, h, w), dtype=torch.float32, device=dev)
+        queries = torch.arange(n, n + hw, dtype=torch.int32, device=dev)
+        for b in range(B):
+            # token-major rows: memory tokens first, the queries after them (the kernel picks its
+            # queries by row index; the selection of the memory rows is never read)
+            key_rows = torch.empty((n + hw, ck), dtype=torch.float32, device=dev)
+            sel_rows = torch.zeros((n + hw, ck), dtype=torch.float32, device=dev)
+            ops.bank_append(_f32c(memory_key[b]).reshape(ck, n), key_rows, 0)
+            ops.bank_append(_f32c(query_key[b]).reshape(ck, hw), key_rows, n)
+            ops.bank_append(_f32c(query_selection[b]).reshape(ck, hw), sel_rows, n)
+            shr = _f32c(memory_shrinkage[b]).reshape(n)
+            aff = ops.softmax_columns(ops.similarity_dense(key_rows, shr, sel_rows, queries, n), hw)
+            ld = aff.shape[1]
+            cv_pad = (cv + 31) // 32 * 32
+            val_rows = torch.zeros((n, cv_pad), dtype=torch.float32, device=dev)
+            for o in range(no):
+                # out[c][q] = sum_n value[n][c] * aff[n][q]: the values are the GEMM's [K][cout] weights, the
+                # affinity matrix its [K = tokens][pixels = queries] input
+                rows = val_rows if cv_pad == cv else torch.empty((n, cv), dtype=torch.float32, device=dev)
+                ops.bank_append(_f32c(memory_value[b, o]).reshape(cv, n), rows, 0)
+                if cv_pad != cv:
+                    val_rows[:, :cv] = rows
+                gemm = ops.PackedConv(val_rows, None, n, cv, cv_pad, 1, 1)
+                r = ops.conv2d(gemm, aff.view(1, n, 1, ld))
+                out[b, o] = r.view(cv, ld)[:, :hw].reshape(cv, h, w)
+        return out
 
     def segment(self, multi_scale_features: Iterable[torch.Tensor], memory_readout: torch.Tensor,
                 sensory: torch.Tensor, last_mask: torch.Tensor, *, selector=None, need_aux: bool = False,
