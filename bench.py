@@ -10,7 +10,7 @@ exactly like evaluation/eval_vos.py:150-186 but over the whole K-frame region.
 
 Workload at N=1 (config.workload): BASELINE.json configs[1] -- DAVIS-2017-style 480p (854x480 ->
 padded 480x864), 5 objects, working memory only, synthetic temporally-coherent frames, recipe
-weights (the checkpoint is a download; oracle/weights.py).  Frames are resident in HBM before the
+weights (the checkpoint is a download; workload/weights.py).  Frames are resident in HBM before the
 timed region.  N>1: independent clips, one per GPU (replicas; RCCL is used only for the barrier
 and the max-over-ranks reduction) -> "scaling": "weak".
 
@@ -50,7 +50,7 @@ PEAK_HBM_GBPS = 8000.0
 
 
 def build_network(device):
-    from oracle import synth, weights
+    from workload import synth, weights
     from deva.model.network import DEVA
     with open(os.path.join(ROOT, 'tests', 'golden', 'state_dict_spec.json')) as f:
         spec = json.load(f)['tensors']
@@ -61,14 +61,14 @@ def build_network(device):
 
 
 def make_clip(height, width, n_frames, seed, device):
-    from oracle import synth
+    from workload import synth
     stream = synth.FrameStream(height, width, seed=seed)
     return [stream.next().to(device) for _ in range(n_frames)]
 
 
 def start_clip(net, cfg, frames, num_objects, device, lt_prefill=0, shard=False):
     """annotated first frame (+ optional pre-filled long-term bank)"""
-    from oracle import synth
+    from workload import synth
     from deva.inference.inference_core import DEVAInferenceCore
     core = DEVAInferenceCore(net, cfg)
     if shard:
@@ -181,7 +181,7 @@ def affinity_microbench(device, n=10000, hw=8160, k=30, iters=20):
 
 def cpu_baseline(sd, cfg, height, width, num_objects, frames_cpu):
     from oracle import deva_oracle as O
-    from oracle import synth
+    from workload import synth
     core = O.OracleCore(sd, cfg)
     mask = synth.box_mask(height, width, num_objects)
     core.step(frames_cpu[0], mask, list(range(1, num_objects + 1)))
@@ -224,7 +224,7 @@ def whole_job_fps(steps_per_rank: int, world: int, elapsed: float) -> float:
 def run_long4k(net, device, steps, warmup, seed, shard, dist):
     """BASELINE configs[4]: one 4K clip, 1 object, 50 000-token long-term bank.  With `shard` the
     memory read is partitioned by query column over the process group (every rank steps the clip)."""
-    from oracle import synth
+    from workload import synth
     cfg = synth.base_config(max_long_term_elements=50000)
     n_frames = 1 + warmup + steps
     frames = make_clip(2160, 3840, n_frames, seed=seed, device=device)
@@ -286,7 +286,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend='nccl')  # RCCL on ROCm
 
-    from oracle import synth
+    from workload import synth
     net, sd = build_network(device)
     if args.workload == 'long4k':
         return long4k(args, net, rank, world, device, dist if distributed else None)

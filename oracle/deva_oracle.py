@@ -19,6 +19,8 @@ algorithm in the reference files below; it shares no module structure with them.
   memory ops   deva/model/memory_utils.py:6-76
   memory mgr   deva/inference/memory_manager.py:64-292, kv_memory_store.py:5-276
   frame loop   deva/inference/inference_core.py:55-113,200-290
+  detections   deva/inference/inference_core.py:137-198, segment_merging.py:17-143,
+               object_manager.py:27-110, object_info.py:11-31
   pad/unpad    deva/utils/tensor_utils.py:7-48
 """
 import math
@@ -529,3 +531,122 @@ class OracleCore:
         if is_mem:
             self._add_memory(image, ms, self.last_mask, key, shrinkage, selection)
         return unpad(prob, pad)
+
+
+# --------------------------------------------------------------------------------------
+# detections + propagation (evaluation/eval_with_detections.py call pattern)
+# --------------------------------------------------------------------------------------
+
+
+def merge_detection(forward: torch.Tensor, detected: torch.Tensor, table: List[Dict], segments: List[Dict],
+                    history: set, max_num_objects: int = -1, incremental: bool = False):
+    """segment_merging.py:17-143 + the ObjectManager side effects it triggers
+    (object_manager.py:27-66), on a plain object table.
+
+    forward: H*W mask in tmp ids (position in `table` + 1); detected: H*W mask in detection ids.
+    table: tracked objects in tmp order, dicts {id, isthing, cats, poke}; segments: detections
+    {id, category_id, isthing}.  `history`: every id ever handed out (collisions are re-drawn from
+    np.random like the reference).  Returns the one-hot merged masks [len(table'), H, W] (bool);
+    `table` and `history` are updated in place."""
+    import numpy as np
+    forward, detected = forward.long(), detected.long()
+    ours = [forward == (i + 1) for i in range(len(table))]
+    if max_num_objects > 0 and len(table) + len(segments) > max_num_objects:
+        segments = []  # too many objects: every new detection is denied (segment_merging.py:115-122)
+    news = [detected == s['id'] for s in segments]
+    our_area = [int(m.sum()) for m in ours]
+    new_area = [int(m.sum()) for m in news]
+    merged = torch.zeros_like(forward)
+    n_tracked_before = len(table)
+
+    for status in (None, False, True):  # untyped, stuff, things are merged separately
+        partner: Dict[int, int] = {}  # tracked index -> detection index
+        queue = []                     # (area, kind, index) in the reference's insertion order
+        for j, seg in enumerate(segments):
+            if seg['isthing'] != status:
+                continue
+            hit = None
+            for i in range(n_tracked_before):
+                if table[i]['isthing'] != status or i in partner:
+                    continue
+                inter = int((news[j] & ours[i]).sum())
+                if inter < 1e-3:
+                    continue
+                union = new_area[j] + our_area[i] - inter
+                if inter / union > 0.5:
+                    hit = (i, union)
+                    break
+            if hit is None:
+                queue.append((new_area[j], 'new', j))
+            else:
+                partner[hit[0]] = j
+                queue.append((hit[1], 'ours', hit[0]))
+        for i in range(n_tracked_before):
+            if table[i]['isthing'] == status and i not in partner:
+                queue.append((our_area[i], 'ours', i))
+        # large areas are painted first so that small segments end up on top (stable order on ties)
+        for _, kind, idx in sorted(queue, key=lambda item: item[0], reverse=True):
+            if kind == 'new':
+                seg = segments[idx]
+                new_id = seg['id']
+                tries = 0
+                while new_id in history:
+                    new_id = int(np.random.randint(1, 256))
+                    tries += 1
+                    if tries > 5000:
+                        raise ValueError('no free object id')
+                history.add(new_id)
+                table.append(dict(id=new_id, isthing=seg['isthing'], cats=[seg['category_id']], poke=0))
+                merged[news[idx]] = new_id
+                continue
+            rec = table[idx]
+            merged[ours[idx]] = rec['id']
+            if idx in partner:
+                j = partner[idx]
+                merged[news[j]] = rec['id']
+                rec['cats'].append(segments[j]['category_id'])
+                rec['poke'] = 0
+            elif incremental:
+                rec['poke'] = rec['poke'] + 1 if our_area[idx] < 1 else 0
+            else:
+                rec['poke'] += 1
+    if not table:
+        return torch.zeros((0, *merged.shape), dtype=torch.bool)
+    return torch.stack([merged == rec['id'] for rec in table], 0)
+
+
+class OracleDetectionCore(OracleCore):
+    """OracleCore + `incorporate_detection` (inference_core.py:137-198) for the online
+    detections-with-propagation setting."""
+
+    def __init__(self, params: Params, cfg: Dict):
+        super().__init__(params, cfg)
+        self.table: List[Dict] = []
+        self.history: set = set()
+
+    def incorporate_detection(self, image: torch.Tensor, new_mask: torch.Tensor, segments: List[Dict],
+                              incremental: bool = False) -> torch.Tensor:
+        self.curr_ti += 1
+        image, pad = pad_to_multiple(image)
+        new_mask, _ = pad_to_multiple(new_mask)
+        image = image.unsqueeze(0)
+        ms, feat = encode_image(self.P, image)
+        key, shrinkage, selection = transform_key(self.P, feat)
+        if self.memory.engaged:
+            forward = torch.argmax(self._segment(key, selection, ms), dim=0)
+        else:
+            forward = torch.zeros_like(new_mask)
+        merged = merge_detection(forward, new_mask, self.table, segments, self.history,
+                                 max_num_objects=self.cfg.get('max_num_objects', -1), incremental=incremental)
+        # retire objects unseen for too long (object_manager.py:89-110) and their memories
+        limit = self.cfg['max_missed_detection_count']
+        keep = [i for i, rec in enumerate(self.table) if rec['poke'] <= limit]
+        if len(keep) != len(self.table):
+            self.table = [self.table[i] for i in keep]
+            self.memory.purge_except([rec['id'] for rec in self.table])
+            merged = merged[keep]
+        self.objects = [rec['id'] for rec in self.table]
+        self.last_mask = merged.unsqueeze(0).type_as(key)
+        if self.last_mask.shape[1] > 0:  # inference_core.py:67-70: nothing to memorise
+            self._add_memory(image, ms, self.last_mask, key, shrinkage, selection)
+        return unpad(aggregate(self.last_mask[0], dim=0), pad)

@@ -21,11 +21,32 @@ def golden_dir():
 
 @pytest.fixture(scope='session')
 def recipe_state_dict():
-    """Recipe weights (oracle/weights.py) for the spec committed in tests/golden."""
+    """Recipe weights (workload/weights.py) for the spec committed in tests/golden."""
     import json
     import torch
-    from oracle import weights
+    from workload import weights
     with open(os.path.join(ROOT, 'tests', 'golden', 'state_dict_spec.json')) as f:
         spec = json.load(f)
     triples = [(k, tuple(s), getattr(torch, d)) for k, s, d in spec['tensors']]
     return weights.make_state_dict(triples, seed=0), spec
+
+
+def pytest_sessionstart(session):
+    """DEVA_TEST_DRYRUN=1 (builder's container, no GPU): run the -m gpu test CODE on the CPU with the
+    emulated ops so that a typo does not cost a GPU-box session.  Never set on the GPU box: there the
+    -m gpu tests run the HIP library (the driver records which .so files the test process loaded)."""
+    if os.environ.get('DEVA_TEST_DRYRUN') != '1':
+        return
+    import torch
+    assert not torch.cuda.is_available(), 'DEVA_TEST_DRYRUN is for boxes without a GPU'
+    import emu_ops
+    import gpu_util
+
+    class _Setter:
+        @staticmethod
+        def setattr(obj, name, value):
+            setattr(obj, name, value)
+
+    emu_ops.install(_Setter)
+    gpu_util.dev = lambda: torch.device('cpu')
+    torch.cuda.synchronize = lambda *a, **k: None

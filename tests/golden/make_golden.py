@@ -3,7 +3,7 @@
 Run in the build container only (needs /root/reference):
     python tests/golden/make_golden.py
 It imports the reference with the two shims of SURVEY.md §8c (stub `pulp`; force
-`pretrained=False` for the ResNets), loads the recipe weights of oracle/weights.py and writes
+`pretrained=False` for the ResNets), loads the recipe weights of workload/weights.py and writes
 small .pt/.npz fixtures next to this file.  Nothing here is imported by the product or the tests.
 """
 import hashlib
@@ -35,7 +35,7 @@ from deva.model import memory_utils as MU  # noqa: E402
 from deva.inference.memory_manager import MemoryManager  # noqa: E402
 from deva.utils.tensor_utils import pad_divide_by  # noqa: E402
 
-from oracle import synth, weights  # noqa: E402
+from workload import synth, weights  # noqa: E402
 import scenarios  # noqa: E402
 
 warnings.filterwarnings('ignore')

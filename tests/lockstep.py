@@ -8,7 +8,7 @@ top-k sets must be identical, so the soft outputs have to agree to 1e-3 (observe
 import torch
 
 from oracle import deva_oracle as O
-from oracle import synth
+from workload import synth
 
 
 def run(network, P, H, W, no, frames, device, stage_tol=2e-4):

@@ -1,0 +1,209 @@
+"""Audit helpers for the memory path (shared by the CPU host-logic tests, which run them on the
+emulated ops, and by the -m gpu tests, which run them on the HIP kernels).
+
+1. `ReadTap` / `OracleTap`: record every top-k memory read of a HIP `MemoryManager` and of the CPU
+   oracle (bank, queries, selected token lists).
+2. `explain_flips`: compare the two runs' selections query by query.  A differing selection is
+   *explained* only if the reference's own score gap between the tokens that were swapped is within
+   the measured score noise between the two runs (their banks/queries differ in the last bits) --
+   i.e. a near-tie that any last-bit change of the keys flips.  Everything else is a kernel bug.
+3. `teacher_forced_memory`: drives a scenario with the CPU oracle and mirrors every memory call
+   (match / add with its consolidation and eviction) into a HIP `MemoryManager` fed with the
+   ORACLE'S inputs, asserting after every call: identical banks (keys bit-exact, i.e. identical
+   prototype index lists and identical surviving token sets), prototype values / shrinkage and usage
+   counters within 1e-5, identical top-k sets, read-outs within 1e-5 relative.
+   Reference: memory_manager.py:91-276, kv_memory_store.py:35-185, memory_utils.py:48-76.
+"""
+from typing import Dict, List
+
+import torch
+
+from deva.hip import ops
+from oracle import deva_oracle as O
+from workload import synth
+
+
+def _sim(mk_rows: torch.Tensor, ms: torch.Tensor, qk: torch.Tensor, qe: torch.Tensor) -> torch.Tensor:
+    """reference similarity (memory_utils.py:6-45) of a token-major bank [N,64] on the CPU"""
+    return O.get_similarity(mk_rows.t().contiguous(), ms.reshape(1, -1), qk, qe)
+
+
+class ReadTap:
+    """records the inputs and the selection of every `ops.affinity_topk` call"""
+
+    def __init__(self):
+        self.reads: List[Dict] = []
+        self._orig = None
+
+    def __enter__(self):
+        self._orig = ops.affinity_topk
+        tap = self
+
+        def wrapped(key_long, shr_long, n_long, key_work, shr_work, n_work, qk, qe, k, usage_fix=None, splits=None):
+            idx, w = tap._orig(key_long, shr_long, n_long, key_work, shr_work, n_work, qk, qe, k, usage_fix, splits)
+            rows = [key_long[:n_long]] if n_long else []
+            shr = [shr_long[:n_long]] if n_long else []
+            rows.append(key_work[:n_work])
+            shr.append(shr_work[:n_work])
+            tap.reads.append(dict(mk=torch.cat(rows, 0).cpu(), ms=torch.cat(shr, 0).cpu(), qk=qk.cpu(), qe=qe.cpu(),
+                                  idx=idx.cpu().long(), w=w.cpu(), n_long=n_long, k=k))
+            return idx, w
+
+        ops.affinity_topk = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        ops.affinity_topk = self._orig
+
+
+class OracleTap:
+    """records the similarity matrix and inputs of every top-k read of the oracle"""
+
+    def __init__(self):
+        self.reads: List[Dict] = []
+        self._orig = None
+        self._last_inputs = None
+
+    def __enter__(self):
+        self._orig = (O.get_similarity, O.dense_affinity)
+        tap = self
+
+        def get_similarity(mk, ms, qk, qe):
+            tap._last_inputs = (mk, ms, qk, qe)
+            return tap._orig[0](mk, ms, qk, qe)
+
+        def dense_affinity(sim, k):
+            if k is not None:
+                mk, ms, qk, qe = tap._last_inputs
+                tap.reads.append(dict(mk=mk.t().contiguous(), ms=ms.reshape(-1).clone(), qk=qk.clone(), qe=qe.clone(),
+                                      sim=sim.clone(), k=k))
+            return tap._orig[1](sim, k)
+
+        O.get_similarity, O.dense_affinity = get_similarity, dense_affinity
+        return self
+
+    def __exit__(self, *exc):
+        O.get_similarity, O.dense_affinity = self._orig
+
+
+def explain_flips(tag: str, hip_read: Dict, ref_read: Dict, slack: float = 4.0):
+    """-> (number of queries whose selected token set differs, the largest unexplained excess).
+    A flip is explained when, for every token selected by one side only, the reference's distance of
+    that token's score to its k-th/(k+1)-th boundary is <= slack x the measured score noise of the
+    query (max |score from the HIP run's bank/queries - score from the reference's| over the tokens
+    involved, both evaluated with the reference formula on the CPU)."""
+    sim_ref = ref_read['sim']
+    k = ref_read['k']
+    n, hw = sim_ref.shape
+    assert hip_read['mk'].shape[0] == n, f'{tag}: bank sizes differ ({hip_read["mk"].shape[0]} vs {n})'
+    vals, ridx = torch.topk(sim_ref, k=min(k + 1, n), dim=0)
+    ref_sets = ridx[:k].t()
+    same = (torch.sort(hip_read['idx'], 1)[0] == torch.sort(ref_sets, 1)[0]).all(1)
+    flipped = torch.nonzero(~same).flatten().tolist()
+    worst_excess, lines = 0.0, []
+    if flipped:
+        sim_hip = _sim(hip_read['mk'], hip_read['ms'], hip_read['qk'], hip_read['qe'])
+    for q in flipped:
+        a, b = set(hip_read['idx'][q].tolist()), set(ref_sets[q].tolist())
+        swapped = sorted(a ^ b)
+        boundary = 0.5 * (vals[k - 1, q] + vals[k, q]).item() if n > k else vals[k - 1, q].item()
+        gap = max(abs(sim_ref[t, q].item() - boundary) for t in swapped)
+        noise = max(abs(sim_hip[t, q].item() - sim_ref[t, q].item()) for t in swapped)
+        noise = max(noise, 1e-6 * abs(boundary))  # fp32 evaluation noise of the score itself
+        excess = gap / noise
+        worst_excess = max(worst_excess, excess)
+        lines.append(f'{tag}: query {q}: {len(swapped) // 2} token(s) swapped, boundary score {boundary:.6g}, '
+                     f'reference gap {gap:.3e}, measured score noise {noise:.3e} (ratio {excess:.2f})')
+    for line in lines[:8]:
+        print(line)
+    return len(flipped), (worst_excess if flipped else 0.0), slack
+
+
+def _cmp(name, got, ref, tol, worst):
+    got = got.detach().float().cpu()
+    e = (got - ref).abs().max().item() / max(1.0, ref.abs().max().item()) if ref.numel() else 0.0
+    worst[name] = max(worst.get(name, 0.0), e)
+    assert e <= tol, (name, e)
+
+
+def _compare_banks(tag, hmem, omem, worst):
+    """keys / selections bit-exact (they are copies: equality <=> same tokens in the same order),
+    computed quantities (prototype values & shrinkage, usage counters) to 1e-5"""
+    stores = [('work', hmem.work_mem, omem.work)]
+    if omem.long_term and omem.long.buckets:
+        stores.append(('long', hmem.long_mem, omem.long))
+    for sname, hs, os_ in stores:
+        assert sorted(hs.buckets) == sorted(os_.buckets), (tag, sname, hs.buckets, os_.buckets)
+        hk, hshr = hs.key, hs.shrinkage
+        for b in os_.buckets:
+            assert hs.size(b) == os_.size(b), (tag, sname, b, hs.size(b), os_.size(b))
+            assert torch.equal(hk[b].cpu(), os_.k[b]), f'{tag}: {sname} bucket {b}: key bank differs (different tokens kept / chosen)'
+            _cmp(f'{sname}.shrinkage', hshr[b], os_.s[b], 1e-5, worst)
+            if os_.keep_selection:
+                assert torch.equal(hs.selection[b].cpu(), os_.e[b]), (tag, sname, b, 'selection')
+            if os_.keep_usage:
+                use, life = hs.usage_arenas(b)
+                _cmp(f'{sname}.use_cnt', use[:hs.size(b)], os_.use[b], 1e-5, worst)
+                _cmp(f'{sname}.life_cnt', life[:hs.size(b)], os_.life[b], 1e-6, worst)
+        hv = hs.value
+        for o, v in os_.v.items():
+            _cmp(f'{sname}.value', hv[o], v, 1e-5, worst)
+
+
+def teacher_forced_memory(P, sc: Dict, device, frames: int = None) -> Dict[str, float]:
+    """see the module docstring (3).  Returns the worst relative error per compared quantity plus
+    event counters."""
+    from deva.inference.memory_manager import MemoryManager
+    cfg = synth.base_config(**sc['cfg'])
+    sc = dict(sc, frames=frames or sc['frames'])
+    hmem = MemoryManager(cfg)
+    worst: Dict[str, float] = {}
+    events = dict(reads=0, adds=0, consolidations=0, evictions=0, tie_swapped_queries=0)
+    state = dict(core=None, frame=-1)
+
+    def install(core):
+        omem = core.memory
+        match0, add0 = omem.match, omem.add
+
+        def match(key, selection):
+            tag = f'frame {core.curr_ti}'
+            with OracleTap() as otap:
+                ro_o = match0(key, selection)
+            with ReadTap() as htap:
+                ro_h = hmem.match_memory(key.to(device), selection.to(device))
+            assert len(otap.reads) == len(htap.reads)
+            for bi, (hr, orr) in enumerate(zip(htap.reads, otap.reads)):
+                assert torch.equal(hr['mk'], orr['mk']) and torch.equal(hr['qk'], orr['qk'])
+                n_flip, excess, slack = explain_flips(f'{tag} bucket#{bi}', hr, orr)
+                # identical inputs: a differing set is only acceptable at an fp32 tie
+                assert excess <= slack, f'{tag}: top-k selection differs from the reference beyond a tie'
+                events['tie_swapped_queries'] += n_flip
+            for o, r in ro_o.items():
+                _cmp('readout', ro_h[o], r, 1e-5 if events['tie_swapped_queries'] == 0 else 1e-2, worst)
+            events['reads'] += 1
+            _compare_banks(tag + ' after read', hmem, omem, worst)
+            return ro_o
+
+        def add(key, shrinkage, value, objects, selection):
+            tag = f'frame {core.curr_ti} add'
+            long_before = {b: omem.long.size(b) for b in omem.long.buckets} if omem.long_term else {}
+            add0(key, shrinkage, value, objects, selection)
+            hmem.add_memory(key.to(device), shrinkage.to(device), value.to(device), list(objects),
+                            selection=selection.to(device))
+            events['adds'] += 1
+            if omem.long_term:
+                for b in omem.long.buckets:
+                    grown = omem.long.size(b) - long_before.get(b, 0)
+                    if b not in long_before or grown != 0:
+                        events['consolidations'] += 1
+                        if grown < cfg['num_prototypes']:
+                            events['evictions'] += 1
+            _compare_banks(tag, hmem, omem, worst)
+
+        omem.match, omem.add = match, add
+        return core
+
+    import scenarios
+    scenarios.run_scenario(lambda c: install(O.OracleCore(P, c)), sc)
+    worst.update({k: float(v) for k, v in events.items()})
+    return worst

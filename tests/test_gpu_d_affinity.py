@@ -13,7 +13,7 @@ import torch
 import emu_ops
 from deva.hip import ops
 from gpu_util import dev, max_err, to_dev
-from oracle import synth
+from workload import synth
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)

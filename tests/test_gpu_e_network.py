@@ -13,10 +13,11 @@ import numpy as np
 import pytest
 import torch
 
+import memory_audit
 import scenarios
 from gpu_util import dev, max_err
 from oracle import deva_oracle as O
-from oracle import synth
+from workload import synth
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
@@ -39,25 +40,37 @@ def _margin_aware_mismatch(got: torch.Tensor, ref: torch.Tensor, err: float) -> 
 
 
 class _Drift:
-    """Free-running full-resolution clips.  A near-tied top-k decision legitimately flips when the
-    keys differ in the last bits, which moves that query's read-out by percents and is then carried
-    by the recurrent state (the reference does this against ITSELF).  The bound is
-    therefore set by the reference's own noise floor on the same clip: the CPU oracle is run twice,
-    once on the frames and once on the frames perturbed by 1e-6 relative noise, and the HIP
-    runtime's drift from the reference must stay within 10x that self-drift (or the 1e-3 target,
-    whichever is larger; both are single draws of a heavy-tailed quantity), with argmax identity wherever the reference's margin is decisive."""
+    """Free-running full-resolution clips.  The bound on the soft outputs is north_star's 1e-3 max-abs
+    (or 10x the reference's own drift under a 1e-6 relative input perturbation, measured in the same
+    test, if that is larger).  It may be exceeded ONLY from a frame on in which a top-k selection of
+    the HIP run differs from the reference's and that difference is explained by a measured near-tie:
+    the reference's own score gap at the k-th/(k+1)-th boundary is within the measured score noise
+    between the two runs (tests/memory_audit.py:explain_flips).  An unexplained differing selection
+    fails the test at once; so does an exceedance without a recorded flip."""
 
     def __init__(self, tag, stride=1):
-        self.tag, self.ours, self.floor, self.pixels, self.stride = tag, [], [], 1, stride
+        self.tag, self.ours, self.floor, self.stride = tag, [], [], stride
+        self.first_flip_frame = None
+        self.flips = 0
 
     @staticmethod
     def _stats(a, b):
         d = (a - b).abs()
         return d.max().item(), (d > 1e-3).float().mean().item()
 
+    def audit_reads(self, frame, hip_reads, ref_reads):
+        """compare the top-k selections of this frame's memory reads (one per bucket)"""
+        assert len(hip_reads) == len(ref_reads), (self.tag, frame)
+        for bi, (hr, rr) in enumerate(zip(hip_reads, ref_reads)):
+            n, excess, slack = memory_audit.explain_flips(f'{self.tag} frame {frame} bucket#{bi}', hr, rr)
+            assert excess <= slack, (f'{self.tag} frame {frame}: top-k selection differs from the reference and the '
+                                     f'score gap is {excess:.1f}x the measured score noise: not a near-tie')
+            if n and self.first_flip_frame is None:
+                self.first_flip_frame = frame
+            self.flips += n
+
     def add(self, got, ref, ref_perturbed=None):
         err, frac = self._stats(got, ref)
-        self.pixels = got.shape[-1] * got.shape[-2]
         bad = _margin_aware_mismatch(got, ref, err)
         flips = int((got.argmax(0) != ref.argmax(0)).sum())
         self.ours.append((err, frac))
@@ -72,18 +85,32 @@ class _Drift:
         assert bad == 0, msg
 
     def finish(self):
-        ours_err, ours_frac = max(e for e, _ in self.ours), max(f for _, f in self.ours)
         fl_err = max([e for e, _ in self.floor] + [0.0])
-        fl_frac = max([f for _, f in self.floor] + [0.0])
-        print(f'{self.tag}: clip max-abs {ours_err:.2e} (reference self-drift {fl_err:.2e}); '
-              f'frac>1e-3 {ours_frac:.2e} (reference self-drift {fl_frac:.2e})')
-        # 5e-3 = the size of ONE flipped top-k decision (measured: 1e-3 .. 4e-3), which can occur in
-        # either run at any frame
-        assert ours_err <= max(5e-3, 10 * fl_err), (self.tag, ours_err, fl_err)
-        # a flipped query perturbs (at least) its own 16x16-pixel cell: allow a few cells' worth
-        cell = 4 * 256.0 / (self.pixels * self.stride * self.stride)
-        assert ours_frac <= max(5e-3, cell, 10 * fl_frac), (self.tag, ours_frac, fl_frac)
+        bound = max(1e-3, 10 * fl_err)
+        ours_err = max(e for e, _ in self.ours)
+        print(f'{self.tag}: clip max-abs {ours_err:.2e} (reference self-drift {fl_err:.2e}, bound {bound:.1e}); '
+              f'top-k selections differing from the reference: {self.flips} (all explained near-ties), first at frame '
+              f'{self.first_flip_frame}')
+        for t, (e, _) in enumerate(self.ours):
+            if e > bound:
+                assert self.first_flip_frame is not None and t >= self.first_flip_frame, \
+                    (f'{self.tag} frame {t}: error {e:.2e} above {bound:.1e} without a differing top-k selection '
+                     'at or before this frame')
         assert ours_err <= 5e-2, (self.tag, ours_err)
+
+
+def _paired_clip(tag, stride, hip_frames, noisy_frames, hip_tap_marks, ref_tap_marks, hip_tap, ref_tap,
+                 reference_outputs):
+    """frame-by-frame comparison of a HIP run against reference outputs, with the selection audit
+    against the live oracle run (`*_marks[t]` = number of reads recorded up to and including frame t)"""
+    drift = _Drift(tag, stride=stride)
+    for t, p in enumerate(hip_frames):
+        lo_h, hi_h = (hip_tap_marks[t - 1] if t else 0), hip_tap_marks[t]
+        lo_r, hi_r = (ref_tap_marks[t - 1] if t else 0), ref_tap_marks[t]
+        drift.audit_reads(t, hip_tap.reads[lo_h:hi_h], ref_tap.reads[lo_r:hi_r])
+        drift.add(p, reference_outputs[t], None if noisy_frames is None else noisy_frames[t])
+    drift.finish()
+    return drift
 
 
 def test_stages_teacher_forced(network, golden_dir):
@@ -113,7 +140,10 @@ def test_e2e_against_reference_golden(network, golden_dir, recipe_state_dict, na
     from deva.inference.inference_core import DEVAInferenceCore
     P, _ = recipe_state_dict
     sc = scenarios.E2E[name]
-    outs, core = scenarios.run_scenario(lambda cfg: DEVAInferenceCore(network, cfg), sc, device=dev())
+    hip_marks, ref_marks = [], []
+    with memory_audit.ReadTap() as hip_tap:
+        outs, core = scenarios.run_scenario(lambda cfg: DEVAInferenceCore(network, cfg), sc, device=dev(),
+                                            on_frame=lambda t, c: hip_marks.append(len(hip_tap.reads)))
     g = np.load(os.path.join(golden_dir, f'e2e_{name}.npz'))
     assert [p.shape[0] for p in outs] == g['nchan'].tolist()
     sizes = json.loads(str(g['sizes']))
@@ -121,15 +151,16 @@ def test_e2e_against_reference_golden(network, golden_dir, recipe_state_dict, na
     assert {str(b): mem.work_mem.size(b) for b in mem.work_mem.buckets} == sizes['work']
     if mem.use_long_term:
         assert {str(b): mem.long_mem.size(b) for b in mem.long_mem.buckets} == sizes['long']
+    # the live oracle on the same frames: its top-k selections are what the HIP run's are audited against
+    with memory_audit.OracleTap() as ref_tap:
+        scenarios.run_scenario(lambda cfg: O.OracleCore(P, cfg), sc,
+                               on_frame=lambda t, c: ref_marks.append(len(ref_tap.reads)))
     # the reference's own sensitivity on this clip: oracle on frames perturbed by 1e-6 relative noise
     gen = torch.Generator().manual_seed(0)
-    sc_noisy = dict(sc)
-    noisy_outs, _ = scenarios.run_scenario(lambda cfg: O.OracleCore(P, cfg), sc_noisy,
+    noisy_outs, _ = scenarios.run_scenario(lambda cfg: O.OracleCore(P, cfg), dict(sc),
                                            perturb=lambda img: img * (1 + 1e-6 * torch.randn(img.shape, generator=gen)))
-    drift = _Drift(name, stride=2)
-    for t, p in enumerate(outs):
-        drift.add(p[:, ::2, ::2], torch.from_numpy(g[f'prob_sub_{t}']), noisy_outs[t][:, ::2, ::2])
-    drift.finish()
+    _paired_clip(name, 2, [p[:, ::2, ::2] for p in outs], [p[:, ::2, ::2] for p in noisy_outs], hip_marks, ref_marks,
+                 hip_tap, ref_tap, [torch.from_numpy(g[f'prob_sub_{t}']) for t in range(len(outs))])
 
 
 def test_vos_example_against_reference_golden(network, golden_dir, recipe_state_dict):
@@ -140,7 +171,7 @@ def test_vos_example_against_reference_golden(network, golden_dir, recipe_state_
     mean = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)
     std = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
     cfg = synth.base_config(enable_long_term_count_usage=False)
-    core, noisy = DEVAInferenceCore(network, cfg), O.OracleCore(P, cfg)
+    core, clean, noisy = DEVAInferenceCore(network, cfg), O.OracleCore(P, cfg), O.OracleCore(P, cfg)
     labels = g['labels'].tolist()
     n = g['frames'].shape[0]
     ann = torch.from_numpy(g['annotation'].astype(np.int64))
@@ -149,10 +180,13 @@ def test_vos_example_against_reference_golden(network, golden_dir, recipe_state_
     for t in range(n):
         img = (torch.from_numpy(g['frames'][t]).permute(2, 0, 1).float() / 255 - mean) / std
         img_n = img * (1 + 1e-6 * torch.randn(img.shape, generator=gen))
-        if t == 0:
-            p, pn = core.step(img.to(dev()), ann.to(dev()), labels), noisy.step(img_n, ann, labels)
-        else:
-            p, pn = core.step(img.to(dev()), end=(t == n - 1)), noisy.step(img_n, end=(t == n - 1))
+        first, last = (ann, labels) if t == 0 else (None, None), (t == n - 1)
+        with memory_audit.ReadTap() as hip_tap:
+            p = core.step(img.to(dev()), None if first[0] is None else first[0].to(dev()), first[1], end=last)
+        with memory_audit.OracleTap() as ref_tap:
+            clean.step(img, first[0], first[1], end=last)
+        pn = noisy.step(img_n, first[0], first[1], end=last)
+        drift.audit_reads(t, hip_tap.reads, ref_tap.reads)
         ref = torch.from_numpy(g['prob_sub'][t])  # the reference's own output
         drift.add(p.cpu()[:, ::4, ::4], ref, pn[:, ::4, ::4])
     drift.finish()
@@ -174,10 +208,13 @@ def test_480p_five_objects_against_oracle(network, recipe_state_dict):
     for t in range(frames):
         img = stream.next()
         img_n = img * (1 + 1e-6 * torch.randn(img.shape, generator=gen))
-        if t == 0:
-            a, b, c = hip.step(img.to(dev()), mask0.to(dev()), objs), orc.step(img, mask0, objs), noisy.step(img_n, mask0, objs)
-        else:
-            a, b, c = hip.step(img.to(dev())), orc.step(img), noisy.step(img_n)
+        first = (mask0, objs) if t == 0 else (None, None)
+        with memory_audit.ReadTap() as hip_tap:
+            a = hip.step(img.to(dev()), None if first[0] is None else first[0].to(dev()), first[1])
+        with memory_audit.OracleTap() as ref_tap:
+            b = orc.step(img, first[0], first[1])
+        c = noisy.step(img_n, first[0], first[1])
+        drift.audit_reads(t, hip_tap.reads, ref_tap.reads)
         drift.add(a.cpu(), b, c)
     drift.finish()
 
@@ -216,7 +253,9 @@ def test_detection_clip_against_reference_golden(network, golden_dir):
     assert state == json.loads(str(g['state']))
     errs = [float(np.abs(p[:, ::2, ::2].numpy() - g[f'prob_sub_{t}']).max()) for t, p in enumerate(outs)]
     print('detections clip: max-abs prob err per frame', ['%.1e' % e for e in errs])
-    assert max(errs) <= 5e-3
+    assert max(errs) <= 1e-3
+    for t, p in enumerate(outs):
+        assert _margin_aware_mismatch(p[:, ::2, ::2], torch.from_numpy(g[f'prob_sub_{t}']), errs[t]) == 0, t
 
 
 def test_sharded_read_single_rank_group_is_identical(network):

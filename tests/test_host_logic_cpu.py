@@ -12,7 +12,7 @@ import torch
 import emu_ops
 import scenarios
 from oracle import deva_oracle as O
-from oracle import synth
+from workload import synth
 
 torch.set_grad_enabled(False)
 

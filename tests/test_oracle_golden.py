@@ -10,7 +10,7 @@ import torch
 
 import scenarios
 from oracle import deva_oracle as O
-from oracle import synth
+from workload import synth
 
 torch.set_grad_enabled(False)
 TOL = 2e-5  # bit-identical in the build container; slack for other CPUs / thread counts
@@ -94,3 +94,21 @@ def test_vos_example(golden_dir, recipe_state_dict):
         err = np.abs(p[:, ::4, ::4].numpy() - g['prob_sub'][t]).max()
         assert err <= 1e-4, (t, err)
         assert (p.argmax(0).numpy() != g['argmax'][t]).mean() < 1e-4
+
+
+def test_detection_restatement_against_reference_golden(golden_dir, recipe_state_dict):
+    """OracleDetectionCore (incorporate_detection + match/merge restated on a plain object table)
+    against the reference's outputs and final ObjectManager state on the 13-frame detection clip"""
+    import json
+    P, _ = recipe_state_dict
+    outs, core = scenarios.run_detection_scenario(lambda cfg: O.OracleDetectionCore(P, cfg),
+                                                  lambda **kw: dict(kw), scenarios.DETECTION)
+    g = np.load(os.path.join(golden_dir, 'e2e_detections.npz'))
+    assert [p.shape[0] for p in outs] == g['nchan'].tolist()
+    want = json.loads(str(g['state']))
+    assert [r['id'] for r in core.table] == want['ids']
+    assert [r['poke'] for r in core.table] == want['poke']
+    assert [r['cats'] for r in core.table] == want['cats']
+    assert [r['isthing'] for r in core.table] == want['isthing']
+    for t, p in enumerate(outs):
+        assert np.abs(p[:, ::2, ::2].numpy() - g[f'prob_sub_{t}']).max() <= 1e-5, t

@@ -52,7 +52,7 @@ def _run(rank, world, port, name, out):
     torch.set_num_threads(2)
     import emu_ops
     import scenarios
-    from oracle import synth, weights
+    from workload import synth, weights
     emu_ops.install(_Patch)
     from deva.inference.inference_core import DEVAInferenceCore
     from deva.model.network import DEVA

@@ -10,7 +10,7 @@ for p in (ROOT, os.path.join(ROOT, 'tracking-anything-with-deva_amd')):
     sys.path.insert(0, p)
 import torch  # noqa: E402
 import bench  # noqa: E402
-from oracle import synth  # noqa: E402
+from workload import synth  # noqa: E402
 
 
 def main():

@@ -1,6 +1,6 @@
 """Deterministic synthetic inputs shared by the golden generator, the tests and bench.py.
 
-TEST INFRASTRUCTURE ONLY (see oracle/README.md).  Everything is generated on the CPU with
+INPUT GENERATION ONLY (see workload/__init__.py).  Everything is generated on the CPU with
 explicitly seeded `torch.Generator`s so the same tensors can be rebuilt on any box.
 Recipes follow SURVEY.md §8d ("Synthetic inputs").
 """

@@ -1,6 +1,6 @@
 """Deterministic synthetic weights for the DEVA propagation network.
 
-TEST INFRASTRUCTURE ONLY (see oracle/README.md): only tests/, bench.py's
+INPUT GENERATION ONLY (see workload/__init__.py): only tests/, bench.py's
 cpu_baseline leg and __graft_entry__.smoke() may import this package.
 
 The real checkpoint (`DEVA-propagation.pth`, 420 tensors / 277 MB fp32,
