@@ -161,14 +161,15 @@ int deva_gru_update(const float* values, const float* h, float* new_h, int batch
  *
  * Step 1 (deva_affinity_topk): grid = query tiles x `splits` token ranges; every wave filters the
  *   scores of its range for 32 queries against a running k-th-best threshold and hands over the
- *   surviving candidates (a superset of the range's top-k, at most 128 per query) as 64-bit keys
- *   (order-preserving score bits << 32 | ~token index) in part_keys [splits][hw][128], zero padded.
+ *   surviving candidates (a superset of the range's top-k, at most 64 per query) as 64-bit keys
+ *   (order-preserving score bits << 32 | ~token index) in part_keys [splits][hw][64], followed by the
+ *   32-bit list lengths [splits][hw] (only the first `length` keys of a list are written).
  * Step 2 (deva_affinity_finalize): one wave per query selects the exact top-k over all ranges,
  *   w = exp(v)/sum exp(v) (NO max subtraction, memory_utils.py:59-60), writes idx/w [hw][k] sorted by
  *   descending score and, if usage_fix != NULL, adds w * 2^40 to usage_fix[token] (uint64 fixed
  *   point: integer atomics make the usage sum order-independent, hence deterministic).
  * Total order used for ties: higher score first, then lower token index.
- * Requires CK == 64, 1 <= k <= 32, n_long + n_work >= k, 1 <= splits <= 16. */
+ * Requires CK == 64, 1 <= k <= 32, n_long + n_work >= k, 1 <= splits <= 32. */
 int deva_affinity_topk(const float* key_long, const float* shr_long, int n_long,
                        const float* key_work, const float* shr_work, int n_work,
                        const float* qk, const float* qe, int hw, int k, int splits,

@@ -633,9 +633,12 @@ class OracleDetectionCore(OracleCore):
         ms, feat = encode_image(self.P, image)
         key, shrinkage, selection = transform_key(self.P, feat)
         if self.memory.engaged:
-            forward = torch.argmax(self._segment(key, selection, ms), dim=0)
+            forward_prob = self._segment(key, selection, ms)
+            forward = torch.argmax(forward_prob, dim=0)
+            self.trace.update(forward_prob=unpad(forward_prob, pad))
         else:
             forward = torch.zeros_like(new_mask)
+            self.trace.pop('forward_prob', None)
         merged = merge_detection(forward, new_mask, self.table, segments, self.history,
                                  max_num_objects=self.cfg.get('max_num_objects', -1), incremental=incremental)
         # retire objects unseen for too long (object_manager.py:89-110) and their memories

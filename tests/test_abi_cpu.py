@@ -72,6 +72,6 @@ def test_version_and_argument_errors_without_a_gpu(library):
     assert L.deva_affinity_topk(None, None, 0, None, None, 0, None, None, 0, 30, 1, None, None) != 0
     assert b'deva_affinity_topk' in L.deva_hip_last_error()
     # pure host-side helpers
-    assert L.deva_affinity_workspace(1620, 30, 4) == 4 * 1620 * 128
-    assert 1 <= L.deva_affinity_default_splits(10000, 8160) <= 16
-    assert L.deva_affinity_default_splits(1620, 1620) == 13  # <= 128 tokens per range: no filtering needed
+    assert L.deva_affinity_workspace(1620, 30, 4) == 4 * 1620 * 64 + 4 * 1620 // 2  # keys + 32-bit list lengths
+    assert 1 <= L.deva_affinity_default_splits(10000, 8160) <= 32
+    assert L.deva_affinity_default_splits(1620, 1620) == 26  # <= 64 tokens per range: no filtering needed

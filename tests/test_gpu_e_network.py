@@ -32,71 +32,8 @@ def network(recipe_state_dict):
     return net.to(dev()).eval()
 
 
-def _margin_aware_mismatch(got: torch.Tensor, ref: torch.Tensor, err: float) -> int:
-    """argmax mismatches at pixels whose reference top-1/top-2 margin exceeds 2*err"""
-    top2 = ref.topk(2, dim=0)[0]
-    decisive = (top2[0] - top2[1]) > 2 * err
-    return int(((got.argmax(0) != ref.argmax(0)) & decisive).sum())
-
-
-class _Drift:
-    """Free-running full-resolution clips.  The bound on the soft outputs is north_star's 1e-3 max-abs
-    (or 10x the reference's own drift under a 1e-6 relative input perturbation, measured in the same
-    test, if that is larger).  It may be exceeded ONLY from a frame on in which a top-k selection of
-    the HIP run differs from the reference's and that difference is explained by a measured near-tie:
-    the reference's own score gap at the k-th/(k+1)-th boundary is within the measured score noise
-    between the two runs (tests/memory_audit.py:explain_flips).  An unexplained differing selection
-    fails the test at once; so does an exceedance without a recorded flip."""
-
-    def __init__(self, tag, stride=1):
-        self.tag, self.ours, self.floor, self.stride = tag, [], [], stride
-        self.first_flip_frame = None
-        self.flips = 0
-
-    @staticmethod
-    def _stats(a, b):
-        d = (a - b).abs()
-        return d.max().item(), (d > 1e-3).float().mean().item()
-
-    def audit_reads(self, frame, hip_reads, ref_reads):
-        """compare the top-k selections of this frame's memory reads (one per bucket)"""
-        assert len(hip_reads) == len(ref_reads), (self.tag, frame)
-        for bi, (hr, rr) in enumerate(zip(hip_reads, ref_reads)):
-            n, excess, slack = memory_audit.explain_flips(f'{self.tag} frame {frame} bucket#{bi}', hr, rr)
-            assert excess <= slack, (f'{self.tag} frame {frame}: top-k selection differs from the reference and the '
-                                     f'score gap is {excess:.1f}x the measured score noise: not a near-tie')
-            if n and self.first_flip_frame is None:
-                self.first_flip_frame = frame
-            self.flips += n
-
-    def add(self, got, ref, ref_perturbed=None):
-        err, frac = self._stats(got, ref)
-        bad = _margin_aware_mismatch(got, ref, err)
-        flips = int((got.argmax(0) != ref.argmax(0)).sum())
-        self.ours.append((err, frac))
-        msg = (f'{self.tag} frame {len(self.ours) - 1}: HIP vs ref max-abs {err:.2e} frac>1e-3 {frac:.2e} '
-               f'raw flips {flips} margin-aware mismatches {bad}')
-        if ref_perturbed is not None:
-            f_err, f_frac = self._stats(ref_perturbed, ref)
-            self.floor.append((f_err, f_frac))
-            msg += (f' | ref vs ref(1e-6 input noise) max-abs {f_err:.2e} frac>1e-3 {f_frac:.2e} '
-                    f'flips {int((ref_perturbed.argmax(0) != ref.argmax(0)).sum())}')
-        print(msg)
-        assert bad == 0, msg
-
-    def finish(self):
-        fl_err = max([e for e, _ in self.floor] + [0.0])
-        bound = max(1e-3, 10 * fl_err)
-        ours_err = max(e for e, _ in self.ours)
-        print(f'{self.tag}: clip max-abs {ours_err:.2e} (reference self-drift {fl_err:.2e}, bound {bound:.1e}); '
-              f'top-k selections differing from the reference: {self.flips} (all explained near-ties), first at frame '
-              f'{self.first_flip_frame}')
-        for t, (e, _) in enumerate(self.ours):
-            if e > bound:
-                assert self.first_flip_frame is not None and t >= self.first_flip_frame, \
-                    (f'{self.tag} frame {t}: error {e:.2e} above {bound:.1e} without a differing top-k selection '
-                     'at or before this frame')
-        assert ours_err <= 5e-2, (self.tag, ours_err)
+_margin_aware_mismatch = memory_audit.margin_aware_mismatch
+_Drift = memory_audit.Drift
 
 
 def _paired_clip(tag, stride, hip_frames, noisy_frames, hip_tap_marks, ref_tap_marks, hip_tap, ref_tap,

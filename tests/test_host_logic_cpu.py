@@ -96,6 +96,17 @@ def test_lockstep_teacher_forced_small(emu, recipe_state_dict):
     assert max(worst.values()) <= 2e-4, worst
 
 
+@pytest.mark.parametrize('name', ['lt_evict', 'two_buckets'])
+def test_memory_events_teacher_forced(emu, recipe_state_dict, name):
+    """host logic of consolidation / eviction / usage on the oracle's inputs (tests/memory_audit.py); the
+    same audit runs on the HIP kernels in tests/test_gpu_f_memory_events.py"""
+    import memory_audit
+    P, _ = recipe_state_dict
+    report = memory_audit.teacher_forced_memory(P, scenarios.E2E[name], torch.device('cpu'))
+    assert report['consolidations'] == 3 and report['evictions'] == (1 if name == 'lt_evict' else 0)
+    assert report['tie_swapped_queries'] == 0
+
+
 def test_store_views_follow_reference_layout(emu):
     from deva.inference.kv_memory_store import KeyValueMemoryStore
     st = KeyValueMemoryStore(save_selection=True, save_usage=True)

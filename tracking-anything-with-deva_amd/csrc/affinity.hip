@@ -15,20 +15,27 @@
 // the whole kernel, the key rows are read straight from the token-major bank and prefetched one
 // tile ahead (a 32x64 fp32 tile per 4096 matrix-pipe cycles -- operand traffic is irrelevant here,
 // the kernel is bound by the fp32 MFMA rate).  Per query the wave keeps a candidate list in LDS
-// (176 slots of 6 bytes) with its length and threshold in registers: scores >= the running lower bound
+// (LCAP slots of 6 bytes) with its length and threshold in registers: scores >= the running lower bound
 // of the k-th best are appended (~k*(1+ln(n/k)) appends per query over n tokens); a list that could
-// overflow is pruned to the entries >= the k-th largest of its 64 per-lane maxima (exact for the final
-// result, and the ballot-driven bisection runs over one key per lane).  grid.y splits the bank into
-// token ranges so small frames still fill 256 CUs; the ranges hand over their lists as they are and a
+// overflow is pruned to the entries >= the k-th largest of its 64 per-lane maxima (at least k entries
+// are >= that value, so the final result stays exact).  That k-th largest is found by rank counting
+// over the 64 lane values (64 independent readlane / compare / add triples, ~200 VALU issue slots)
+// instead of a ballot bisection, whose ~10-30 dependent VALU->SALU->branch round trips cost ~3 700
+// cycles per list and, at three prune rounds of 32 lists per range, a third of the kernel at the
+// N = 10 000 shape (round-1 profile).  grid.y splits the bank into token ranges so small frames still
+// fill the chip; every range hands over its (pruned, <= CAP entries) lists with their lengths and a
 // second kernel (one wave per query) selects the exact top-k over all ranges, applies exp/normalise
 // and accumulates the usage counters.
 //
 // Issue model that shaped the loop (tools/probe/README.md): VALU instructions do not overlap the
-// wave's own MFMAs, and only one wave per SIMD fits next to 136 KiB of lists -- so every VALU
-// instruction per tile is paid in full.  Hence: packed-fp32 scoring, rows filed only when some lane
-// passes (one ballot + one scalar branch per row otherwise), list positions from the ballot instead
-// of atomics, accumulators kept in VGPRs (-amdgpu-mfma-vgpr-form, see the Makefile), operand rows
-// loaded with a per-half-lane offset instead of being selected.
+// wave's own MFMAs (~4.5 cycles each with one wave per SIMD, ~2 with two), so the kernel comes in two
+// shapes: 176-slot lists with one workgroup per CU (long ranges: few prunes), and 100-slot lists with
+// two workgroups per CU (two waves per SIMD: the other wave's MFMAs run under this wave's scoring /
+// pruning).  Rows are filed only when some lane passes (one ballot + one scalar branch per row
+// otherwise), list positions come from the ballot instead of atomics, accumulators stay in VGPRs
+// (-amdgpu-mfma-vgpr-form, see the Makefile), operand rows are loaded with a per-half-lane offset
+// instead of being selected, and the scrambled tile order is advanced incrementally (a 64-bit modulo
+// per tile was ~300 scalar instructions on the critical path).
 #include <math.h>
 
 #include <type_traits>
@@ -47,13 +54,12 @@ typedef f32x4 f32x4_u __attribute__((aligned(4)));  // 16-B load from a dword-al
 
 constexpr int CK = 64;
 constexpr int QT = 32;            // queries per wave
-constexpr int CAP = 128;          // candidate slots per (range, query) handed to the merge kernel
-// in-kernel candidate lists: 176 slots of 6 bytes (order-preserving score bits + 16-bit token offset
-// inside the range).  A range of up to ~1 000 tokens then never has to prune (k*(1+ln(n/k)) appends
-// expected), and the merge kernel does the only exact selection.
-constexpr int LCAP = 176;
-constexpr int LSTRIDE = LCAP + 1;  // odd row stride: spreads the LDS banks
-constexpr int MAX_SPLITS = 16;    // splits * CAP <= 2048 = 64 lanes x 32 keys in the merge kernel
+constexpr int CAP = 64;           // candidate slots per (range, query) handed to the merge kernel (one per lane)
+// in-kernel candidate lists: LCAP slots of 6 bytes (order-preserving score bits + 16-bit token offset
+// inside the range); row stride LCAP + 1 (odd: spreads the LDS banks).
+constexpr int LCAP_WIDE = 176;    // one workgroup per CU (136 KiB of lists)
+constexpr int LCAP_DUAL = 100;    // two workgroups per CU (2 x 76 KiB)
+constexpr int MAX_SPLITS = 32;    // one 64-bit key per lane and range in the merge kernel
 constexpr int WAVES = 4;
 constexpr int TOKT = 32;          // tokens per tile
 
@@ -117,27 +123,86 @@ __device__ __forceinline__ uint64_t kth_largest(const uint64_t (&e)[E], int n_li
   return ((uint64_t)T << 32) | L;
 }
 
-// Prune one candidate list (wave-cooperative, 64 <= c <= 192 entries).  Threshold = the k-th largest of
-// the 64 per-lane maxima: at least k entries of the list are >= it, so nothing below it can belong to
-// the top-k -- the result stays exact while the bisection (what a prune costs) runs over one key per
-// lane instead of three.  Typically k .. 1.5k entries survive.  Returns the threshold key; *kept =
-// number of survivors (compacted to the front, unsorted).
-__device__ __forceinline__ uint64_t prune_list(uint32_t* sc, uint16_t* tk, uint32_t c, int k, int lane,
-                                               int* kept) {
-  uint64_t e[3];
+// Lower bound of the k-th largest of the 64 lane values `m` (order-preserving score bits, 0 = empty
+// lane; needs >= k non-empty lanes) by rank counting: the low 6 bits are replaced by the lane number so
+// that the values are unique, the 64 values go through a 256-B LDS scratch row, every lane reads them
+// back as 16 broadcast 16-B reads and counts the values above its own (128 independent compare / add
+// pairs -- no readlane hazards and no dependent VALU -> SALU -> branch chain as in a bisection), and the
+// lane of rank k-1 publishes its value with the low bits cleared: at least k lanes have m >= the result.
+__device__ __forceinline__ uint32_t kth_lane_value(uint32_t m, int k, int lane, uint32_t* scratch) {
+  const uint32_t u = (m & ~63u) | (uint32_t)lane;
+  scratch[lane] = u;
+  DEVA_COMPILER_FENCE();
+  int rank = 0;
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int j = 0; j < 16; ++j) {
+    const uint4 o = *reinterpret_cast<const uint4*>(scratch + 4 * j);
+    rank += (o.x > u) ? 1 : 0;
+    rank += (o.y > u) ? 1 : 0;
+    rank += (o.z > u) ? 1 : 0;
+    rank += (o.w > u) ? 1 : 0;
+  }
+  DEVA_COMPILER_FENCE();
+  const unsigned long long b = __ballot(rank == k - 1);  // exactly one lane: the values are unique
+  return (uint32_t)__builtin_amdgcn_readlane((int)u, __ffsll(b) - 1) & ~63u;
+}
+
+// Prune one candidate list (wave-cooperative, 64 <= c <= 64*E entries).  Threshold = (a lower bound of)
+// the k-th largest of the 64 per-lane maxima: at least k entries of the list are >= it, so nothing below
+// it can belong to the top-k -- the result stays exact.  At most E*k entries survive (k lanes hold a
+// maximum >= the threshold, each with <= E entries), typically k .. 1.5k.  Returns the threshold (score
+// bits); *kept = number of survivors (compacted to the front, unsorted).
+template <int E>
+__device__ __forceinline__ uint32_t prune_list(uint32_t* sc, uint16_t* tk, uint32_t c, int k, int lane, int* kept,
+                                               uint32_t* scratch) {
+  uint32_t e[E], t[E];
+  uint32_t m = 0u;
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    const uint32_t j = (uint32_t)lane + 64u * i;
+    e[i] = (j < c) ? sc[j] : 0u;
+    t[i] = (j < c) ? (uint32_t)tk[j] : 0u;
+    m = e[i] > m ? e[i] : m;
+  }
+  const uint32_t thr = kth_lane_value(m, k, lane, scratch);
+  DEVA_COMPILER_FENCE();
+  int base = 0;
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    const bool keep = e[i] >= thr && e[i] != 0u;
+    const unsigned long long b = __ballot(keep);
+    if (keep) {
+      const int w = base + prefix_below(b);
+      sc[w] = e[i];
+      tk[w] = (uint16_t)t[i];
+    }
+    base += __popcll(b);
+  }
+  DEVA_COMPILER_FENCE();
+  *kept = base;
+  return thr;
+}
+
+// Exact variant (slow path): threshold = the exact k-th largest of the 64 per-lane maxima of the UNIQUE
+// 64-bit keys (score bits, token), by ballot bisection.  Exactly k lanes hold a maximum >= it, so at
+// most E*k entries survive whatever the scores are -- including banks full of identical keys, where the
+// rank-counting prune (which compares 26 score bits) cannot separate anything.
+template <int E>
+__device__ __forceinline__ uint32_t prune_list_exact(uint32_t* sc, uint16_t* tk, uint32_t c, int k, int lane,
+                                                     int* kept) {
+  uint64_t e[E];
+  uint64_t m[1] = {0ull};
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
     const uint32_t j = (uint32_t)lane + 64u * i;
     e[i] = (j < c) ? (((uint64_t)sc[j] << 32) | (uint64_t)(0xffffu - tk[j])) : 0ull;
+    m[0] = e[i] > m[0] ? e[i] : m[0];
   }
-  uint64_t m[1] = {e[0]};
-  m[0] = e[1] > m[0] ? e[1] : m[0];
-  m[0] = e[2] > m[0] ? e[2] : m[0];
   const uint64_t thr = kth_largest<1>(m, 1, k);
   DEVA_COMPILER_FENCE();
   int base = 0;
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < E; ++i) {
     const bool keep = e[i] >= thr && e[i] != 0ull;
     const unsigned long long b = __ballot(keep);
     if (keep) {
@@ -149,7 +214,7 @@ __device__ __forceinline__ uint64_t prune_list(uint32_t* sc, uint16_t* tk, uint3
   }
   DEVA_COMPILER_FENCE();
   *kept = base;
-  return thr;
+  return (uint32_t)(thr >> 32);
 }
 
 struct AffArgs {
@@ -165,13 +230,21 @@ struct AffArgs {
   int k;
   int splits;
   int total_tiles;
-  uint64_t* part;
+  uint64_t* part;     // [splits][hw][CAP] candidate keys
+  uint32_t* part_cnt;  // [splits][hw] live entries of each list
 };
 
-__global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs p) {
+// LCAP: list slots per query; MINB: workgroups per CU the register / LDS budget is sized for
+template <int LCAP, int MINB>
+__global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const AffArgs p) {
+  constexpr int LSTRIDE = LCAP + 1;
+  constexpr int E = (LCAP + 63) / 64;  // list entries per lane in a prune
+  static_assert(LCAP - TOKT >= 64, "a list is pruned only when every lane holds an entry");
+  static_assert(LCAP < 65536 && CAP == 64, "hand-over: one key per lane");
   __shared__ uint32_t s_sc[WAVES][QT][LSTRIDE];  // candidate scores (order-preserving bits)
   __shared__ uint16_t s_tk[WAVES][QT][LSTRIDE];  // candidate tokens (offset inside this range)
   __shared__ __attribute__((aligned(16))) float s_ms[WAVES][TOKT];  // shrinkage / 8 of the current tile
+  __shared__ __attribute__((aligned(16))) uint32_t s_rank[WAVES][64];  // scratch row of the prune
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -218,7 +291,12 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
   const int n_my = (p.total_tiles - split + p.splits - 1) / p.splits;  // tiles of this range
   int stride = 61;  // a prime that does not divide n_my: c -> (c * stride) % n_my is a permutation
   if (n_my % 61 == 0) stride = (n_my % 59 == 0) ? 53 : 59;
-  auto tile_at = [&](int i) { return split + p.splits * (int)(((int64_t)i * stride) % n_my); };
+  // the cyclic index of visit i is (i * stride) % n_my, advanced by one conditional subtraction per tile
+  const int step = (n_my > 0) ? stride % n_my : 0;
+  auto advance = [&](int c) {
+    c += step;
+    return c >= n_my ? c - n_my : c;
+  };
   // candidate tokens are stored as 16 bits: (cyclic tile index << 5) | row
 
   // ---- per-query state in registers (the same value in both half-lanes of a query): list length and
@@ -234,7 +312,8 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
   // (a shifted read would touch the next row) and selected.
   f32x4 xbuf[CK / 4];
   float ms_buf;
-  auto prefetch = [&](int tile) {
+  auto prefetch = [&](int cyc) {
+    const int tile = split + p.splits * cyc;
     const int n_mine = min(tile * TOKT + l31, p.n_total - 1);
     const float* krow = (n_mine < p.n_long) ? (p.key_long + (int64_t)n_mine * CK)
                                             : (p.key_work + (int64_t)(n_mine - p.n_long) * CK);
@@ -245,29 +324,39 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
     for (int j = 0; j < CK / 4 - 1; ++j) xbuf[j] = *reinterpret_cast<const f32x4_u*>(shifted + 4 * j);
     xbuf[CK / 4 - 1] = *reinterpret_cast<const f32x4*>(krow + CK - 4);
   };
-  if (n_my > 0) prefetch(tile_at(0));
+  int cyc = 0;  // cyclic tile index of the current visit
+  if (n_my > 0) prefetch(cyc);
 
-  auto prune_over = [&](uint32_t limit) {
+  // fast = rank-counting prune first; the exact prune runs if that left the list above the limit (or
+  // alone if !fast).  One exact prune leaves <= E*k <= limit entries in the tile loop.
+  auto prune_over = [&](uint32_t limit, bool fast) {
     uint64_t need = __ballot(cnt > limit) & 0xffffffffull;
     while (need) {
       const int qq = __ffsll((unsigned long long)need) - 1;
       need &= need - 1;
       const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cnt, qq);
-      int kept;
-      const uint64_t thr = prune_list(csc + qq * LSTRIDE, ctk + qq * LSTRIDE, c, p.k, lane, &kept);
+      int kept = (int)c;
+      uint32_t thr = 0u;
+      if (fast) thr = prune_list<E>(csc + qq * LSTRIDE, ctk + qq * LSTRIDE, c, p.k, lane, &kept, &s_rank[wave][0]);
+      if ((uint32_t)kept > limit) {
+        const uint32_t thr2 =
+            prune_list_exact<E>(csc + qq * LSTRIDE, ctk + qq * LSTRIDE, (uint32_t)kept, p.k, lane, &kept);
+        thr = thr2 > thr ? thr2 : thr;
+      }
       if (l31 == qq) {
         cnt = (uint32_t)kept;
-        tau = from_orderable((uint32_t)(thr >> 32));
+        tau = from_orderable(thr);
       }
     }
   };
 
   for (int it = 0; it < n_my; ++it) {
-    const int tile = tile_at(it);
+    const int tile = split + p.splits * cyc;
     const int n_base = tile * TOKT;
+    const uint32_t tok0 = (uint32_t)(cyc * TOKT + 4 * half);
 
     // ---- prune lists that could overflow during this tile (at most 32 appends per query per tile)
-    prune_over((uint32_t)(LCAP - TOKT));
+    prune_over((uint32_t)(LCAP - TOKT), true);
 
     // ---- this tile's operand: channel 2t + half of this lane's token, then start the next loads
     float a_op[CK / 2];
@@ -280,7 +369,8 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
     a_op[CK / 2 - 1] = half ? xbuf[CK / 4 - 1][3] : xbuf[CK / 4 - 1][2];
     if (lane < TOKT) msl[lane] = ms_buf;
     DEVA_COMPILER_FENCE();
-    prefetch(tile_at(min(it + 1, n_my - 1)));
+    if (it + 1 < n_my) cyc = advance(cyc);
+    prefetch(cyc);
 
     f32x16 accA, accB;
 #pragma unroll
@@ -303,7 +393,6 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
 #pragma unroll
     for (int g = 0; g < 4; ++g) ms4[g] = *reinterpret_cast<const float4*>(&msl[8 * g + 4 * half]);
     const int rows_left = p.n_total - n_base;  // >= TOKT except in the last tile of the bank
-    const uint32_t tok0 = (uint32_t)(((tile - split) / p.splits) * TOKT + 4 * half);
     auto file_rows = [&](auto full) {
       constexpr bool full_tile = decltype(full)::value;
 #pragma unroll
@@ -342,34 +431,33 @@ __global__ __launch_bounds__(WAVES * 64) void affinity_topk_kernel(const AffArgs
     DEVA_COMPILER_FENCE();
   }
 
-  // ---- the candidate lists of this range go to global memory as they are (zero padded to CAP keys per
-  // query): the exact top-k selection over all ranges happens in the merge kernel, where one wave per
-  // query gives thousands of independent waves -- here it would run serially, 32 lists per wave.
-  // Only a list that outgrew the CAP hand-over slots is pruned first.
-  prune_over((uint32_t)CAP);
+  // ---- hand-over: every list is pruned to at most CAP = 64 entries (one per lane) and written with its
+  // length.  A rank-counting round first; exact rounds only for lists still above CAP (an exact round
+  // leaves <= 64 * ceil(c/64) * k / 64 entries: <= 3k from 176, <= 2k <= 64 from 96).  The exact top-k
+  // selection over all ranges happens in the merge kernel, where one wave per query gives thousands of
+  // independent waves -- here it would run serially, 32 lists per wave.
+  static_assert(LCAP <= 192, "two exact rounds must reach CAP");
+  prune_over((uint32_t)CAP, true);
+  prune_over((uint32_t)CAP, false);
   DEVA_COMPILER_FENCE();
   const int nq = min(QT, p.hw - q0);
   uint64_t* dst = p.part + ((int64_t)split * p.hw + q0) * CAP;
+  if (lane < nq) p.part_cnt[(int64_t)split * p.hw + q0 + lane] = cnt;  // lanes 0..31 hold query l31 = lane
   for (int ql = 0; ql < nq; ++ql) {
     const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cnt, ql);
-#pragma unroll
-    for (int i = 0; i < CAP / 64; ++i) {
-      const uint32_t r = (uint32_t)lane + 64u * i;
-      uint64_t key = 0ull;
-      if (r < c) {
-        const uint32_t off = (uint32_t)ctk[ql * LSTRIDE + r];
-        const uint32_t token = ((off >> 5) * (uint32_t)p.splits + (uint32_t)split) * TOKT + (off & 31u);
-        key = ((uint64_t)csc[ql * LSTRIDE + r] << 32) | (uint64_t)(~token);
-      }
-      dst[(int64_t)ql * CAP + r] = key;
+    if ((uint32_t)lane < c) {
+      const uint32_t off = (uint32_t)ctk[ql * LSTRIDE + lane];
+      const uint32_t token = ((off >> 5) * (uint32_t)p.splits + (uint32_t)split) * TOKT + (off & 31u);
+      dst[(int64_t)ql * CAP + lane] = ((uint64_t)csc[ql * LSTRIDE + lane] << 32) | (uint64_t)(~token);
     }
   }
 }
 
-// one wave per query: exact top-k of the splits*CAP candidate slots (ME keys per lane), sorted by
-// rank counting, then exp / normalise / usage
+// one wave per query: exact top-k over the candidate lists of all ranges (lane l holds entry l of every
+// range's list: ME >= splits keys per lane), sorted by rank counting, then exp / normalise / usage
 template <int ME>
-__global__ __launch_bounds__(256) void affinity_finalize_kernel(const uint64_t* __restrict__ part, int hw, int k,
+__global__ __launch_bounds__(256) void affinity_finalize_kernel(const uint64_t* __restrict__ part,
+                                                                const uint32_t* __restrict__ part_cnt, int hw, int k,
                                                                 int splits, int32_t* __restrict__ idx,
                                                                 float* __restrict__ weight,
                                                                 unsigned long long* __restrict__ usage_fix) {
@@ -381,16 +469,14 @@ __global__ __launch_bounds__(256) void affinity_finalize_kernel(const uint64_t* 
   volatile uint64_t* unsorted = &s_buf[wave][0][0];
   volatile uint64_t* sorted = &s_buf[wave][1][0];
 
-  const int total = splits * CAP;
-  const int n_live = (total + 63) >> 6;
+  const int n_live = splits;
   uint64_t e[ME];
 #pragma unroll
   for (int i = 0; i < ME; ++i) {
-    const int c = lane + 64 * i;
     uint64_t v = 0ull;
-    if (c < total) {
-      const int sp = c / CAP;
-      v = part[((int64_t)sp * hw + q) * CAP + (c - sp * CAP)];
+    if (i < splits) {
+      const int64_t list = (int64_t)i * hw + q;
+      if ((uint32_t)lane < part_cnt[list]) v = part[list * CAP + lane];
     }
     e[i] = v;
   }
@@ -503,19 +589,37 @@ using namespace deva;
 
 extern "C" int64_t deva_affinity_workspace(int hw, int k, int splits) {
   (void)k;
-  return (int64_t)splits * hw * CAP;  // one zero-padded candidate list per (range, query)
+  // [splits][hw][CAP] 64-bit candidate keys, then [splits][hw] 32-bit list lengths
+  return (int64_t)splits * hw * CAP + ((int64_t)splits * hw + 1) / 2;
+}
+
+// 0: pick by shape; 1: 176-slot lists, one workgroup per CU; 2: 100-slot lists, two workgroups per CU
+static int affinity_shape_override() {
+  static const int v = [] {
+    const char* e = getenv("DEVA_AFFINITY_SHAPE");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+
+static bool affinity_dual(int n_total, int hw) {
+  (void)n_total;
+  (void)hw;
+  const int o = affinity_shape_override();
+  return o == 0 ? true : o == 2;
 }
 
 extern "C" int deva_affinity_default_splits(int n_total, int hw) {
-  // one 4-wave workgroup per CU is resident (133 KB of candidate lists): aim at ~256 workgroups
+  // aim at one resident set of workgroups: 256 CUs x (1 or 2) four-wave workgroups
+  const int slots = affinity_dual(n_total, hw) ? 512 : 256;
   const int qblocks = (int)ceil_div(hw, WAVES * QT);
   const int tiles = (int)ceil_div(n_total, TOKT);
-  int s = (int)ceil_div(256, qblocks);
+  int s = (int)ceil_div(slots, qblocks);
   if (s > tiles / 4) s = tiles / 4;  // keep >= 4 tiles (128 tokens) per range
   if (s > MAX_SPLITS) s = MAX_SPLITS;
   if (s < 1) s = 1;
   // small banks (first memory frames of a clip): ranges of <= CAP tokens hand every score over without
-  // building a threshold or pruning (a prune round of 32 lists costs ~50 us, measured)
+  // building a threshold or pruning
   const int s_nofilter = (int)ceil_div(tiles, CAP / TOKT);
   if (s_nofilter <= MAX_SPLITS && s_nofilter > s) s = s_nofilter;
   while (s < MAX_SPLITS && ceil_div(tiles, s) > 2047) ++s;  // 16-bit token offsets inside a range
@@ -552,8 +656,13 @@ extern "C" int deva_affinity_topk(const float* key_long, const float* shr_long, 
                "deva_affinity_topk: %d tokens per range exceed the 16-bit in-range token offset; use more splits",
                (int)ceil_div(a.total_tiles, splits) * TOKT);
   a.part = part_keys;
+  a.part_cnt = reinterpret_cast<uint32_t*>(part_keys + (int64_t)splits * hw * CAP);
   dim3 grid((unsigned)ceil_div(hw, WAVES * QT), (unsigned)splits);
-  hipLaunchKernelGGL(affinity_topk_kernel, grid, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
+  if (affinity_dual((int)n_total, hw)) {
+    hipLaunchKernelGGL((affinity_topk_kernel<LCAP_DUAL, 2>), grid, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
+  } else {
+    hipLaunchKernelGGL((affinity_topk_kernel<LCAP_WIDE, 1>), grid, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
+  }
   return check_launch("deva_affinity_topk");
 }
 
@@ -562,12 +671,20 @@ extern "C" int deva_affinity_finalize(const uint64_t* part_keys, int hw, int k, 
   DEVA_REQUIRE(part_keys && idx && weight && hw > 0, "deva_affinity_finalize: bad args");
   DEVA_REQUIRE(k >= 1 && k <= 32 && splits >= 1 && splits <= MAX_SPLITS,
                "deva_affinity_finalize: k/splits out of range");
-  if (splits * CAP <= 64 * 8) {
-    hipLaunchKernelGGL(affinity_finalize_kernel<8>, dim3((unsigned)ceil_div(hw, 4)), dim3(256), 0,
-                       (hipStream_t)stream, part_keys, hw, k, splits, idx, weight, (unsigned long long*)usage_fix);
+  const uint32_t* cnt = reinterpret_cast<const uint32_t*>(part_keys + (int64_t)splits * hw * CAP);
+  const dim3 grid((unsigned)ceil_div(hw, 4));
+  if (splits <= 4) {
+    hipLaunchKernelGGL(affinity_finalize_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, part_keys, cnt, hw, k,
+                       splits, idx, weight, (unsigned long long*)usage_fix);
+  } else if (splits <= 8) {
+    hipLaunchKernelGGL(affinity_finalize_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, part_keys, cnt, hw, k,
+                       splits, idx, weight, (unsigned long long*)usage_fix);
+  } else if (splits <= 16) {
+    hipLaunchKernelGGL(affinity_finalize_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, part_keys, cnt, hw, k,
+                       splits, idx, weight, (unsigned long long*)usage_fix);
   } else {
-    hipLaunchKernelGGL(affinity_finalize_kernel<32>, dim3((unsigned)ceil_div(hw, 4)), dim3(256), 0,
-                       (hipStream_t)stream, part_keys, hw, k, splits, idx, weight, (unsigned long long*)usage_fix);
+    hipLaunchKernelGGL(affinity_finalize_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, part_keys, cnt, hw, k,
+                       splits, idx, weight, (unsigned long long*)usage_fix);
   }
   return check_launch("deva_affinity_finalize");
 }

@@ -125,9 +125,11 @@ _WORKSPACE_ELEMS = 16 * 1024 * 1024  # 64 MB of split-K scratch per device
 
 
 def _workspace(device) -> torch.Tensor:
-    ws = _WORKSPACE.get(device)
+    """split-K scratch, one per (device, stream): launches on different streams never share partial sums"""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WORKSPACE.get(key)
     if ws is None:
-        ws = _WORKSPACE[device] = torch.empty(_WORKSPACE_ELEMS, dtype=torch.float32, device=device)
+        ws = _WORKSPACE[key] = torch.empty(_WORKSPACE_ELEMS, dtype=torch.float32, device=device)
     return ws
 
 
@@ -280,6 +282,20 @@ def gru_update(values: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------ memory read
+_AFF_WS = {}
+
+
+def _affinity_workspace(elems: int, device) -> torch.Tensor:
+    """hand-over buffer between the two affinity kernels, kept alive (grow-only) per device and stream:
+    deva_affinity_topk rewrites every list length and the live part of every list before
+    deva_affinity_finalize reads them"""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _AFF_WS.get(key)
+    if ws is None or ws.numel() < elems:
+        ws = _AFF_WS[key] = torch.empty((max(elems, 1 << 20),), dtype=torch.int64, device=device)
+    return ws
+
+
 def affinity_topk(key_long, shr_long, n_long: int, key_work, shr_work, n_work: int, qk: torch.Tensor,
                   qe: torch.Tensor, k: int, usage_fix: Optional[torch.Tensor] = None,
                   splits: Optional[int] = None):
@@ -292,7 +308,7 @@ def affinity_topk(key_long, shr_long, n_long: int, key_work, shr_work, n_work: i
     L = lib()
     if splits is None:
         splits = L.deva_affinity_default_splits(n_long + n_work, hw)
-    part = torch.empty((L.deva_affinity_workspace(hw, k, splits),), dtype=torch.int64, device=qk.device)
+    part = _affinity_workspace(L.deva_affinity_workspace(hw, k, splits), qk.device)
     check(L.deva_affinity_topk(_p(key_long) if n_long else None, _p(shr_long) if n_long else None, n_long,
                                _p(key_work) if n_work else None, _p(shr_work) if n_work else None, n_work,
                                _p(qk), _p(qe), hw, k, splits, _p(part, torch.int64), _stream()),

@@ -74,3 +74,29 @@ def stage_inputs(height: int, width: int, num_objects: int, seed: int = 3):
     sensory = torch.randn(1, num_objects, 512, h, w, generator=g) * 0.5
     readout = torch.randn(1, num_objects, 512, h, w, generator=g) * 0.5
     return masks, sensory, readout
+
+
+def prefill_bank(n: int, objects: List[int], seed: int = 1, ck: int = 64, cv: int = 512):
+    """long-term bank contents mk~N(0,1) [ck,n], ms~U(1,2) [1,n],
+    values~N(0,1) {obj: [cv,n]}, to be appended through the store's own `add(key, values, shrinkage,
+    None, <bucket 0>)` after the first frame has created bucket 0."""
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    key = torch.randn(ck, n, generator=g)
+    shr = torch.rand(1, n, generator=g) + 1.0
+    values = {o: torch.randn(cv, n, generator=g) for o in objects}
+    return key, shr, values
+
+
+def detection_frame(height: int, width: int, t: int, segments: int = 1):
+    """Synthetic precomputed detection of frame t (BASELINE configs[2], eval_with_detections style):
+    an index mask with `segments` boxes that drift 2 px per frame, ids 10, 20, ..., and their
+    segments_info dicts (alternating thing / stuff, category = id // 10)."""
+    m = torch.zeros(height, width, dtype=torch.long)
+    info = []
+    bh, bw = height // 4, width // (2 * segments + 2)
+    for s in range(segments):
+        y0 = (height // 8) + (s % 2) * (height // 2)
+        x0 = (2 * s + 1) * bw // 1 + 2 * t
+        m[y0:y0 + bh, x0:x0 + bw] = 10 * (s + 1)
+        info.append(dict(id=10 * (s + 1), category_id=s + 1, isthing=(s % 2 == 0)))
+    return m, info
