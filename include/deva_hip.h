@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DEVA_HIP_ABI_VERSION 1
+#define DEVA_HIP_ABI_VERSION 2
 
 int deva_hip_version(void);
 const char* deva_hip_last_error(void);
@@ -110,10 +110,12 @@ int deva_area_downsample(const float* in, float* out, int64_t planes, int height
  * (u/255 - mean)/std per channel and, when the size differs, the resize of the readers:
  * antialias != 0: transforms.Resize(..., BILINEAR, antialias=True) (deva/inference/data/video_reader.py:139-144,
  * detection_video_reader.py:63-71); antialias == 0: F.interpolate(bilinear, align_corners=False)
- * (deva/inference/demo_utils.py:10-19).  mean3 / std3 are HOST pointers to three floats. */
+ * (deva/inference/demo_utils.py:10-19).  mean3 / std3 are HOST pointers to three floats.
+ * The zero padding of pad_divide_by (deva/utils/tensor_utils.py:7-22) is fused: out is
+ * [3][pad_top + out_height + pad_bottom][pad_left + out_width + pad_right] with a zero border. */
 int deva_input_head(const unsigned char* image_hwc, int height, int width, const float* mean3,
                     const float* std3, int antialias, float* out, int out_height, int out_width,
-                    void* stream);
+                    int pad_left, int pad_right, int pad_top, int pad_bottom, void* stream);
 
 /* DEVA.aggregate (network.py:33-40) over `num` object planes of `pixels` each:
  * p = apply_sigmoid ? sigmoid(in) : in;  out[0] = logit(clamp(prod(1-p)));  out[i+1] = logit(clamp(p_i)).

@@ -252,13 +252,14 @@ def index_mask(prob, size=None, lut=None):
     return idx if lut is None else lut_remap(idx, lut)
 
 
-def input_head(image_u8, size=None, *, antialias=True, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+def input_head(image_u8, size=None, *, antialias=True, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225),
+               pad=(0, 0, 0, 0)):
     import torch.nn.functional as F
     x = image_u8.permute(2, 0, 1).float() / 255
     x = (x - torch.tensor(mean).view(3, 1, 1)) / torch.tensor(std).view(3, 1, 1)
     if size is not None and tuple(size) != tuple(x.shape[-2:]):
         x = F.interpolate(x.unsqueeze(0), tuple(size), mode='bilinear', align_corners=False, antialias=antialias)[0]
-    return x
+    return F.pad(x, tuple(pad))
 
 
 def install(monkeypatch):

@@ -108,3 +108,12 @@ def test_input_head(h, w, size, aa):
     got = ops.input_head(to_dev(img), size, antialias=aa)
     assert tuple(got.shape) == tuple(want.shape)
     _check(f'input_head {h}x{w}->{size} aa={aa}', got, want, 3e-6)
+    # fused pad_divide_by: same pixels inside an exactly zero border
+    pad = (3, 4, 1, 2)
+    padded = ops.input_head(to_dev(img), size, antialias=aa, pad=pad)
+    want_p = emu_ops.input_head(img, size, antialias=aa, pad=pad)
+    assert tuple(padded.shape) == tuple(want_p.shape)
+    assert torch.equal(padded[:, 1:padded.shape[1] - 2, 3:padded.shape[2] - 4], got)
+    border = padded.clone()
+    border[:, 1:padded.shape[1] - 2, 3:padded.shape[2] - 4] = 0
+    assert (border == 0).all()

@@ -295,6 +295,29 @@ def test_edge_paths_match_reference(emu, golden_dir, recipe_state_dict):
     _check_edge_cases(got, torch.load(os.path.join(golden_dir, 'edge_cases.pt')), 1e-3)
 
 
+def test_soft_annotation_on_engaged_memory_and_top_k_validation(emu, recipe_state_dict):
+    """(a) an incomplete SOFT annotation while objects are already tracked -- the path the reference
+    crashes on (TypeError in inference_core.py:255) -- blends by values and by annotation position;
+    (b) an unsupported top_k is rejected when the memory is configured, not at the first read mid-clip"""
+    from deva.inference.inference_core import DEVAInferenceCore
+    from deva.inference.memory_manager import MemoryManager
+    net = _network(recipe_state_dict)
+    core = DEVAInferenceCore(net, synth.base_config(mem_every=2))
+    stream = synth.FrameStream(96, 128, seed=3)
+    core.step(stream.next(), synth.box_mask(96, 128, 2), [1, 2])
+    core.step(stream.next())
+    soft = torch.zeros(1, 96, 128)
+    soft[0, 60:90, 10:40] = 0.9
+    prob = core.step(stream.next(), soft, [7], hard_mask=False)
+    assert tuple(prob.shape) == (4, 96, 128) and core.object_manager.all_obj_ids == [1, 2, 7]
+    assert (prob[3, 60:90, 10:40] > 0.5).all() and (prob[1:3, 60:90, 10:40] < 0.5).all()
+    assert core.step(stream.next()).shape[0] == 4
+    with pytest.raises(ValueError, match='top_k'):
+        MemoryManager(synth.base_config(top_k=50))
+    with pytest.raises(ValueError, match='top_k'):
+        core.memory.update_config(synth.base_config(top_k=0, mem_every=2))
+
+
 def test_prob_to_obj_cls_equals_the_drivers_tail(emu):
     """ObjectManager.prob_to_obj_cls == argmax -> tmp_to_obj_cls (and the resized variant)"""
     import torch.nn.functional as F
@@ -309,15 +332,41 @@ def test_prob_to_obj_cls_equals_the_drivers_tail(emu):
 
 
 def test_frame_to_network_input_shapes(emu, monkeypatch):
-    """host side of the device input head: size rule of the readers (shorter side -> min_side)"""
+    """host side of the device input head: the readers' size rule (torchvision `Resize(size)`: shorter
+    side == size exactly, longer side int(size * long / short); video_reader.py:139-144), the demo's rule
+    (demo_utils.py:10-19) and the fused pad_divide_by"""
     import numpy as np
     from deva.utils import tensor_utils as TU
     monkeypatch.setattr(torch.Tensor, 'cuda', lambda self, *a, **k: self)
     monkeypatch.setattr(torch.Tensor, 'is_cuda', property(lambda self: True))
-    frame = np.random.RandomState(0).randint(0, 256, (72, 128, 3), dtype=np.uint8)
+    # known torchvision answers
+    for (h, w), want in {(427, 640): (480, 719), (640, 427): (719, 480), (480, 854): (480, 854),
+                         (720, 1280): (480, 853), (1080, 1920): (480, 853), (2160, 3840): (480, 853),
+                         (352, 500): (480, 681), (358, 640): (480, 858)}.items():
+        assert TU.network_input_size(h, w, 480) == want, (h, w)
+    # sweep: the shorter side is always exactly `size` (it came out as size-1 for 214 values in 200..2200 before)
+    for short in range(200, 2201):
+        for long_ in (short, short + 1, int(short * 1.5), short * 16 // 9):
+            oh, ow = TU.network_input_size(short, long_, 480)
+            assert oh == 480 and ow == (long_ if short == 480 else int(480 * long_ / short)), (short, long_)
+            assert TU.network_input_size(long_, short, 480) == (ow, oh)
+    assert TU.network_input_size(427, 640, 480, antialias=False) == (479, 719)  # the demo truncates both sides
+    assert TU.network_input_size(427, 640, -1) == (427, 640)
+    rs = np.random.RandomState(0)
+    frame = rs.randint(0, 256, (72, 128, 3), dtype=np.uint8)
     out = TU.frame_to_network_input(frame, 48)
     assert tuple(out.shape) == (3, 48, 85) and out.dtype == torch.float32
     assert tuple(TU.frame_to_network_input(frame).shape) == (3, 72, 128)
+    # fused padding == pad_divide_by of the unpadded result, and step() then has nothing left to pad
+    for shape, side in (((72, 128, 3), 48), ((50, 70, 3), -1), ((64, 96, 3), -1), ((427, 640, 3), 100)):
+        frame = rs.randint(0, 256, shape, dtype=np.uint8)
+        plain = TU.frame_to_network_input(frame, side)
+        fused, pad = TU.frame_to_network_input(frame, side, pad_to=16)
+        want, want_pad = TU.pad_divide_by(plain, 16)
+        assert tuple(pad) == tuple(want_pad) and torch.equal(fused, want)
+        again, no_pad = TU.pad_divide_by(fused, 16)
+        assert no_pad == (0, 0, 0, 0) and again.data_ptr() == fused.data_ptr()
+        assert torch.equal(TU.unpad(fused, pad), plain)
 
 
 def test_read_memory_matches_reference(emu, golden_dir, recipe_state_dict):

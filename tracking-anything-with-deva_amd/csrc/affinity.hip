@@ -59,6 +59,7 @@ constexpr int CAP = 64;           // candidate slots per (range, query) handed t
 // inside the range); row stride LCAP + 1 (odd: spreads the LDS banks).
 constexpr int LCAP_WIDE = 176;    // one workgroup per CU (136 KiB of lists)
 constexpr int LCAP_DUAL = 100;    // two workgroups per CU (2 x 76 KiB)
+constexpr int K_MAX = 32;          // top-k supported by the list / hand-over sizing below
 constexpr int MAX_SPLITS = 32;    // one 64-bit key per lane and range in the merge kernel
 constexpr int WAVES = 4;
 constexpr int TOKT = 32;          // tokens per tile
@@ -241,6 +242,8 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
   constexpr int E = (LCAP + 63) / 64;  // list entries per lane in a prune
   static_assert(LCAP - TOKT >= 64, "a list is pruned only when every lane holds an entry");
   static_assert(LCAP < 65536 && CAP == 64, "hand-over: one key per lane");
+  static_assert(E * K_MAX <= LCAP - TOKT, "one exact prune (<= E*k survivors) must get below the in-loop limit");
+  static_assert(2 * K_MAX <= CAP, "an exact prune of a two-entries-per-lane list must fit the hand-over");
   __shared__ uint32_t s_sc[WAVES][QT][LSTRIDE];  // candidate scores (order-preserving bits)
   __shared__ uint16_t s_tk[WAVES][QT][LSTRIDE];  // candidate tokens (offset inside this range)
   __shared__ __attribute__((aligned(16))) float s_ms[WAVES][TOKT];  // shrinkage / 8 of the current tile
@@ -633,7 +636,7 @@ extern "C" int deva_affinity_topk(const float* key_long, const float* shr_long, 
   DEVA_REQUIRE(n_long >= 0 && n_work >= 0, "deva_affinity_topk: negative bank size");
   DEVA_REQUIRE(n_long == 0 || (key_long && shr_long), "deva_affinity_topk: null long-term segment");
   DEVA_REQUIRE(n_work == 0 || (key_work && shr_work), "deva_affinity_topk: null working segment");
-  DEVA_REQUIRE(k >= 1 && k <= 32, "deva_affinity_topk: k=%d unsupported (1..32)", k);
+  DEVA_REQUIRE(k >= 1 && k <= K_MAX, "deva_affinity_topk: k=%d unsupported (1..%d)", k, K_MAX);
   const int64_t n_total = (int64_t)n_long + n_work;
   DEVA_REQUIRE(n_total >= k, "deva_affinity_topk: selected index k out of range (bank has %lld tokens, k=%d)",
                (long long)n_total, k);
@@ -669,7 +672,7 @@ extern "C" int deva_affinity_topk(const float* key_long, const float* shr_long, 
 extern "C" int deva_affinity_finalize(const uint64_t* part_keys, int hw, int k, int splits, int32_t* idx,
                                       float* weight, uint64_t* usage_fix, void* stream) {
   DEVA_REQUIRE(part_keys && idx && weight && hw > 0, "deva_affinity_finalize: bad args");
-  DEVA_REQUIRE(k >= 1 && k <= 32 && splits >= 1 && splits <= MAX_SPLITS,
+  DEVA_REQUIRE(k >= 1 && k <= K_MAX && splits >= 1 && splits <= MAX_SPLITS,
                "deva_affinity_finalize: k/splits out of range");
   const uint32_t* cnt = reinterpret_cast<const uint32_t*>(part_keys + (int64_t)splits * hw * CAP);
   const dim3 grid((unsigned)ceil_div(hw, 4));

@@ -298,6 +298,7 @@ __global__ void gru_update_kernel(const float* __restrict__ values, const float*
 struct HeadArgs {
   const unsigned char* img;
   int h, w, oh, ow, antialias;
+  int pad_left, pad_top, ph, pw;  // the resized frame sits at (pad_top, pad_left) of a zeroed ph x pw plane
   float mean[3], stdv[3];
   float* out;
 };
@@ -330,11 +331,14 @@ __global__ void input_head_kernel(const HeadArgs p) {
   }
   __syncthreads();
   const float sy = (float)p.h / (float)p.oh, sx = (float)p.w / (float)p.ow;
-  const int64_t total = (int64_t)p.oh * p.ow;
+  const int64_t total = (int64_t)p.ph * p.pw;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int y = (int)(i / p.ow), x = (int)(i - (int64_t)y * p.ow);
+    const int py = (int)(i / p.pw), px_ = (int)(i - (int64_t)py * p.pw);
+    const int y = py - p.pad_top, x = px_ - p.pad_left;
     float r[3];
-    if (p.oh == p.h && p.ow == p.w) {
+    if (y < 0 || y >= p.oh || x < 0 || x >= p.ow) {
+      r[0] = r[1] = r[2] = 0.0f;  // pad_divide_by's zero border (tensor_utils.py:7-22), fused
+    } else if (p.oh == p.h && p.ow == p.w) {
       const unsigned char* px = p.img + ((int64_t)y * p.w + x) * 3;
       for (int c = 0; c < 3; ++c) r[c] = lut[c][px[c]];
     } else if (p.antialias) {
@@ -478,10 +482,11 @@ extern "C" int deva_gru_update(const float* values, const float* h, float* new_h
 
 extern "C" int deva_input_head(const unsigned char* image_hwc, int height, int width, const float* mean3,
                                const float* std3, int antialias, float* out, int out_height, int out_width,
-                               void* stream) {
+                               int pad_left, int pad_right, int pad_top, int pad_bottom, void* stream) {
   using namespace deva;
   DEVA_REQUIRE(image_hwc && mean3 && std3 && out && height > 0 && width > 0 && out_height > 0 && out_width > 0,
                "deva_input_head: bad args");
+  DEVA_REQUIRE(pad_left >= 0 && pad_right >= 0 && pad_top >= 0 && pad_bottom >= 0, "deva_input_head: negative pad");
   // the antialias filter holds at most 24 taps per axis: shrink factors up to 11
   DEVA_REQUIRE(!antialias || ((float)height / out_height <= 11.0f && (float)width / out_width <= 11.0f),
                "deva_input_head: shrink factor above 11 is not supported with antialias");
@@ -492,11 +497,15 @@ extern "C" int deva_input_head(const unsigned char* image_hwc, int height, int w
   a.oh = out_height;
   a.ow = out_width;
   a.antialias = antialias;
+  a.pad_left = pad_left;
+  a.pad_top = pad_top;
+  a.ph = out_height + pad_top + pad_bottom;
+  a.pw = out_width + pad_left + pad_right;
   for (int c = 0; c < 3; ++c) {
     a.mean[c] = mean3[c];
     a.stdv[c] = std3[c];
   }
   a.out = out;
-  hipLaunchKernelGGL(input_head_kernel, grid_for((int64_t)out_height * out_width), dim3(TPB), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(input_head_kernel, grid_for((int64_t)a.ph * a.pw), dim3(TPB), 0, (hipStream_t)stream, a);
   return check_launch("deva_input_head");
 }

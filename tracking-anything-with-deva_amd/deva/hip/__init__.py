@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdeva_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQUARE_PLUS_ONE = 0, 1, 2, 3
 KLAYOUT_TAP_MAJOR, KLAYOUT_CHUNK32 = 0, 1
@@ -72,7 +72,7 @@ SIGNATURES = {
     'deva_label_histogram': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p]),
     'deva_lut_remap': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     'deva_input_head': (c_int, [c_void_p, c_int, c_int, POINTER(c_float), POINTER(c_float), c_int, c_void_p, c_int, c_int,
-                                c_void_p]),
+                                c_int, c_int, c_int, c_int, c_void_p]),
     'deva_index_mask': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     'deva_merge_paint': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_int, c_int64, c_void_p, c_void_p]),

@@ -457,16 +457,18 @@ IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 
 
 def input_head(image_u8: torch.Tensor, size: Optional[Tuple[int, int]] = None, *, antialias: bool = True,
-               mean=IMAGENET_MEAN, std=IMAGENET_STD) -> torch.Tensor:
-    """uint8 [H,W,3] frame on the device -> normalised fp32 [3,OH,OW] (ToTensor + Normalize + Resize)"""
+               mean=IMAGENET_MEAN, std=IMAGENET_STD, pad: Tuple[int, int, int, int] = (0, 0, 0, 0)) -> torch.Tensor:
+    """uint8 [H,W,3] frame on the device -> normalised fp32 [3,OH,OW] (ToTensor + Normalize + Resize), placed
+    inside a zero border `pad` = (left, right, top, bottom) (pad_divide_by fused)"""
     import ctypes
     if image_u8.dtype != torch.uint8 or image_u8.dim() != 3 or image_u8.shape[2] != 3:
         raise DevaHipError('input_head: expects a uint8 [H, W, 3] frame')
     h, w = image_u8.shape[:2]
     oh, ow = (h, w) if size is None else (int(size[0]), int(size[1]))
-    out = _alloc((3, oh, ow), image_u8.device)
+    left, right, top, bottom = (int(v) for v in pad)
+    out = _alloc((3, oh + top + bottom, ow + left + right), image_u8.device)
     m = (ctypes.c_float * 3)(*mean)
     sd = (ctypes.c_float * 3)(*std)
     check(lib().deva_input_head(_p(image_u8, torch.uint8, 'image'), h, w, m, sd, int(antialias), _p(out), oh, ow,
-                                _stream()), 'deva_input_head')
+                                left, right, top, bottom, _stream()), 'deva_input_head')
     return out

@@ -127,7 +127,8 @@ class DEVAInferenceCore:
         new_mask, _ = pad_divide_by(new_mask, 16)
 
         if forward_mask is None:
-            forward_mask = (torch.argmax(self._segment(key, selection, ms_features), dim=0)
+            # argmax over the propagated probabilities in one pass (the output-tail kernel without resize / LUT)
+            forward_mask = (ops.index_mask(self._segment(key, selection, ms_features).contiguous())
                             if self.memory.engaged else torch.zeros_like(new_mask))
 
         merged = match_and_merge(forward_mask, new_mask, self.object_manager, segments_info,
@@ -148,13 +149,16 @@ class DEVAInferenceCore:
                           new_tmp_ids: List[int], hard_mask: bool) -> torch.Tensor:
         """an annotation that covers only some objects on top of the propagated prediction
         ((no+1)*H*W): annotated pixels win, channels of newly introduced objects are appended
-        (inference_core.py:251-272, including its channel indexing)"""
+        (inference_core.py:251-272, including its channel indexing).  For soft masks the reference
+        compares the (values, indices) pair of `mask.max(0)` with 0.5 and indexes the annotation by tmp
+        id (a TypeError on every call); here the values are compared and channel `pos` of the annotation
+        is taken, which is what that code means."""
         fg = prediction[1:]
-        annotated = (mask > 0) if hard_mask else (mask.max(0) > 0.5)
+        annotated = (mask > 0) if hard_mask else (mask.max(0).values > 0.5)
         fg[:, annotated] = 0
         appended = []
         for pos, tmp_id in enumerate(new_tmp_ids):
-            channel = (mask == objects[pos]).type_as(fg) if hard_mask else mask[tmp_id]
+            channel = (mask == objects[pos]).type_as(fg) if hard_mask else mask[pos].type_as(fg)
             if tmp_id < fg.shape[0]:
                 fg[tmp_id + 1] = channel
             else:

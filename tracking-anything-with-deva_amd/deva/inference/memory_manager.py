@@ -30,9 +30,18 @@ class MemoryManager:
     Manages all three memory stores and the transition between working/long-term memory
     """
 
+    MAX_TOP_K = 32  # the fused affinity kernel keeps one candidate per lane pair: 1 <= top_k <= 32
+
+    @classmethod
+    def _checked_top_k(cls, top_k) -> int:
+        if top_k is None or not 1 <= int(top_k) <= cls.MAX_TOP_K:
+            raise ValueError(f'top_k={top_k} is not supported by the HIP memory read (1..{cls.MAX_TOP_K}; the '
+                             'reference default is 30)')
+        return int(top_k)
+
     def __init__(self, config: Dict):
         self.sensory_dim = config['value_dim']
-        self.top_k = config['top_k']
+        self.top_k = self._checked_top_k(config['top_k'])
         self.use_long_term = config['enable_long_term']
         self.count_long_term_usage = config['enable_long_term_count_usage']
         self.chunk_size = config['chunk_size']
@@ -66,7 +75,7 @@ class MemoryManager:
         # memory_manager.py:47-62
         self.config_stale = True
         self.sensory_dim = config['value_dim']
-        self.top_k = config['top_k']
+        self.top_k = self._checked_top_k(config['top_k'])
         assert self.use_long_term == config['enable_long_term'], 'cannot update this'
         assert self.count_long_term_usage == config['enable_long_term_count_usage'], 'cannot update this'
         if self.use_long_term:
