@@ -178,6 +178,18 @@ int deva_affinity_topk(const float* key_long, const float* shr_long, int n_long,
                        uint64_t* part_keys, void* stream);
 int deva_affinity_finalize(const uint64_t* part_keys, int hw, int k, int splits, int32_t* idx,
                            float* weight, uint64_t* usage_fix, void* stream);
+/* Token-sharded bank (one shard of the memory per GPU, SURVEY.md 8e "shard the bank"):
+ * deva_affinity_select turns a shard's candidate lists (output of deva_affinity_topk run on that shard's
+ *   rows) into the shard's own sorted top-k in the same hand-over format -- out_keys [hw][64] (first k
+ *   entries of each list live), out_counts [hw] -- with every token index shifted by token_offset (the
+ *   shard's first row in the global long-then-work index space).
+ * deva_affinity_merge is step 2 on explicit buffers: keys [lists][hw][64], counts [lists][hw] -- the
+ *   all-gathered out_keys / out_counts of every shard.  Since each shard's top-k contains every member of
+ *   the global top-k that lives on it, the merged result is bit-identical to the unsharded read. */
+int deva_affinity_select(const uint64_t* part_keys, int hw, int k, int splits, int64_t token_offset,
+                         uint64_t* out_keys, uint32_t* out_counts, void* stream);
+int deva_affinity_merge(const uint64_t* keys, const uint32_t* counts, int hw, int k, int lists, int32_t* idx,
+                        float* weight, uint64_t* usage_fix, void* stream);
 /* workspace query: number of uint64 elements part_keys must hold */
 int64_t deva_affinity_workspace(int hw, int k, int splits);
 /* splits the library would pick for a bank/query size (>= 1) */
@@ -191,10 +203,12 @@ int deva_usage_update(uint64_t* usage_fix, int64_t offset, float* use, float* li
 
 /* MemoryManager._readout (memory_manager.py:64-75) in sparse form, one object per call:
  * out[c][q] = sum_j weight[q][j] * value(idx[q][j])[c], value rows token-major [n][cv] in the
- * same long-then-work index space.  out is [cv][hw] (an NCHW plane stack). */
+ * same long-then-work index space.  out is [cv][hw] (an NCHW plane stack).  Only tokens in
+ * [tok_lo, tok_hi) contribute (pass 0, INT_MAX for the whole bank): a bank shard adds its own terms
+ * and the partial read-outs are summed over the shards. */
 int deva_readout_sparse(const int32_t* idx, const float* weight, int hw, int k,
                         const float* val_long, int n_long, const float* val_work, int cv,
-                        float* out, void* stream);
+                        float* out, int tok_lo, int tok_hi, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Bank maintenance (KeyValueMemoryStore.add / sieve_by_range / remove_obsolete_features,
@@ -244,6 +258,8 @@ int deva_softmax_columns(float* x, int n, int p, int ld, void* stream);
  *   n_new = anything else): counts[t*(n_new+1)+j] += 1 per pixel (int32, must be zeroed by the caller).
  *   Every intersection / area / union of _get_iou (segment_merging.py:17-22) is an entry or a row /
  *   column sum of this matrix -- one device pass and one small copy instead of one sync per pair.
+ *   Any number of label pairs: tables up to 60 KiB are accumulated per workgroup in LDS, larger ones
+ *   with global integer atomics.
  * deva_merge_paint: replays the area-ordered repaint (segment_merging.py:62-85): source t (propagated)
  *   and source j (detection) each carry (order, label), order < 0 = not painted; a pixel takes the
  *   label of the source painted last; the result is written as one-hot planes out[o][pixel] =

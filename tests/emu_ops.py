@@ -150,14 +150,58 @@ def usage_update(usage_fix, offset, use, life, n):
     seg.zero_()
 
 
-def readout_sparse(idx, weight, val_long, n_long, val_work, out):
+def readout_sparse(idx, weight, val_long, n_long, val_work, out, tok_range=None):
     hw, k = idx.shape
     cv = out.shape[0]
     n_work_needed = int(idx.max().item()) + 1 - n_long
     vals = _bank(val_long, n_long, val_work, max(n_work_needed, 0))
     g = vals[idx.long().reshape(-1)].reshape(hw, k, cv)
-    out.copy_((g * weight[:, :, None]).sum(1).t().reshape(out.shape))
+    w = weight
+    if tok_range is not None:
+        w = torch.where((idx >= tok_range[0]) & (idx < tok_range[1]), weight, torch.zeros_like(weight))
+    out.copy_((g * w[:, :, None]).sum(1).t().reshape(out.shape))
     return out
+
+
+def _orderable(score):
+    """order-preserving 32-bit image of an fp32 score (as int64), like affinity.hip:orderable"""
+    u = score.contiguous().view(torch.int32).long() & 0xffffffff
+    return torch.where(u >= 0x80000000, (~u) & 0xffffffff, u | 0x80000000)
+
+
+def affinity_candidates(key_long, shr_long, n_long, key_work, shr_work, n_work, qk, qe, k, token_offset=0,
+                        splits=None):
+    mk = _bank(key_long, n_long, key_work, n_work)
+    ms = _bank(shr_long, n_long, shr_work, n_work)
+    a_sq = mk.pow(2) @ qe
+    two_ab = 2 * (mk @ (qk * qe))
+    b_sq = (qe * qk.pow(2)).sum(0, keepdim=True)
+    sim = (-a_sq + two_ab - b_sq) * ms[:, None] / 8.0
+    vals, idx = torch.topk(sim, k=k, dim=0)
+    hw = qk.shape[1]
+    keys = torch.zeros((hw, 64), dtype=torch.int64)
+    token = (idx.t().long() + token_offset)
+    keys[:, :k] = (_orderable(vals.t()) << 32) | ((~token) & 0xffffffff)
+    return keys, torch.full((hw,), k, dtype=torch.int32)
+
+
+def affinity_merge(keys, counts, k, usage_fix=None):
+    lists, hw = counts.shape
+    live = torch.arange(64)[None, None, :] < counts[:, :, None]
+    flat = torch.where(live, keys, torch.full_like(keys, -(1 << 62))).permute(1, 0, 2).reshape(hw, lists * 64)
+    # keys are "unsigned": compare on (score bits, ~token) -- map to a sortable signed value
+    signed = torch.where(live.permute(1, 0, 2).reshape(hw, -1), flat ^ (-(1 << 63)), torch.full_like(flat, -(1 << 63)))
+    top = torch.topk(signed, k=k, dim=1)[0] ^ (-(1 << 63))
+    o = (top >> 32) & 0xffffffff
+    token = (~top) & 0xffffffff
+    bits = torch.where(o >= 0x80000000, o & 0x7fffffff, (~o) & 0xffffffff)
+    score = bits
+    score = torch.where(score >= 0x80000000, score - (1 << 32), score).to(torch.int32).view(torch.float32)
+    w = score.exp()
+    w = w / w.sum(1, keepdim=True)
+    if usage_fix is not None:
+        usage_fix.index_add_(0, token.reshape(-1), (w.reshape(-1).double() * TWO40).long())
+    return token.int(), w
 
 
 def bank_append(src, arena, row0):

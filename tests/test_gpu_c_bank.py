@@ -88,7 +88,9 @@ def test_similarity_dense_and_softmax_columns(nc, p):
     assert max_err(out, ref) <= 1e-5 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize('h,w,n_our,n_new', [(64, 80, 3, 4), (480, 864, 8, 12), (17, 5, 0, 2), (33, 47, 5, 0)])
+# (240, 320, 150, 140): 151 x 141 label pairs = 85 KB, beyond the LDS histogram -> global-atomic kernel
+@pytest.mark.parametrize('h,w,n_our,n_new', [(64, 80, 3, 4), (480, 864, 8, 12), (17, 5, 0, 2), (33, 47, 5, 0),
+                                             (240, 320, 150, 140)])
 def test_label_histogram_and_merge_paint(h, w, n_our, n_new):
     g = torch.Generator().manual_seed(h + n_our)
     ours = torch.randint(0, n_our + 1, (h, w), generator=g)

@@ -160,3 +160,47 @@ def test_query_column_slices_are_bit_identical():
                                          to_dev(qe[:, lo:hi].contiguous()), k, fix)
             assert torch.equal(i_s.cpu(), idx[lo:hi]) and torch.equal(w_s.cpu(), w[lo:hi]), (world, r)
         assert torch.equal(fix, full_fix), world
+
+
+@pytest.mark.parametrize('world', [2, 3, 8])
+def test_token_sharded_read_merges_to_the_unsharded_result(world):
+    """bank sharded by token range (MemoryManager.shard_bank): every shard's own top-k, in the hand-over
+    format and with global token ids, merged by deva_affinity_merge must be BIT-identical to the unsharded
+    read (indices, weights, usage counters); the shards' partial read-outs must add up to the full one"""
+    n, hw, k, n_long = 5000, 700, 30, 1800
+    mk, ms, qk, qe = synth.affinity_inputs(n, hw, seed=world, key_scale=2.0)
+    rows, shr = mk.t().contiguous(), ms.reshape(-1).contiguous()
+    kl, sl = to_dev(rows[:n_long].contiguous()), to_dev(shr[:n_long].contiguous())
+    kw, sw = to_dev(rows[n_long:].contiguous()), to_dev(shr[n_long:].contiguous())
+    qk_d, qe_d = to_dev(qk), to_dev(qe)
+    full_fix = torch.zeros(n, dtype=torch.int64, device=dev())
+    idx, w = ops.affinity_topk(kl, sl, n_long, kw, sw, n - n_long, qk_d, qe_d, k, full_fix)
+    per = -(-n // world)
+    keys, counts = [], []
+    for r in range(world):
+        lo, hi = r * per, min(n, (r + 1) * per)
+        l0, l1 = min(lo, n_long), min(hi, n_long)
+        w0, w1 = max(lo, n_long) - n_long, max(hi, n_long) - n_long
+        kk, cc = ops.affinity_candidates(kl[l0:l1] if l1 > l0 else None, sl[l0:l1] if l1 > l0 else None, l1 - l0,
+                                         kw[w0:w1] if w1 > w0 else None, sw[w0:w1] if w1 > w0 else None, w1 - w0,
+                                         qk_d, qe_d, k, token_offset=lo)
+        assert int(cc.min()) == k and int(cc.max()) == k
+        keys.append(kk)
+        counts.append(cc)
+    fix = torch.zeros(n, dtype=torch.int64, device=dev())
+    idx_m, w_m = ops.affinity_merge(torch.stack(keys), torch.stack(counts), k, fix)
+    torch.cuda.synchronize()
+    assert torch.equal(idx_m, idx) and torch.equal(w_m, w) and torch.equal(fix, full_fix)
+    cv = 512
+    v = synth.value_inputs(1, cv, n, seed=3)[0].t().contiguous()
+    vl, vw = to_dev(v[:n_long].contiguous()), to_dev(v[n_long:].contiguous())
+    full = torch.empty(cv, hw, device=dev())
+    ops.readout_sparse(idx, w, vl, n_long, vw, full)
+    total = torch.zeros_like(full)
+    for r in range(world):
+        part = torch.empty_like(full)
+        ops.readout_sparse(idx, w, vl, n_long, vw, part, tok_range=(r * per, min(n, (r + 1) * per)))
+        total += part
+    err = max_err(total, full.cpu())
+    print(f'world={world}: merged selection bit-identical; partial read-outs sum to the full one within {err:.2e}')
+    assert err <= 1e-5 * max(1.0, full.abs().max().item())

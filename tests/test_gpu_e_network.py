@@ -195,10 +195,13 @@ def test_detection_clip_against_reference_golden(network, golden_dir):
         assert _margin_aware_mismatch(p[:, ::2, ::2], torch.from_numpy(g[f'prob_sub_{t}']), errs[t]) == 0, t
 
 
-def test_sharded_read_single_rank_group_is_identical(network):
-    """MemoryManager.shard_queries over a 1-rank RCCL group: the collective code path of the
-    multi-GPU read (all-gather of read-out columns, all-reduce of usage) must reproduce the plain
-    read bit for bit (the 2- and 3-rank splits run on CPU/gloo in tests/test_sharded_read_gloo.py)"""
+@pytest.mark.parametrize('mode', ['queries', 'owner', 'bank'])
+def test_sharded_read_single_rank_group_is_identical(network, mode):
+    """The three one-clip-on-several-GPUs modes of MemoryManager over a 1-rank RCCL group: the collective
+    code paths (all-gather / gather of read-out columns, all-reduce of usage; broadcast of query and
+    memory rows in frame-owner mode; all-gather of candidate keys + all-reduce of partial read-outs in
+    bank-sharded mode) must reproduce the plain read bit for bit (the 2- and 3-rank splits run on
+    CPU/gloo in tests/test_sharded_read_gloo.py)"""
     import socket
     import torch.distributed as dist
     from deva.inference.inference_core import DEVAInferenceCore
@@ -213,12 +216,16 @@ def test_sharded_read_single_rank_group_is_identical(network):
     try:
         def make(cfg):
             c = DEVAInferenceCore(net, cfg)
-            c.memory.shard_queries()
+            if mode == 'bank':
+                c.memory.shard_bank()
+            else:
+                c.memory.shard_queries(owner=0 if mode == 'owner' else None)
             return c
         sharded, core_b = scenarios.run_scenario(make, sc, device=dev())
     finally:
         dist.destroy_process_group()
     assert all(torch.equal(a, b) for a, b in zip(plain, sharded))
+    assert core_b.memory.comm_bytes > 0
     for b in core_a.memory.work_mem.buckets:
         assert torch.equal(core_a.memory.work_mem.get_usage(b), core_b.memory.work_mem.get_usage(b))
 

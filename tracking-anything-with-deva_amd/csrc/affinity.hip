@@ -457,13 +457,18 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
 }
 
 // one wave per query: exact top-k over the candidate lists of all ranges (lane l holds entry l of every
-// range's list: ME >= splits keys per lane), sorted by rank counting, then exp / normalise / usage
+// range's list: ME >= splits keys per lane), sorted by rank counting, then exp / normalise / usage.
+// With out_keys != NULL the sorted top-k is instead written back in the hand-over format (token index
+// shifted by token_offset): the per-shard selection of a token-sharded bank, merged by a second pass of
+// this kernel over the gathered lists of all shards.
 template <int ME>
 __global__ __launch_bounds__(256) void affinity_finalize_kernel(const uint64_t* __restrict__ part,
                                                                 const uint32_t* __restrict__ part_cnt, int hw, int k,
                                                                 int splits, int32_t* __restrict__ idx,
                                                                 float* __restrict__ weight,
-                                                                unsigned long long* __restrict__ usage_fix) {
+                                                                unsigned long long* __restrict__ usage_fix,
+                                                                uint64_t* __restrict__ out_keys,
+                                                                uint32_t* __restrict__ out_cnt, uint32_t token_offset) {
   __shared__ uint64_t s_buf[4][2][64];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -509,6 +514,11 @@ __global__ __launch_bounds__(256) void affinity_finalize_kernel(const uint64_t* 
   DEVA_COMPILER_FENCE();
   const uint64_t mine = live ? sorted[lane] : 0ull;  // lane r holds the r-th best
 
+  if (out_keys) {
+    if (live) out_keys[(int64_t)q * CAP + lane] = (mine & 0xffffffff00000000ull) | (uint64_t)(~(~(uint32_t)mine + token_offset));
+    if (lane == 0) out_cnt[q] = (uint32_t)k;
+    return;
+  }
   const float score = from_orderable((uint32_t)(mine >> 32));
   const uint32_t token = ~(uint32_t)mine;
   const float ex = live ? expf(score) : 0.0f;
@@ -546,7 +556,7 @@ __global__ __launch_bounds__(256) void readout_sparse_kernel(const int32_t* __re
                                                              const float* __restrict__ weight, int hw, int k,
                                                              const float* __restrict__ val_long, int n_long,
                                                              const float* __restrict__ val_work, int cv,
-                                                             float* __restrict__ out) {
+                                                             float* __restrict__ out, int tok_lo, int tok_hi) {
   __shared__ float tile[RC][RQ + 1];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -561,6 +571,7 @@ __global__ __launch_bounds__(256) void readout_sparse_kernel(const int32_t* __re
     if (q < hw && c_ok) {
       for (int j = 0; j < k; ++j) {
         const int t = idx[(int64_t)q * k + j];
+        if (t < tok_lo || t >= tok_hi) continue;  // token of another bank shard: its owner adds that term
         const float w = weight[(int64_t)q * k + j];
         const float* row = (t < n_long) ? (val_long + (int64_t)t * cv) : (val_work + (int64_t)(t - n_long) * cv);
         const float4 v = *reinterpret_cast<const float4*>(row + c0 + cl);
@@ -669,27 +680,54 @@ extern "C" int deva_affinity_topk(const float* key_long, const float* shr_long, 
   return check_launch("deva_affinity_topk");
 }
 
+static int launch_merge(const uint64_t* keys, const uint32_t* cnt, int hw, int k, int lists, int32_t* idx, float* weight,
+                        uint64_t* usage_fix, uint64_t* out_keys, uint32_t* out_cnt, uint32_t token_offset,
+                        void* stream, const char* what) {
+  const dim3 grid((unsigned)ceil_div(hw, 4));
+#define DEVA_MERGE(ME)                                                                                            \
+  hipLaunchKernelGGL(affinity_finalize_kernel<ME>, grid, dim3(256), 0, (hipStream_t)stream, keys, cnt, hw, k, lists, \
+                     idx, weight, (unsigned long long*)usage_fix, out_keys, out_cnt, token_offset)
+  if (lists <= 4) {
+    DEVA_MERGE(4);
+  } else if (lists <= 8) {
+    DEVA_MERGE(8);
+  } else if (lists <= 16) {
+    DEVA_MERGE(16);
+  } else {
+    DEVA_MERGE(32);
+  }
+#undef DEVA_MERGE
+  return check_launch(what);
+}
+
 extern "C" int deva_affinity_finalize(const uint64_t* part_keys, int hw, int k, int splits, int32_t* idx,
                                       float* weight, uint64_t* usage_fix, void* stream) {
   DEVA_REQUIRE(part_keys && idx && weight && hw > 0, "deva_affinity_finalize: bad args");
   DEVA_REQUIRE(k >= 1 && k <= K_MAX && splits >= 1 && splits <= MAX_SPLITS,
                "deva_affinity_finalize: k/splits out of range");
   const uint32_t* cnt = reinterpret_cast<const uint32_t*>(part_keys + (int64_t)splits * hw * CAP);
-  const dim3 grid((unsigned)ceil_div(hw, 4));
-  if (splits <= 4) {
-    hipLaunchKernelGGL(affinity_finalize_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, part_keys, cnt, hw, k,
-                       splits, idx, weight, (unsigned long long*)usage_fix);
-  } else if (splits <= 8) {
-    hipLaunchKernelGGL(affinity_finalize_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, part_keys, cnt, hw, k,
-                       splits, idx, weight, (unsigned long long*)usage_fix);
-  } else if (splits <= 16) {
-    hipLaunchKernelGGL(affinity_finalize_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, part_keys, cnt, hw, k,
-                       splits, idx, weight, (unsigned long long*)usage_fix);
-  } else {
-    hipLaunchKernelGGL(affinity_finalize_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, part_keys, cnt, hw, k,
-                       splits, idx, weight, (unsigned long long*)usage_fix);
-  }
-  return check_launch("deva_affinity_finalize");
+  return launch_merge(part_keys, cnt, hw, k, splits, idx, weight, usage_fix, nullptr, nullptr, 0u, stream,
+                      "deva_affinity_finalize");
+}
+
+extern "C" int deva_affinity_select(const uint64_t* part_keys, int hw, int k, int splits, int64_t token_offset,
+                                    uint64_t* out_keys, uint32_t* out_counts, void* stream) {
+  DEVA_REQUIRE(part_keys && out_keys && out_counts && hw > 0, "deva_affinity_select: bad args");
+  DEVA_REQUIRE(k >= 1 && k <= K_MAX && splits >= 1 && splits <= MAX_SPLITS,
+               "deva_affinity_select: k/splits out of range");
+  DEVA_REQUIRE(token_offset >= 0 && token_offset < (1ll << 31), "deva_affinity_select: bad token offset");
+  const uint32_t* cnt = reinterpret_cast<const uint32_t*>(part_keys + (int64_t)splits * hw * CAP);
+  return launch_merge(part_keys, cnt, hw, k, splits, nullptr, nullptr, nullptr, out_keys, out_counts,
+                      (uint32_t)token_offset, stream, "deva_affinity_select");
+}
+
+extern "C" int deva_affinity_merge(const uint64_t* keys, const uint32_t* counts, int hw, int k, int lists, int32_t* idx,
+                                   float* weight, uint64_t* usage_fix, void* stream) {
+  DEVA_REQUIRE(keys && counts && idx && weight && hw > 0, "deva_affinity_merge: bad args");
+  DEVA_REQUIRE(k >= 1 && k <= K_MAX && lists >= 1 && lists <= MAX_SPLITS,
+               "deva_affinity_merge: k/lists out of range");
+  return launch_merge(keys, counts, hw, k, lists, idx, weight, usage_fix, nullptr, nullptr, 0u, stream,
+                      "deva_affinity_merge");
 }
 
 extern "C" int deva_usage_update(uint64_t* usage_fix, int64_t offset, float* use, float* life, int n,
@@ -702,7 +740,8 @@ extern "C" int deva_usage_update(uint64_t* usage_fix, int64_t offset, float* use
 }
 
 extern "C" int deva_readout_sparse(const int32_t* idx, const float* weight, int hw, int k, const float* val_long,
-                                   int n_long, const float* val_work, int cv, float* out, void* stream) {
+                                   int n_long, const float* val_work, int cv, float* out, int tok_lo, int tok_hi,
+                                   void* stream) {
   DEVA_REQUIRE(idx && weight && out && hw > 0 && k > 0 && cv > 0, "deva_readout_sparse: bad args");
   DEVA_REQUIRE(cv % 4 == 0, "deva_readout_sparse: value dim must be a multiple of 4");
   DEVA_REQUIRE(n_long == 0 || val_long, "deva_readout_sparse: null long-term values");
@@ -711,6 +750,6 @@ extern "C" int deva_readout_sparse(const int32_t* idx, const float* weight, int 
   DEVA_REQUIRE(vl && vw, "deva_readout_sparse: no value segment");
   dim3 grid((unsigned)ceil_div(hw, RQ), (unsigned)ceil_div(cv, RC));
   hipLaunchKernelGGL(readout_sparse_kernel, grid, dim3(256), 0, (hipStream_t)stream, idx, weight, hw, k, vl, n_long,
-                     vw, cv, out);
+                     vw, cv, out, tok_lo, tok_hi);
   return check_launch("deva_readout_sparse");
 }

@@ -35,6 +35,19 @@ __global__ void label_histogram_kernel(const int64_t* __restrict__ ours, const i
     if (hist[i]) atomicAdd(&counts[i], hist[i]);
 }
 
+// the same without the LDS stage, for label tables beyond 60 KiB (> ~124 x 124 pairs: "segment everything"
+// clips with --max_num_objects -1): integer atomics straight into `counts` (exact in any order)
+__global__ void label_histogram_global_kernel(const int64_t* __restrict__ ours, const int64_t* __restrict__ news,
+                                              const int64_t* __restrict__ new_ids, int n_our, int n_new,
+                                              int64_t pixels, int* __restrict__ counts) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < pixels; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = ours[i];
+    if (t < 0 || t > n_our) t = 0;
+    const int j = find_id(new_ids, n_new, news[i]);
+    atomicAdd(&counts[(int64_t)t * (n_new + 1) + j], 1);
+  }
+}
+
 // paint: every source (propagated tmp id t, detection column j) carries (order, label) or order < 0;
 // the pixel takes the label of the source painted last; out[o][i] = (label == out_ids[o])
 __global__ void merge_paint_kernel(const int64_t* __restrict__ ours, const int64_t* __restrict__ news,
@@ -139,12 +152,16 @@ extern "C" int deva_label_histogram(const int64_t* ours, const int64_t* news, co
   DEVA_REQUIRE(ours && news && counts && n_our >= 0 && n_new >= 0 && pixels > 0, "deva_label_histogram: bad args");
   DEVA_REQUIRE(n_new == 0 || new_ids, "deva_label_histogram: null id list");
   const size_t smem = sizeof(int) * (size_t)(n_our + 1) * (n_new + 1);
-  DEVA_REQUIRE(smem <= 60 * 1024, "deva_label_histogram: %d x %d label pairs do not fit the LDS histogram", n_our + 1,
-               n_new + 1);
+  DEVA_REQUIRE((int64_t)(n_our + 1) * (n_new + 1) < (1ll << 31), "deva_label_histogram: label table too large");
   int64_t blocks = ceil_div(pixels, 256 * 8);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(label_histogram_kernel, dim3((unsigned)blocks), dim3(256), smem, (hipStream_t)stream, ours, news,
-                     new_ids, n_our, n_new, pixels, counts);
+  if (smem <= 60 * 1024) {
+    hipLaunchKernelGGL(label_histogram_kernel, dim3((unsigned)blocks), dim3(256), smem, (hipStream_t)stream, ours,
+                       news, new_ids, n_our, n_new, pixels, counts);
+  } else {  // the table does not fit the LDS: global integer atomics (the reference has no object limit)
+    hipLaunchKernelGGL(label_histogram_global_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ours,
+                       news, new_ids, n_our, n_new, pixels, counts);
+  }
   return check_launch("deva_label_histogram");
 }
 

@@ -59,7 +59,9 @@ SIGNATURES = {
     'deva_affinity_default_splits': (c_int, [c_int, c_int]),
     'deva_usage_update': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p]),
     'deva_readout_sparse': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
-                                    c_void_p, c_void_p]),
+                                    c_void_p, c_int, c_int, c_void_p]),
+    'deva_affinity_select': (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
+    'deva_affinity_merge': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'deva_bank_append': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     'deva_bank_gather_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'deva_bank_export': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),

@@ -15,7 +15,7 @@ from . import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQUARE_PLUS_ONE, KLAYOUT_CHU
 
 __all__ = ['PackedConv', 'pack_conv', 'conv2d', 'maxpool3x3s2', 'upsample2x_add', 'area_downsample',
            'aggregate', 'softmax_channels', 'upsample4x_softmax', 'cbam', 'gru_update',
-           'affinity_topk', 'usage_update', 'readout_sparse', 'bank_append', 'bank_gather_rows',
+           'affinity_topk', 'affinity_candidates', 'affinity_merge', 'usage_update', 'readout_sparse', 'bank_append', 'bank_gather_rows',
            'bank_export', 'rank', 'rank_select', 'evict_select', 'similarity_dense', 'softmax_columns',
            'label_histogram', 'merge_paint', 'lut_remap', 'index_mask', 'input_head',
            'ACT_NONE', 'ACT_RELU', 'ACT_SIGMOID', 'ACT_SQUARE_PLUS_ONE']
@@ -327,15 +327,51 @@ def usage_update(usage_fix: torch.Tensor, offset: int, use: Optional[torch.Tenso
 
 
 def readout_sparse(idx: torch.Tensor, weight: torch.Tensor, val_long, n_long: int, val_work,
-                   out: torch.Tensor) -> torch.Tensor:
-    """out [cv, hw(...)] = sparse readout of token-major values ([>=n, cv] arenas)"""
+                   out: torch.Tensor, tok_range: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+    """out [cv, hw(...)] = sparse readout of token-major values ([>=n, cv] arenas); with tok_range =
+    (lo, hi) only the tokens lo <= t < hi contribute (partial read-out of one bank shard)"""
     hw, k = idx.shape
     cv = out.shape[0]
     if out.numel() != cv * hw:
         raise DevaHipError('readout_sparse: bad output shape')
+    lo, hi = (0, (1 << 31) - 1) if tok_range is None else (int(tok_range[0]), int(tok_range[1]))
     check(lib().deva_readout_sparse(_p(idx, torch.int32), _p(weight), hw, k, _p(val_long) if n_long else None,
-                                    n_long, _p(val_work), cv, _p(out), _stream()), 'deva_readout_sparse')
+                                    n_long, _p(val_work), cv, _p(out), lo, hi, _stream()), 'deva_readout_sparse')
     return out
+
+
+def affinity_candidates(key_long, shr_long, n_long: int, key_work, shr_work, n_work: int, qk: torch.Tensor,
+                        qe: torch.Tensor, k: int, token_offset: int = 0, splits: Optional[int] = None):
+    """One shard of a token-sharded bank: the shard's own sorted top-k per query in the hand-over format of
+    the affinity kernels -- keys int64 [hw, 64] (order-preserving score bits << 32 | ~(token + offset); the
+    first k entries of a list are live), counts int32 [hw]"""
+    hw = qk.shape[1]
+    if qk.shape[0] != 64 or tuple(qe.shape) != tuple(qk.shape):
+        raise DevaHipError('affinity_candidates: queries must be [64, hw]')
+    L = lib()
+    if splits is None:
+        splits = L.deva_affinity_default_splits(n_long + n_work, hw)
+    part = _affinity_workspace(L.deva_affinity_workspace(hw, k, splits), qk.device)
+    check(L.deva_affinity_topk(_p(key_long) if n_long else None, _p(shr_long) if n_long else None, n_long,
+                               _p(key_work) if n_work else None, _p(shr_work) if n_work else None, n_work,
+                               _p(qk), _p(qe), hw, k, splits, _p(part, torch.int64), _stream()),
+          'deva_affinity_topk')
+    keys = torch.zeros((hw, 64), dtype=torch.int64, device=qk.device)
+    counts = torch.empty((hw,), dtype=torch.int32, device=qk.device)
+    check(L.deva_affinity_select(_p(part, torch.int64), hw, k, splits, int(token_offset), _p(keys, torch.int64),
+                                 _p(counts, torch.int32), _stream()), 'deva_affinity_select')
+    return keys, counts
+
+
+def affinity_merge(keys: torch.Tensor, counts: torch.Tensor, k: int, usage_fix: Optional[torch.Tensor] = None):
+    """keys int64 [lists, hw, 64], counts int32 [lists, hw] (the gathered `affinity_candidates` of every
+    shard) -> idx int32 [hw, k], weight fp32 [hw, k] of the exact global top-k (+ usage like affinity_topk)"""
+    lists, hw = counts.shape
+    idx = torch.empty((hw, k), dtype=torch.int32, device=keys.device)
+    weight = torch.empty((hw, k), dtype=torch.float32, device=keys.device)
+    check(lib().deva_affinity_merge(_p(keys, torch.int64), _p(counts, torch.int32), hw, k, lists, _p(idx, torch.int32),
+                                    _p(weight), _p(usage_fix, torch.int64), _stream()), 'deva_affinity_merge')
+    return idx, weight
 
 
 # ------------------------------------------------------------------------------------------ bank upkeep

@@ -165,6 +165,83 @@ class DEVAInferenceCore:
                 appended.append(channel.unsqueeze(0))
         return torch.cat([fg, *appended], dim=0)
 
+    def _step_frame_owner(self, image, mask, objects, hard_mask, end, image_ti_override, delete_buffer):
+        """`step` of ONE clip on several GPUs in frame-owner mode (`MemoryManager.shard_queries(group,
+        owner=r)`): every rank of the group calls `step` with the same arguments; only the
+        owner runs the key encoder, the mask decoder and the value encoder.  Per frame the owner broadcasts
+        the query key / selection, every rank matches and reads out its share of the query columns against
+        its replica of the bank, the read-out columns are gathered to the owner and the integer usage
+        counters all-reduced; on memory frames the owner broadcasts the new key / shrinkage / selection /
+        value rows and every rank appends them (consolidation and eviction then run redundantly on
+        identical inputs with deterministic kernels, so the replicas cannot diverge).  The frame state
+        machine depends on host-side state only, which is identical on all ranks.  Returns the
+        probabilities on the owner, None elsewhere."""
+        mem, om = self.memory, self.object_manager
+        own = mem.is_frame_owner
+        annotated = mask is not None
+        self.curr_ti += 1
+        frame_ti = image_ti_override if image_ti_override is not None else self.curr_ti
+        padded, self.pad = pad_divide_by(image, 16)
+        h, w = padded.shape[-2] // 16, padded.shape[-1] // 16
+        device = image.device
+        ms_features = key = shrinkage = selection = None
+        if own:
+            batch = padded.unsqueeze(0)
+            store = self.image_feature_store
+            ms_features = store.get_ms_features(frame_ti, batch)
+            key, shrinkage, selection = store.get_key(frame_ti, batch)
+        due = self.curr_ti - self.last_mem_ti >= self.mem_every
+        commit = (annotated or due) and not end
+        propagate = (not annotated) or (om.num_obj > 0 and not om.has_all(objects))
+
+        prob = None
+        if propagate:
+            if not mem.engaged:
+                warnings.warn('Trying to segment without any memory!', RuntimeWarning)
+                if own:
+                    prob = torch.zeros((1, h * 16, w * 16), device=device, dtype=torch.float32)
+            else:
+                qk, qe = mem.broadcast_query(key, selection, h, w, device)
+                readout = mem.match_memory(qk, qe)
+                if own:
+                    ids = om.all_obj_ids
+                    sensory, _, dec = self.network.segment(ms_features, om.realize_dict(readout).unsqueeze(0),
+                                                           mem.get_sensory(ids), self.last_mask,
+                                                           chunk_size=self.chunk_size, update_sensory=not end)
+                    if not end:
+                        mem.update_sensory(sensory, ids)
+                    prob = dec[0]
+        if annotated:
+            new_tmp_ids, _ = om.add_new_objects(objects)
+            if own:
+                mask, _ = pad_divide_by(mask, 16)
+                if propagate:
+                    mask = self._blend_annotation(prob, mask, objects, new_tmp_ids, hard_mask)
+                elif hard_mask:
+                    mask = torch.stack([mask == o for o in objects], dim=0)
+                prob = ops.softmax_channels(self.network.aggregate(mask, dim=0))
+        if own:
+            self.last_mask = prob[1:].unsqueeze(0)
+        if commit:
+            ids = om.all_obj_ids
+            if not ids:
+                warnings.warn('Empty object mask!', RuntimeWarning)
+            else:
+                value = sensory = None
+                if own:
+                    mem.initialize_sensory_if_needed(key, ids)
+                    value, sensory = self.network.encode_mask(batch, ms_features, mem.get_sensory(ids), self.last_mask,
+                                                              is_deep_update=True, chunk_size=self.chunk_size)
+                key_b, shr_b, val_b, sel_b = mem.broadcast_memory_frame(key, shrinkage, value, selection, ids, h, w,
+                                                                        device)
+                mem.add_memory(key_b, shr_b, val_b, ids, selection=sel_b)
+                self.last_mem_ti = self.curr_ti
+                if own:
+                    mem.update_sensory(sensory, ids)
+        if own and delete_buffer:
+            self.image_feature_store.delete(frame_ti)
+        return unpad(prob, self.pad) if own else None
+
     def step(self, image: torch.Tensor, mask: torch.Tensor = None, objects: Optional[List[int]] = None, *,
              hard_mask: bool = True, end: bool = False, image_ti_override: bool = None,
              delete_buffer: bool = True) -> torch.Tensor:
@@ -178,6 +255,8 @@ class DEVAInferenceCore:
         if annotated and objects is None:
             assert not hard_mask
             objects = list(range(1, mask.shape[0] + 1))
+        if self.memory._shard_group is not None and self.memory._shard_owner is not None:
+            return self._step_frame_owner(image, mask, objects, hard_mask, end, image_ti_override, delete_buffer)
 
         frame_ti, batch, ms_features, key, shrinkage, selection = self._begin_frame(image, image_ti_override)
         due = self.curr_ti - self.last_mem_ti >= self.mem_every

@@ -25,6 +25,16 @@ from deva.hip import ops
 from deva.inference.kv_memory_store import KeyValueMemoryStore
 
 
+class StackedReadout(dict):
+    """{object id: CV*H*W read-out} whose values are consecutive rows of ONE [objects, CV, H, W] tensor
+    (`stack`, rows in `order`), so that `ObjectManager.realize_dict` can hand that tensor to the decoder
+    without re-stacking it"""
+
+    def __init__(self, stack: Optional[torch.Tensor] = None, order=()):
+        super().__init__({obj: stack[i] for i, obj in enumerate(order)} if stack is not None else {})
+        self.stack, self.order = stack, list(order)
+
+
 class MemoryManager:
     """
     Manages all three memory stores and the transition between working/long-term memory
@@ -41,6 +51,7 @@ class MemoryManager:
 
     def __init__(self, config: Dict):
         self.sensory_dim = config['value_dim']
+        self.key_dim = config.get('key_dim', 64)
         self.top_k = self._checked_top_k(config['top_k'])
         self.use_long_term = config['enable_long_term']
         self.count_long_term_usage = config['enable_long_term_count_usage']
@@ -67,6 +78,9 @@ class MemoryManager:
 
         self._usage_fix: Optional[torch.Tensor] = None  # int64 fixed-point usage scratch, kept zeroed
         self._shard_group = None  # torch.distributed group the memory read is sharded over
+        self._shard_mode: Optional[str] = None  # 'queries' | 'bank'
+        self._shard_owner: Optional[int] = None  # group rank that owns the encoder / decoder (frame-owner mode)
+        self.comm_bytes = 0  # bytes this rank sent + received in collectives since sharding was enabled
 
         self.config_stale = True
         self.engaged = False
@@ -93,82 +107,236 @@ class MemoryManager:
             self._usage_fix = torch.zeros(max(2 * n, 1 << 16), dtype=torch.int64, device=device)
         return self._usage_fix
 
-    def shard_queries(self, group=None) -> None:
-        """Partition every following `match_memory` by query column over `group` (default: the world
-        group).  All ranks of the group must step the same clip."""
+    # ------------------------------------------------------------------ one clip on several GPUs
+    def shard_queries(self, group=None, owner: Optional[int] = None) -> None:
+        """Partition every following `match_memory` by QUERY COLUMN over `group` (default: the world
+        group); every rank keeps a full replica of the bank (SURVEY.md 8e "replicate bank, shard queries").
+        owner=None: every rank steps the same clip and receives every read-out (all-gather).
+        owner=r   : frame-owner mode -- rank r alone runs the encoder / decoder; `DEVAInferenceCore.step`
+                    broadcasts the query key / selection from it, the read-out columns are gathered to it
+                    only, and on memory frames it broadcasts the new key / shrinkage / selection / value
+                    rows to the other ranks' banks."""
         import torch.distributed as dist
         if not dist.is_initialized():
             raise RuntimeError('shard_queries: torch.distributed is not initialised')
         self._shard_group = group if group is not None else dist.group.WORLD
+        self._shard_mode = 'queries'
+        self._shard_owner = owner
+        self.comm_bytes = 0
 
-    def _shard_range(self, hw: int) -> Tuple[int, int, int, int]:
-        """-> (rank, world, columns per rank, first column of this rank)"""
+    def shard_bank(self, group=None) -> None:
+        """Partition every following `match_memory` by MEMORY TOKEN RANGE over `group` (SURVEY.md 8e
+        "shard the bank"): rank r matches the queries against rows [r*per, (r+1)*per) of the virtual
+        long-then-work bank only, the per-shard top-k candidates (64-bit score|token keys, hw*k*8 B per
+        rank) are all-gathered and merged to the exact global top-k on every rank, each rank reads out
+        the value rows of its own range and the partial read-outs are summed (all-reduce).  The merged
+        selection, weights and usage counters are bit-identical to the unsharded read.  Storage is still
+        replicated (every rank appends every memory frame); dropping the rows a rank does not own is a
+        store-level follow-up that needs no further collective."""
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError('shard_bank: torch.distributed is not initialised')
+        self._shard_group = group if group is not None else dist.group.WORLD
+        self._shard_mode = 'bank'
+        self._shard_owner = None
+        self.comm_bytes = 0
+
+    @property
+    def is_frame_owner(self) -> bool:
+        """True unless another rank owns the encoder / decoder of this clip"""
+        if self._shard_group is None or self._shard_owner is None:
+            return True
+        import torch.distributed as dist
+        return dist.get_rank(self._shard_group) == self._shard_owner
+
+    def _owner_global_rank(self) -> int:
+        import torch.distributed as dist
+        return dist.get_global_rank(self._shard_group, self._shard_owner)
+
+    def _shard_range(self, n: int) -> Tuple[int, int, int, int]:
+        """-> (rank, world, items per rank, first item of this rank) for n columns / tokens"""
         import torch.distributed as dist
         world = dist.get_world_size(self._shard_group)
         rank = dist.get_rank(self._shard_group)
-        per = -(-hw // world)
+        per = -(-n // world)
         return rank, world, per, rank * per
+
+    def _readout_into(self, out: torch.Tensor, idx, weight, bucket_id: int, obj: int, with_long: bool, n_long: int,
+                      tok_range=None) -> None:
+        obj_long = with_long and obj in self.long_mem
+        ops.readout_sparse(idx, weight, self.long_mem.value_arena(obj) if obj_long else None,
+                           n_long if obj_long else 0, self.work_mem.value_arena(obj), out, tok_range=tok_range)
 
     def match_memory(self, query_key: torch.Tensor, selection: torch.Tensor) -> Dict[int, torch.Tensor]:
         """query_key, selection: 1 x C^k x H x W  ->  {object id: C^v x H x W readout}
-        (memory_manager.py:91-169)"""
+        (memory_manager.py:91-169).  The read-outs of all objects are views of ONE [objects, C^v, H, W]
+        tensor in bucket order (`ObjectManager.realize_dict` returns it without a copy when the order is
+        the tmp-id order).  In frame-owner mode the other ranks return an empty dict."""
         assert query_key.shape[0] == 1
         h, w = query_key.shape[-2:]
         hw = h * w
         qk = query_key[0].reshape(query_key.shape[1], hw)
         qe = selection[0].reshape(selection.shape[1], hw)
-        sharded = self._shard_group is not None
-        if sharded:
-            import torch.distributed as dist
-            rank, world, per, lo = self._shard_range(hw)
-            n_mine = max(0, min(hw, lo + per) - lo)
-            # this rank's query columns (an empty tail rank still matches one column: the kernels
-            # need hw >= 1; its result is discarded and its usage contribution masked below)
-            cols = slice(lo, lo + n_mine) if n_mine else slice(0, 1)
-            qk, qe = qk[:, cols].contiguous(), qe[:, cols].contiguous()
-        readouts: Dict[int, torch.Tensor] = {}
+        mode = self._shard_mode if self._shard_group is not None else None
+        order = [obj for bucket in self.work_mem.buckets.values() for obj in bucket]
+        receives = mode != 'queries' or self.is_frame_owner
+        stack = (torch.empty((len(order), self.CV, h, w), dtype=torch.float32, device=qk.device)
+                 if receives else None)
+        at = 0
         for bucket_id, bucket in self.work_mem.buckets.items():
-            with_long = self.use_long_term and self.long_mem.engaged(bucket_id)
-            n_long = self.long_mem.size(bucket_id) if with_long else 0
-            n_work = self.work_mem.size(bucket_id)
-            count_usage = self.use_long_term and not (sharded and n_mine == 0)
-            usage_fix = self._usage_scratch(n_long + n_work, qk.device) if self.use_long_term else None
-            idx, weight = ops.affinity_topk(
-                self.long_mem.key_arena(bucket_id) if with_long else None,
-                self.long_mem.shrinkage_arena(bucket_id) if with_long else None, n_long,
-                self.work_mem.key_arena(bucket_id), self.work_mem.shrinkage_arena(bucket_id), n_work,
-                qk, qe, self.top_k, usage_fix if count_usage else None)
-            if self.use_long_term:
-                if sharded:
-                    dist.all_reduce(usage_fix[:n_long + n_work], op=dist.ReduceOp.SUM, group=self._shard_group)
-                # usage bookkeeping (memory_manager.py:128-152)
-                self.work_mem.apply_usage_fix(bucket_id, usage_fix, n_long)
-                if with_long:
-                    self.long_mem.apply_usage_fix(bucket_id, usage_fix, 0)
-            if not sharded:
-                for obj in bucket:
-                    obj_long = with_long and obj in self.long_mem
-                    out = torch.empty((self.CV, h, w), dtype=torch.float32, device=qk.device)
-                    ops.readout_sparse(idx, weight, self.long_mem.value_arena(obj) if obj_long else None,
-                                       n_long if obj_long else 0, self.work_mem.value_arena(obj), out)
-                    readouts[obj] = out
-                continue
-            # sharded: [objects, CV, per] column slabs of this rank -> all-gather -> [objects, CV, hw]
-            nq = qk.shape[1]
-            mine = torch.zeros((len(bucket), self.CV, per), dtype=torch.float32, device=qk.device)
-            for i, obj in enumerate(bucket):
-                obj_long = with_long and obj in self.long_mem
-                out = torch.empty((self.CV, nq), dtype=torch.float32, device=qk.device)
-                ops.readout_sparse(idx, weight, self.long_mem.value_arena(obj) if obj_long else None,
-                                   n_long if obj_long else 0, self.work_mem.value_arena(obj), out)
+            rows = None if stack is None else stack[at:at + len(bucket)]
+            if mode == 'queries':
+                self._read_bucket_query_sharded(bucket_id, bucket, qk, qe, rows)
+            elif mode == 'bank':
+                self._read_bucket_bank_sharded(bucket_id, bucket, qk, qe, rows)
+            else:
+                self._read_bucket(bucket_id, bucket, qk, qe, rows)
+            at += len(bucket)
+        if stack is None:
+            return StackedReadout()
+        return StackedReadout(stack, order)
+
+    def _bucket_extent(self, bucket_id: int):
+        with_long = self.use_long_term and self.long_mem.engaged(bucket_id)
+        n_long = self.long_mem.size(bucket_id) if with_long else 0
+        return with_long, n_long, self.work_mem.size(bucket_id)
+
+    def _apply_usage(self, bucket_id: int, usage_fix, with_long: bool, n_long: int) -> None:
+        # usage bookkeeping (memory_manager.py:128-152)
+        self.work_mem.apply_usage_fix(bucket_id, usage_fix, n_long)
+        if with_long:
+            self.long_mem.apply_usage_fix(bucket_id, usage_fix, 0)
+
+    def _read_bucket(self, bucket_id: int, bucket: List[int], qk, qe, rows: torch.Tensor) -> None:
+        with_long, n_long, n_work = self._bucket_extent(bucket_id)
+        usage_fix = self._usage_scratch(n_long + n_work, qk.device) if self.use_long_term else None
+        idx, weight = ops.affinity_topk(
+            self.long_mem.key_arena(bucket_id) if with_long else None,
+            self.long_mem.shrinkage_arena(bucket_id) if with_long else None, n_long,
+            self.work_mem.key_arena(bucket_id), self.work_mem.shrinkage_arena(bucket_id), n_work,
+            qk, qe, self.top_k, usage_fix)
+        if self.use_long_term:
+            self._apply_usage(bucket_id, usage_fix, with_long, n_long)
+        for i, obj in enumerate(bucket):
+            self._readout_into(rows[i], idx, weight, bucket_id, obj, with_long, n_long)
+
+    def _read_bucket_query_sharded(self, bucket_id: int, bucket: List[int], qk, qe, rows) -> None:
+        """rank r matches and reads out query columns [r*per, (r+1)*per); the column slabs are gathered
+        (to every rank, or to the frame owner only) and the fixed-point usage counters all-reduced
+        (integer sums: exact in any order)"""
+        import torch.distributed as dist
+        hw = qk.shape[1]
+        rank, world, per, lo = self._shard_range(hw)
+        n_mine = max(0, min(hw, lo + per) - lo)
+        # an empty tail rank still matches one column (the kernels need hw >= 1); its result is
+        # discarded and its usage contribution suppressed
+        cols = slice(lo, lo + n_mine) if n_mine else slice(0, 1)
+        qk_r, qe_r = qk[:, cols].contiguous(), qe[:, cols].contiguous()
+        with_long, n_long, n_work = self._bucket_extent(bucket_id)
+        usage_fix = self._usage_scratch(n_long + n_work, qk.device) if self.use_long_term else None
+        idx, weight = ops.affinity_topk(
+            self.long_mem.key_arena(bucket_id) if with_long else None,
+            self.long_mem.shrinkage_arena(bucket_id) if with_long else None, n_long,
+            self.work_mem.key_arena(bucket_id), self.work_mem.shrinkage_arena(bucket_id), n_work,
+            qk_r, qe_r, self.top_k, usage_fix if (self.use_long_term and n_mine) else None)
+        if self.use_long_term:
+            dist.all_reduce(usage_fix[:n_long + n_work], op=dist.ReduceOp.SUM, group=self._shard_group)
+            self.comm_bytes += 8 * (n_long + n_work)
+            self._apply_usage(bucket_id, usage_fix, with_long, n_long)
+        # this rank's [objects, CV, per] slab; the read-out kernel writes straight into it when the rank
+        # has a full set of columns (every rank but possibly the last)
+        nobj = len(bucket)
+        mine = torch.empty((nobj, self.CV, per), dtype=torch.float32, device=qk.device)
+        for i, obj in enumerate(bucket):
+            if n_mine == per:
+                self._readout_into(mine[i], idx, weight, bucket_id, obj, with_long, n_long)
+            else:
+                part = torch.empty((self.CV, qk_r.shape[1]), dtype=torch.float32, device=qk.device)
+                self._readout_into(part, idx, weight, bucket_id, obj, with_long, n_long)
+                mine[i].zero_()
                 if n_mine:
-                    mine[i, :, :n_mine] = out
-            gathered = torch.empty((world * len(bucket), self.CV, per), dtype=torch.float32, device=qk.device)
-            dist.all_gather_into_tensor(gathered, mine, group=self._shard_group)  # rank-major concatenation
-            full = gathered.view(world, len(bucket), self.CV, per).permute(1, 2, 0, 3).reshape(len(bucket), self.CV, world * per)[:, :, :hw]
-            for i, obj in enumerate(bucket):
-                readouts[obj] = full[i].reshape(self.CV, h, w).contiguous()
-        return readouts
+                    mine[i, :, :n_mine] = part
+        slab_bytes = mine.numel() * 4
+        if self._shard_owner is None:
+            gathered = torch.empty((world, nobj, self.CV, per), dtype=torch.float32, device=qk.device)
+            dist.all_gather_into_tensor(gathered.view(world * nobj, self.CV, per), mine, group=self._shard_group)
+            self.comm_bytes += slab_bytes * (world - 1)
+            slabs = list(gathered.unbind(0))
+        elif self.is_frame_owner:
+            slabs = [torch.empty_like(mine) for _ in range(world)]
+            dist.gather(mine, slabs, dst=self._owner_global_rank(), group=self._shard_group)
+            self.comm_bytes += slab_bytes * (world - 1)
+        else:
+            dist.gather(mine, None, dst=self._owner_global_rank(), group=self._shard_group)
+            self.comm_bytes += slab_bytes
+            return
+        # [rank][obj, CV, per] column slabs -> [obj, CV, hw] (one strided copy per slab, ragged tail cut)
+        flat = rows.view(nobj, self.CV, hw)
+        for r, slab in enumerate(slabs):
+            c0 = r * per
+            c1 = min(hw, c0 + per)
+            if c1 > c0:
+                flat[:, :, c0:c1] = slab[:, :, :c1 - c0]
+
+    def _read_bucket_bank_sharded(self, bucket_id: int, bucket: List[int], qk, qe, rows) -> None:
+        import torch.distributed as dist
+        with_long, n_long, n_work = self._bucket_extent(bucket_id)
+        n = n_long + n_work
+        rank, world, per, lo = self._shard_range(n)
+        if n < 128 * world:  # first frames of a clip: a shard could hold fewer than top_k tokens
+            return self._read_bucket(bucket_id, bucket, qk, qe, rows)
+        hi = min(n, lo + per)
+        hw = qk.shape[1]
+        # this rank's rows of the virtual bank [long | work]
+        l0, l1 = min(lo, n_long), min(hi, n_long)
+        w0, w1 = max(lo, n_long) - n_long, max(hi, n_long) - n_long
+        keys, counts = ops.affinity_candidates(
+            self.long_mem.key_arena(bucket_id)[l0:l1] if l1 > l0 else None,
+            self.long_mem.shrinkage_arena(bucket_id)[l0:l1] if l1 > l0 else None, l1 - l0,
+            self.work_mem.key_arena(bucket_id)[w0:w1] if w1 > w0 else None,
+            self.work_mem.shrinkage_arena(bucket_id)[w0:w1] if w1 > w0 else None, w1 - w0,
+            qk, qe, self.top_k, token_offset=lo)
+        all_keys = torch.empty((world, *keys.shape), dtype=keys.dtype, device=keys.device)
+        all_counts = torch.empty((world, *counts.shape), dtype=counts.dtype, device=counts.device)
+        dist.all_gather_into_tensor(all_keys.view(world * hw, -1), keys, group=self._shard_group)
+        dist.all_gather_into_tensor(all_counts.view(-1), counts, group=self._shard_group)
+        self.comm_bytes += (keys.numel() * 8 + counts.numel() * 4) * (world - 1)
+        usage_fix = self._usage_scratch(n, qk.device) if self.use_long_term else None
+        idx, weight = ops.affinity_merge(all_keys, all_counts, self.top_k, usage_fix)
+        if self.use_long_term:  # every rank merged the complete selection: the counters are already global
+            self._apply_usage(bucket_id, usage_fix, with_long, n_long)
+        for i, obj in enumerate(bucket):
+            self._readout_into(rows[i], idx, weight, bucket_id, obj, with_long, n_long, tok_range=(lo, hi))
+        dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=self._shard_group)
+        self.comm_bytes += 2 * rows.numel() * 4 * (world - 1) // world
+
+    def broadcast_memory_frame(self, key, shrinkage, value, selection, objects: List[int], h: int, w: int, device):
+        """frame-owner mode, memory frame: the owner's new key (1*CK*h*w), shrinkage (1*1*h*w), selection
+        (1*CK*h*w) and value (1*objects*CV*h*w) rows are broadcast as one packed buffer so that every rank
+        appends the same tokens to its replica -- the 'RCCL all-gather of memory keys' of BASELINE.json.
+        The other ranks pass None for the tensors and receive them."""
+        import torch.distributed as dist
+        ck, cv = self.key_dim, self.sensory_dim
+        nobj = len(objects)
+        if self.is_frame_owner:
+            packed = torch.cat([key[0].reshape(ck, h * w), shrinkage[0].reshape(1, h * w),
+                                selection[0].reshape(ck, h * w), value[0].reshape(nobj * cv, h * w)], 0)
+        else:
+            packed = torch.empty((2 * ck + 1 + nobj * cv, h * w), dtype=torch.float32, device=device)
+        dist.broadcast(packed, src=self._owner_global_rank(), group=self._shard_group)
+        self.comm_bytes += packed.numel() * 4
+        return (packed[:ck].view(1, ck, h, w), packed[ck:ck + 1].view(1, 1, h, w),
+                packed[2 * ck + 1:].view(1, nobj, cv, h, w), packed[ck + 1:2 * ck + 1].view(1, ck, h, w))
+
+    def broadcast_query(self, key, selection, h: int, w: int, device):
+        """frame-owner mode, every frame: the owner's query key / selection (1*CK*h*w each) -> all ranks"""
+        import torch.distributed as dist
+        ck = self.key_dim
+        packed = (torch.cat([key[0].reshape(ck, h * w), selection[0].reshape(ck, h * w)], 0) if self.is_frame_owner
+                  else torch.empty((2 * ck, h * w), dtype=torch.float32, device=device))
+        dist.broadcast(packed, src=self._owner_global_rank(), group=self._shard_group)
+        self.comm_bytes += packed.numel() * 4
+        return packed[:ck].view(1, ck, h, w), packed[ck:].view(1, ck, h, w)
 
     # ------------------------------------------------------------------ write
     def add_memory(self, key: torch.Tensor, shrinkage: torch.Tensor, value: torch.Tensor,

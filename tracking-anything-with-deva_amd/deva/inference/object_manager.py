@@ -99,6 +99,9 @@ class ObjectManager:
 
     def realize_dict(self, obj_dict: Dict[int, torch.Tensor]) -> torch.Tensor:
         """{object id: tensor} -> stacked tensor in tmp-id order"""
+        stack, order = getattr(obj_dict, 'stack', None), getattr(obj_dict, 'order', None)
+        if stack is not None and order == [obj.id for obj in self.tmp_id_to_obj.values()]:
+            return stack  # MemoryManager.match_memory already produced the rows in this order: no copy
         rows = []
         for obj in self.tmp_id_to_obj.values():
             if obj.id not in obj_dict:
