@@ -32,8 +32,17 @@ if has tests; then
     fi
   done
 fi
+if has affshapes; then  # the affinity tests with every kernel shape forced in turn
+  for shape in 1 2 3; do
+    DEVA_AFFINITY_SHAPE=$shape timeout -k 10 300 python -m pytest tests/test_gpu_d_affinity.py -m gpu -q -p no:cacheprovider > gpurun_out/test_gpu_d_affinity_shape$shape.log 2>&1
+    echo "test_gpu_d_affinity with shape $shape exit $? : $(tail -1 gpurun_out/test_gpu_d_affinity_shape$shape.log)"
+  done
+fi
+if has custom; then
+  eval "$CUSTOM_CMD"
+fi
 if has affinity && [ -z "$AFF_FALLBACK" ]; then
-  for shape in 1 2; do
+  for shape in ${AFF_SHAPE_LIST:-1 2 3}; do
     DEVA_AFFINITY_SHAPE=$shape SHAPES=${AFF_SHAPES:-1620x1620,8100x1620,10000x1620,24580x1620,10000x8160,83440x8160,50000x32400} ITERS=10 \
       timeout -k 10 200 python tools/affinity_microbench.py > gpurun_out/affinity_shape$shape.txt 2>&1
     echo "--- affinity shape $shape"; cat gpurun_out/affinity_shape$shape.txt

@@ -156,12 +156,13 @@ __device__ __forceinline__ uint32_t kth_lane_value(uint32_t m, int k, int lane, 
 template <int E>
 __device__ __forceinline__ uint32_t prune_list(uint32_t* sc, uint16_t* tk, uint32_t c, int k, int lane, int* kept,
                                                uint32_t* scratch) {
-  uint32_t e[E], t[E];
+  uint32_t raw[E], e[E], t[E];  // the lists hold raw fp32 bits (cheap appends); ordered here
   uint32_t m = 0u;
 #pragma unroll
   for (int i = 0; i < E; ++i) {
     const uint32_t j = (uint32_t)lane + 64u * i;
-    e[i] = (j < c) ? sc[j] : 0u;
+    raw[i] = (j < c) ? sc[j] : 0u;
+    e[i] = (j < c) ? orderable(__uint_as_float(raw[i])) : 0u;
     t[i] = (j < c) ? (uint32_t)tk[j] : 0u;
     m = e[i] > m ? e[i] : m;
   }
@@ -174,7 +175,7 @@ __device__ __forceinline__ uint32_t prune_list(uint32_t* sc, uint16_t* tk, uint3
     const unsigned long long b = __ballot(keep);
     if (keep) {
       const int w = base + prefix_below(b);
-      sc[w] = e[i];
+      sc[w] = raw[i];
       tk[w] = (uint16_t)t[i];
     }
     base += __popcll(b);
@@ -196,7 +197,7 @@ __device__ __forceinline__ uint32_t prune_list_exact(uint32_t* sc, uint16_t* tk,
 #pragma unroll
   for (int i = 0; i < E; ++i) {
     const uint32_t j = (uint32_t)lane + 64u * i;
-    e[i] = (j < c) ? (((uint64_t)sc[j] << 32) | (uint64_t)(0xffffu - tk[j])) : 0ull;
+    e[i] = (j < c) ? (((uint64_t)orderable(__uint_as_float(sc[j])) << 32) | (uint64_t)(0xffffu - tk[j])) : 0ull;
     m[0] = e[i] > m[0] ? e[i] : m[0];
   }
   const uint64_t thr = kth_largest<1>(m, 1, k);
@@ -208,7 +209,7 @@ __device__ __forceinline__ uint32_t prune_list_exact(uint32_t* sc, uint16_t* tk,
     const unsigned long long b = __ballot(keep);
     if (keep) {
       const int w = base + prefix_below(b);
-      sc[w] = (uint32_t)(e[i] >> 32);
+      sc[w] = __float_as_uint(from_orderable((uint32_t)(e[i] >> 32)));
       tk[w] = (uint16_t)(0xffffu - (uint32_t)(e[i] & 0xffffu));
     }
     base += __popcll(b);
@@ -235,8 +236,19 @@ struct AffArgs {
   uint32_t* part_cnt;  // [splits][hw] live entries of each list
 };
 
-// LCAP: list slots per query; MINB: workgroups per CU the register / LDS budget is sized for
-template <int LCAP, int MINB>
+// key tile of the SHARED variant in LDS: [buffer][channel parity][token row][TROW floats]; a row holds
+// the 32 even (or odd) channels of one token; 36-float stride: 16-B aligned rows whose bank groups rotate
+constexpr int TROW = 36;
+
+// LCAP: list slots per query; MINB: workgroups per CU the register / LDS budget is sized for.
+// SHARED: the four waves of a workgroup (same token range, different queries) load every key tile ONCE,
+// coalesced (8 KiB contiguous: 2 x 16 B per lane), and pass it through LDS, de-interleaved into even /
+// odd channels so that each lane then reads exactly the 32 operands it feeds to the MFMAs with eight
+// 16-B LDS reads.  Without it every lane reads its own 256-B row (16 loads touching 64 cache lines
+// each, four times per workgroup): ~1 000 L1 line accesses per wave and tile against 4 100 MFMA
+// cycles -- the round-1 counters show the waves of that kernel waiting on memory for 34-51 % of their
+// cycles.  One s_barrier per tile (double-buffered tile).
+template <int LCAP, int MINB, bool SHARED>
 __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const AffArgs p) {
   constexpr int LSTRIDE = LCAP + 1;
   constexpr int E = (LCAP + 63) / 64;  // list entries per lane in a prune
@@ -244,17 +256,22 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
   static_assert(LCAP < 65536 && CAP == 64, "hand-over: one key per lane");
   static_assert(E * K_MAX <= LCAP - TOKT, "one exact prune (<= E*k survivors) must get below the in-loop limit");
   static_assert(2 * K_MAX <= CAP, "an exact prune of a two-entries-per-lane list must fit the hand-over");
-  __shared__ uint32_t s_sc[WAVES][QT][LSTRIDE];  // candidate scores (order-preserving bits)
+  __shared__ uint32_t s_sc[WAVES][QT][LSTRIDE];  // candidate scores (fp32 bits)
   __shared__ uint16_t s_tk[WAVES][QT][LSTRIDE];  // candidate tokens (offset inside this range)
   __shared__ __attribute__((aligned(16))) float s_ms[WAVES][TOKT];  // shrinkage / 8 of the current tile
   __shared__ __attribute__((aligned(16))) uint32_t s_rank[WAVES][64];  // scratch row of the prune
+  __shared__ __attribute__((aligned(16))) float s_tile[SHARED ? 2 : 1][2][SHARED ? TOKT : 1][SHARED ? TROW : 4];
+  __shared__ __attribute__((aligned(16))) float s_tms[2][TOKT];  // SHARED: shrinkage / 8, per tile buffer
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int l31 = lane & 31;
   const int half = lane >> 5;
   const int q0 = (blockIdx.x * WAVES + wave) * QT;
-  if (q0 >= p.hw) return;  // whole wave idle (no block-level barrier is used in this kernel)
+  // a wave without queries (ragged last query block): idle, except that in the SHARED variant it still
+  // loads its quarter of every tile and takes part in the barriers
+  const bool active = q0 < p.hw;
+  if (!SHARED && !active) return;
   const int split = blockIdx.y;
 
   // NB plain (non-volatile) LDS accesses: hipcc puts `s_waitcnt vmcnt(0)` next to every volatile
@@ -327,8 +344,37 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
     for (int j = 0; j < CK / 4 - 1; ++j) xbuf[j] = *reinterpret_cast<const f32x4_u*>(shifted + 4 * j);
     xbuf[CK / 4 - 1] = *reinterpret_cast<const f32x4*>(krow + CK - 4);
   };
+  // SHARED: wave w loads token rows 8w .. 8w+7 of a tile, lane L the 32 bytes (channels 8c .. 8c+7,
+  // c = L & 7) of row 8w + (L >> 3); wave 0 also loads the 32 shrinkage values
+  f32x4 g0, g1;
+  float g_ms = 0.0f;
+  auto load_shared = [&](int cyc_) {
+    const int tile = split + p.splits * cyc_;
+    const int n_mine = min(tile * TOKT + 8 * wave + (lane >> 3), p.n_total - 1);
+    const float* krow = (n_mine < p.n_long) ? (p.key_long + (int64_t)n_mine * CK)
+                                            : (p.key_work + (int64_t)(n_mine - p.n_long) * CK);
+    const f32x4* src = reinterpret_cast<const f32x4*>(krow + 8 * (lane & 7));
+    g0 = src[0];
+    g1 = src[1];
+    if (wave == 0 && lane < TOKT) {
+      const int n_s = min(tile * TOKT + lane, p.n_total - 1);
+      g_ms = (n_s < p.n_long) ? p.shr_long[n_s] : p.shr_work[n_s - p.n_long];  // scaled when stored: no wait here
+    }
+  };
+  auto store_shared = [&](int buf) {
+    const int r = 8 * wave + (lane >> 3), c4 = 4 * (lane & 7);
+    *reinterpret_cast<f32x4*>(&s_tile[buf][0][r][c4]) = f32x4{g0[0], g0[2], g1[0], g1[2]};  // channels 8c, +2, +4, +6
+    *reinterpret_cast<f32x4*>(&s_tile[buf][1][r][c4]) = f32x4{g0[1], g0[3], g1[1], g1[3]};  // channels 8c+1, +3, +5, +7
+    if (wave == 0 && lane < TOKT) s_tms[buf][lane] = g_ms * 0.125f;  // 1/sqrt(CK) folded in (exact)
+  };
   int cyc = 0;  // cyclic tile index of the current visit
-  if (n_my > 0) prefetch(cyc);
+  if (n_my > 0) {
+    if (SHARED) {
+      load_shared(cyc);
+    } else {
+      prefetch(cyc);
+    }
+  }
 
   // fast = rank-counting prune first; the exact prune runs if that left the list above the limit (or
   // alone if !fast).  One exact prune leaves <= E*k <= limit entries in the tile loop.
@@ -358,22 +404,44 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
     const int n_base = tile * TOKT;
     const uint32_t tok0 = (uint32_t)(cyc * TOKT + 4 * half);
 
-    // ---- prune lists that could overflow during this tile (at most 32 appends per query per tile)
-    prune_over((uint32_t)(LCAP - TOKT), true);
-
-    // ---- this tile's operand: channel 2t + half of this lane's token, then start the next loads
     float a_op[CK / 2];
+    if (SHARED) {
+      // ---- publish the tile loaded during the previous iteration, start loading the next one
+      store_shared(it & 1);
+      __syncthreads();
+      if (it + 1 < n_my) {
+        cyc = advance(cyc);
+        load_shared(cyc);
+      }
+      if (!active) continue;
+      prune_over((uint32_t)(LCAP - TOKT), true);
+      const float* arow = &s_tile[it & 1][half][l31][0];
 #pragma unroll
-    for (int j = 0; j < CK / 4 - 1; ++j) {
-      a_op[2 * j] = xbuf[j][0];
-      a_op[2 * j + 1] = xbuf[j][2];
+      for (int j = 0; j < CK / 8; ++j) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(arow + 4 * j);
+        a_op[4 * j] = v[0];
+        a_op[4 * j + 1] = v[1];
+        a_op[4 * j + 2] = v[2];
+        a_op[4 * j + 3] = v[3];
+      }
+      msl = &s_tms[it & 1][0];
+    } else {
+      // ---- prune lists that could overflow during this tile (at most 32 appends per query per tile)
+      prune_over((uint32_t)(LCAP - TOKT), true);
+
+      // ---- this tile's operand: channel 2t + half of this lane's token, then start the next loads
+#pragma unroll
+      for (int j = 0; j < CK / 4 - 1; ++j) {
+        a_op[2 * j] = xbuf[j][0];
+        a_op[2 * j + 1] = xbuf[j][2];
+      }
+      a_op[CK / 2 - 2] = half ? xbuf[CK / 4 - 1][1] : xbuf[CK / 4 - 1][0];
+      a_op[CK / 2 - 1] = half ? xbuf[CK / 4 - 1][3] : xbuf[CK / 4 - 1][2];
+      if (lane < TOKT) msl[lane] = ms_buf;
+      DEVA_COMPILER_FENCE();
+      if (it + 1 < n_my) cyc = advance(cyc);
+      prefetch(cyc);
     }
-    a_op[CK / 2 - 2] = half ? xbuf[CK / 4 - 1][1] : xbuf[CK / 4 - 1][0];
-    a_op[CK / 2 - 1] = half ? xbuf[CK / 4 - 1][3] : xbuf[CK / 4 - 1][2];
-    if (lane < TOKT) msl[lane] = ms_buf;
-    DEVA_COMPILER_FENCE();
-    if (it + 1 < n_my) cyc = advance(cyc);
-    prefetch(cyc);
 
     f32x16 accA, accB;
 #pragma unroll
@@ -415,10 +483,11 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
           if (!full_tile) ok = ok && (j0 + 4 * half < rows_left);
           const unsigned long long b = __ballot(ok);
           if (b) {
-            const uint32_t ok_lo = (uint32_t)(b >> l31) & 1u, ok_hi = (uint32_t)(b >> (32 + l31)) & 1u;
+            // the two half-lanes of query l31 are lanes l31 and 32 + l31: one 32-bit bit-field extract each
+            const uint32_t ok_lo = ((uint32_t)b >> l31) & 1u, ok_hi = ((uint32_t)(b >> 32) >> l31) & 1u;
             if (ok) {
               const uint32_t pos = cnt + (half ? ok_lo : 0u);
-              srow[pos] = orderable(v);
+              srow[pos] = __float_as_uint(v);  // raw bits: ordered when a list is pruned / handed over
               trow[pos] = (uint16_t)(tok0 + j0);
             }
             cnt += ok_lo + ok_hi;
@@ -440,6 +509,7 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
   // selection over all ranges happens in the merge kernel, where one wave per query gives thousands of
   // independent waves -- here it would run serially, 32 lists per wave.
   static_assert(LCAP <= 192, "two exact rounds must reach CAP");
+  if (!active) return;
   prune_over((uint32_t)CAP, true);
   prune_over((uint32_t)CAP, false);
   DEVA_COMPILER_FENCE();
@@ -451,7 +521,8 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
     if ((uint32_t)lane < c) {
       const uint32_t off = (uint32_t)ctk[ql * LSTRIDE + lane];
       const uint32_t token = ((off >> 5) * (uint32_t)p.splits + (uint32_t)split) * TOKT + (off & 31u);
-      dst[(int64_t)ql * CAP + lane] = ((uint64_t)csc[ql * LSTRIDE + lane] << 32) | (uint64_t)(~token);
+      dst[(int64_t)ql * CAP + lane] =
+          ((uint64_t)orderable(__uint_as_float(csc[ql * LSTRIDE + lane])) << 32) | (uint64_t)(~token);
     }
   }
 }
@@ -607,25 +678,23 @@ extern "C" int64_t deva_affinity_workspace(int hw, int k, int splits) {
   return (int64_t)splits * hw * CAP + ((int64_t)splits * hw + 1) / 2;
 }
 
-// 0: pick by shape; 1: 176-slot lists, one workgroup per CU; 2: 100-slot lists, two workgroups per CU
-static int affinity_shape_override() {
-  static const int v = [] {
+// kernel shapes: 1 = 176-slot lists, one workgroup per CU, every lane loads its own key row;
+// 2 = 100-slot lists, two workgroups per CU (small frames: twice the resident workgroups);
+// 3 = 176-slot lists, one workgroup per CU, key tiles loaded once per workgroup through LDS.
+// DEVA_AFFINITY_SHAPE overrides the choice (tuning / A-B measurements only).
+static int affinity_shape(int n_total, int hw) {
+  static const int forced = [] {
     const char* e = getenv("DEVA_AFFINITY_SHAPE");
     return e ? atoi(e) : 0;
   }();
-  return v;
-}
-
-static bool affinity_dual(int n_total, int hw) {
+  if (forced >= 1 && forced <= 3) return forced;
   (void)n_total;
-  (void)hw;
-  const int o = affinity_shape_override();
-  return o == 0 ? true : o == 2;
+  return hw >= 4096 ? 3 : 2;  // >= 32 query blocks fill the chip with one workgroup per CU
 }
 
 extern "C" int deva_affinity_default_splits(int n_total, int hw) {
   // aim at one resident set of workgroups: 256 CUs x (1 or 2) four-wave workgroups
-  const int slots = affinity_dual(n_total, hw) ? 512 : 256;
+  const int slots = affinity_shape(n_total, hw) == 2 ? 512 : 256;
   const int qblocks = (int)ceil_div(hw, WAVES * QT);
   const int tiles = (int)ceil_div(n_total, TOKT);
   int s = (int)ceil_div(slots, qblocks);
@@ -672,10 +741,15 @@ extern "C" int deva_affinity_topk(const float* key_long, const float* shr_long, 
   a.part = part_keys;
   a.part_cnt = reinterpret_cast<uint32_t*>(part_keys + (int64_t)splits * hw * CAP);
   dim3 grid((unsigned)ceil_div(hw, WAVES * QT), (unsigned)splits);
-  if (affinity_dual((int)n_total, hw)) {
-    hipLaunchKernelGGL((affinity_topk_kernel<LCAP_DUAL, 2>), grid, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
-  } else {
-    hipLaunchKernelGGL((affinity_topk_kernel<LCAP_WIDE, 1>), grid, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
+  switch (affinity_shape((int)n_total, hw)) {
+    case 1:
+      hipLaunchKernelGGL((affinity_topk_kernel<LCAP_WIDE, 1, false>), grid, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
+      break;
+    case 2:
+      hipLaunchKernelGGL((affinity_topk_kernel<LCAP_DUAL, 2, false>), grid, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
+      break;
+    default:
+      hipLaunchKernelGGL((affinity_topk_kernel<LCAP_WIDE, 1, true>), grid, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
   }
   return check_launch("deva_affinity_topk");
 }
