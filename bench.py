@@ -16,21 +16,34 @@ and the max-over-ranks reduction) -> "scaling": "weak".
 
 Extra objects on the JSON line:
   roofline      dominant kernel (conv implicit GEMM, fp32 MFMA): algorithmic FLOPs of every launch
-                / its HIP-event duration, measured in an instrumented pass right after the timed
-                region (so event overhead never touches `value`); peak = 157.3 TFLOP/s fp32 matrix.
+                / its HIP-event duration.  The events are recorded on the launch stream around every
+                deva_conv2d call WITHOUT any synchronisation, in a pass that replays the same number of
+                frames right after the timed region (event overhead never touches `value`); the stream
+                stays busy back to back, so an event pair brackets exactly the kernel(s) of its launch
+                at the clocks of the real frame loop.  peak = 157.3 TFLOP/s fp32 matrix.  `traffic` =
+                HBM bytes per frame of those kernels from the committed rocprofv3 --pmc passes over
+                this same command (profiles/pmc_r02/conv_traffic.json; bench.py cannot collect PMC
+                counters itself), next to the algorithmic bytes per frame computed here.
   affinity      the north-star kernel (fused similarity/top-k/softmax): event-timed at the
                 BASELINE shape (N=10 000 bank, 1080p queries), reported against the fp32-MFMA roof
                 that binds it and as HBM GB/s on algorithmic and on materialised-equivalent bytes
                 (SURVEY.md §8d asks for all three).
   cpu_baseline  the CPU oracle (port of the reference's PyTorch path) on the same workload, on this
-                box's host cores, for a bounded sample of frames.
-  extra         1080p / 10k-token long-term bank propagation FPS (BASELINE target line) and the
-                4K / 50k-token bank FPS of configs[4] on this GPU.
+                box's host cores: median of 3 runs over a bounded sample of frames, with per-stage ms.
+  also          further lines of BASELINE.json's metric, each with its own warm-up and timed frames:
+                1080p / detections every 5th frame / 10k-token long-term bank (BASELINE configs[2] and
+                the north-star target line) and 4K / 50k-token bank (configs[4] on this one GPU).  Each
+                names the -m gpu test that gates its parity.
 
 `--workload long4k` runs BASELINE configs[4] instead: ONE 2160x3840 clip with a 50 000-token
-long-term bank on N GPUs -- every rank steps the same clip (replicated bank), the memory read is
-sharded by query column with an RCCL all-gather of the read-out columns and an all-reduce of the
-usage counters (MemoryManager.shard_queries) -> "scaling": "strong".
+long-term bank on N GPUs, `--long4k_mode`:
+  owner    (default) rank 0 alone encodes / decodes; it broadcasts the query key / selection, every rank
+           matches and reads out its share of the query columns against its replica of the bank, the
+           read-out columns are gathered to rank 0, usage counters all-reduced, new memory rows broadcast;
+  queries  every rank steps the whole clip, only the memory read is sharded by query column (all-gather);
+  bank     memory read sharded by token range: per-shard top-k keys all-gathered and merged exactly,
+           partial read-outs all-reduced.
+-> "scaling": "strong"; the line reports the bytes every rank moved per frame next to the FPS.
 """
 import argparse
 import json
@@ -66,30 +79,34 @@ def make_clip(height, width, n_frames, seed, device):
     return [stream.next().to(device) for _ in range(n_frames)]
 
 
-def start_clip(net, cfg, frames, num_objects, device, lt_prefill=0, shard=False):
-    """annotated first frame (+ optional pre-filled long-term bank)"""
+def start_clip(net, cfg, frames, num_objects, device, lt_prefill=0, shard=None):
+    """annotated first frame (+ optional pre-filled long-term bank); shard =
+    None | 'owner' | 'queries' | 'bank' (one clip on all ranks of the process group)"""
     from workload import synth
     from deva.inference.inference_core import DEVAInferenceCore
     core = DEVAInferenceCore(net, cfg)
-    if shard:
-        core.memory.shard_queries()
+    if shard == 'bank':
+        core.memory.shard_bank()
+    elif shard is not None:
+        core.memory.shard_queries(owner=0 if shard == 'owner' else None)
     h, w = frames[0].shape[-2:]
     mask = synth.box_mask(h, w, num_objects).to(device)
-    core.step(frames[0], mask, list(range(1, num_objects + 1)))
+    objects = list(range(1, num_objects + 1))
+    core.step(frames[0], mask, objects)
     if lt_prefill:
-        g = torch.Generator().manual_seed(1)
-        key = torch.randn(64, lt_prefill, generator=g).to(device)
-        shr = (torch.rand(1, lt_prefill, generator=g) + 1).to(device)
-        vals = {o: torch.randn(512, lt_prefill, generator=g).to(device) for o in range(1, num_objects + 1)}
-        core.memory.long_mem.add(key, vals, shr, selection=None, supposed_bucket_id=0)
+        key, shr, vals = synth.prefill_bank(lt_prefill, objects, seed=1)
+        core.memory.long_mem.add(key.to(device), {o: v.to(device) for o, v in vals.items()}, shr.to(device),
+                                 selection=None, supposed_bucket_id=0)
     return core
 
 
 class ConvTimer:
-    """HIP-event timing of every deva_conv2d launch.  The events are recorded on torch's current
-    stream (the stream the kernels are launched on) immediately around the C call, with a device
-    sync before each launch so that the interval is the kernel(s) of that launch and not host-side
-    gaps (the un-instrumented frame loop is GPU-bound, the instrumented one would not be)."""
+    """HIP-event timing of every deva_conv2d launch WITHOUT synchronisation: the two events are recorded
+    on torch's current stream (the stream the kernels are launched on) immediately around the C call.
+    The frame loop is GPU-bound (the stream stays busy back to back), so an event pair brackets exactly
+    the kernel(s) of its launch -- the implicit-GEMM kernel and, for split-K layers, its reduction -- at the
+    clocks of the real frame loop.  (Round 1 synchronised before every launch, which let the chip boost
+    on big layers and charged launch latency to small ones.)"""
 
     def __init__(self):
         from deva.hip import lib
@@ -102,14 +119,21 @@ class ConvTimer:
             d = desc_ref._obj if hasattr(desc_ref, '_obj') else desc_ref
             oh = (d.height + 2 * d.pad - d.kh) // d.stride + 1
             ow = (d.width + 2 * d.pad - d.kw) // d.stride + 1
-            flops = 2.0 * d.cout * (d.c0 + d.c1) * d.kh * d.kw * d.batch * oh * ow
-            sig = (d.c0 + d.c1, d.cout, d.kh, d.stride, d.batch, oh, ow)
-            torch.cuda.synchronize()
+            cin = d.c0 + d.c1
+            flops = 2.0 * d.cout * cin * d.kh * d.kw * d.batch * oh * ow
+            # algorithmic bytes: every operand once (a broadcast operand has batch stride 0)
+            b0 = d.batch if d.in0_batch_stride else 1
+            b1 = d.batch if d.in1_batch_stride else 1
+            br = d.batch if d.residual_batch_stride else 1
+            nbytes = 4.0 * (d.c0 * b0 * d.height * d.width + d.c1 * b1 * d.height * d.width
+                            + cin * d.kh * d.kw * d.cout + d.cout * oh * ow * d.batch
+                            + (d.cout * oh * ow * br if d.residual else 0) + (d.cout if d.bias else 0))
+            sig = (cin, d.cout, d.kh, d.stride, d.batch, oh, ow)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             rc = self.real(desc_ref, stream)
             e.record()
-            self.records.append((flops, s, e, sig))
+            self.records.append((flops, s, e, sig, nbytes))
             return rc
 
         self.handle.deva_conv2d = timed
@@ -122,12 +146,12 @@ class ConvTimer:
     def summary(self):
         flops = sum(r[0] for r in self.records)
         ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
-        return flops, ms, len(self.records)
+        return flops, ms, len(self.records), sum(r[4] for r in self.records)
 
     def per_layer(self, frames):
         """time and achieved TFLOP/s per distinct (cin, cout, k, stride, batch, OH, OW)"""
         agg = {}
-        for fl, s, e, sig in self.records:
+        for fl, s, e, sig, _ in self.records:
             a = agg.setdefault(sig, [0, 0.0, 0.0])
             a[0] += 1
             a[1] += fl
@@ -140,11 +164,11 @@ class ConvTimer:
 
 def affinity_microbench(device, n=10000, hw=8160, k=30, iters=20):
     from deva.hip import ops
-    g = torch.Generator().manual_seed(0)
-    key = torch.randn(n, 64, generator=g).to(device)
-    shr = (torch.rand(n, generator=g) + 1).to(device)
-    qk = torch.randn(64, hw, generator=g).to(device)
-    qe = torch.rand(64, hw, generator=g).to(device)
+    from workload import synth
+    mk, ms, qk, qe = synth.affinity_inputs(n, hw, seed=0)  # SURVEY.md §8d kernel-only inputs
+    key = mk.t().contiguous().to(device)
+    shr = ms.reshape(-1).contiguous().to(device)
+    qk, qe = qk.to(device), qe.to(device)
     fix = torch.zeros(n, dtype=torch.int64, device=device)
     L = __import__('deva.hip', fromlist=['lib']).lib()
     splits = L.deva_affinity_default_splits(n, hw)
@@ -176,22 +200,55 @@ def affinity_microbench(device, n=10000, hw=8160, k=30, iters=20):
                 bound='mfma_fp32', achieved_tflops=flops / t / 1e12, peak_tflops=PEAK_FP32_MATRIX_TFLOPS,
                 frac=flops / t / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
                 hbm_algorithmic_gbps=b_alg / t / 1e9, hbm_algorithmic_frac=b_alg / t / 1e9 / PEAK_HBM_GBPS,
-                hbm_materialised_equiv_gbps=b_mat / t / 1e9)
+                hbm_materialised_equiv_gbps=b_mat / t / 1e9,
+                parity_gate='tests/test_gpu_g_fullsize.py::test_affinity_at_bench_shapes')
 
 
-def cpu_baseline(sd, cfg, height, width, num_objects, frames_cpu):
+def cpu_baseline(sd, cfg, height, width, num_objects, frames_cpu, repeats=3):
+    """the CPU oracle on the first frames of the same clip: median FPS of `repeats` runs and per-stage
+    milliseconds per propagated frame (stage timers wrapped around the oracle's own functions)"""
     from oracle import deva_oracle as O
     from workload import synth
-    core = O.OracleCore(sd, cfg)
-    mask = synth.box_mask(height, width, num_objects)
-    core.step(frames_cpu[0], mask, list(range(1, num_objects + 1)))
-    t0 = time.perf_counter()
-    for f in frames_cpu[1:]:
-        core.step(f)
-    dt = time.perf_counter() - t0
+    stages = {}
+
+    def timed(name, fn):
+        def wrapper(*a, **kw):
+            t0 = time.perf_counter()
+            out = fn(*a, **kw)
+            stages[name] = stages.get(name, 0.0) + time.perf_counter() - t0
+            return out
+        return wrapper
+
+    names = ('encode_image', 'transform_key', 'segment', 'encode_mask')
+    saved = {n: getattr(O, n) for n in names}
+    mem_saved = (O.OracleMemory.match, O.OracleMemory.add)
+    for n in names:
+        setattr(O, n, timed(n, saved[n]))
+    O.OracleMemory.match = timed('match_memory', mem_saved[0])
+    O.OracleMemory.add = timed('add_memory', mem_saved[1])
+    fps = []
     n = len(frames_cpu) - 1
-    return dict(value=n / dt, unit='frames/s', cores=torch.get_num_threads(), kind='port',
-                sample=f'{n} propagated frames after the annotated one, same workload (CPU oracle, fp32)')
+    try:
+        mask = synth.box_mask(height, width, num_objects)
+        for _ in range(repeats):
+            core = O.OracleCore(sd, cfg)
+            core.step(frames_cpu[0], mask, list(range(1, num_objects + 1)))
+            stages.clear()
+            t0 = time.perf_counter()
+            for f in frames_cpu[1:]:
+                core.step(f)
+            fps.append(n / (time.perf_counter() - t0))
+    finally:
+        for k_, v in saved.items():
+            setattr(O, k_, v)
+        O.OracleMemory.match, O.OracleMemory.add = mem_saved
+    fps.sort()
+    kind = 'port'  # oracle/deva_oracle.py; /root/reference (the "reference" kind) does not exist on the GPU box
+    return dict(value=fps[len(fps) // 2], unit='frames/s', cores=torch.get_num_threads(), kind=kind,
+                runs_fps=fps, stage_ms_per_frame={k_: 1e3 * v / n for k_, v in stages.items()},
+                sample=f'median of {repeats} runs over {n} propagated frames after the annotated one (memory frames '
+                       f'every {cfg["mem_every"]}th), same workload and weights (CPU oracle, fp32); stage times '
+                       'are of the last run')
 
 
 def timed_region(fn, dist=None, device=None):
@@ -222,8 +279,9 @@ def whole_job_fps(steps_per_rank: int, world: int, elapsed: float) -> float:
 
 
 def run_long4k(net, device, steps, warmup, seed, shard, dist):
-    """BASELINE configs[4]: one 4K clip, 1 object, 50 000-token long-term bank.  With `shard` the
-    memory read is partitioned by query column over the process group (every rank steps the clip)."""
+    """BASELINE configs[4]: one 4K clip, 1 object, 50 000-token long-term bank.  shard = None (one GPU) |
+    'owner' | 'queries' | 'bank' (MemoryManager modes, all ranks of the group step the same clip).
+    -> (FPS, bank sizes at the end, collective bytes this rank moved per timed frame)"""
     from workload import synth
     cfg = synth.base_config(max_long_term_elements=50000)
     n_frames = 1 + warmup + steps
@@ -231,6 +289,7 @@ def run_long4k(net, device, steps, warmup, seed, shard, dist):
     core = start_clip(net, cfg, frames, 1, device, lt_prefill=50000 - cfg['num_prototypes'], shard=shard)
     for t in range(1, 1 + warmup):
         core.step(frames[t])
+    comm0 = core.memory.comm_bytes
 
     def timed_steps():
         for t in range(1 + warmup, n_frames):
@@ -240,12 +299,52 @@ def run_long4k(net, device, steps, warmup, seed, shard, dist):
     mem = core.memory
     bank = {'long': {b: mem.long_mem.size(b) for b in mem.long_mem.buckets},
             'work': {b: mem.work_mem.size(b) for b in mem.work_mem.buckets}}
-    return steps / elapsed, bank
+    return steps / elapsed, bank, (mem.comm_bytes - comm0) / steps
+
+
+def run_1080p_detections(net, device, steps, warmup, seed=7):
+    """BASELINE configs[2] / the north-star target line: 1920x1080 (padded 1088x1920), one detected object,
+    detections merged every 5th frame through incorporate_detection, long-term memory pre-filled to 10 000
+    tokens, propagation in between (the workload of tests/test_gpu_g_fullsize.py::
+    test_1080p_detections_10k_bank_against_oracle, with the default mem_every=5)"""
+    from workload import synth
+    from deva.inference.inference_core import DEVAInferenceCore
+    from deva.inference.object_info import ObjectInfo
+    H, W, every = 1080, 1920, 5
+    cfg = synth.base_config(max_missed_detection_count=5, max_num_objects=-1)
+    n_frames = 1 + warmup + steps
+    frames = make_clip(H, W, n_frames, seed=seed, device=device)
+    dets = {t: synth.detection_frame(H, W, t, segments=1) for t in range(0, n_frames, every)}
+    dets = {t: (m.to(device), info) for t, (m, info) in dets.items()}
+    core = DEVAInferenceCore(net, cfg)
+
+    def run(t):
+        if t in dets:
+            m, info = dets[t]
+            core.incorporate_detection(frames[t], m, [ObjectInfo(**i) for i in info])
+        else:
+            core.step(frames[t])
+
+    run(0)
+    key, shr, vals = synth.prefill_bank(10000, core.object_manager.all_obj_ids, seed=1)
+    core.memory.long_mem.add(key.to(device), {o: v.to(device) for o, v in vals.items()}, shr.to(device),
+                             selection=None, supposed_bucket_id=0)
+    for t in range(1, 1 + warmup):
+        run(t)
+    elapsed = timed_region(lambda: [run(t) for t in range(1 + warmup, n_frames)], None, device)
+    mem = core.memory
+    return steps / elapsed, {'long': {b: mem.long_mem.size(b) for b in mem.long_mem.buckets},
+                             'work': {b: mem.work_mem.size(b) for b in mem.work_mem.buckets},
+                             'objects': core.object_manager.num_obj}
 
 
 def long4k(args, net, rank, world, device, dist):
     """`--workload long4k`: strong scaling of ONE clip over the GPUs of the node"""
-    fps, bank = run_long4k(net, device, args.steps, args.warmup, seed=11, shard=dist is not None, dist=dist)
+    mode = args.long4k_mode if dist is not None else None
+    fps, bank, comm = run_long4k(net, device, args.steps, args.warmup, seed=11, shard=mode, dist=dist)
+    what = {None: 'one GPU', 'owner': 'frame owner (rank 0 encodes / decodes) + query-sharded read',
+            'queries': 'every rank steps the clip, query-sharded read',
+            'bank': 'every rank steps the clip, token-sharded read (candidate keys all-gathered, exact merge)'}[mode]
     if rank == 0:
         print(json.dumps({
             'metric': 'propagation FPS @4K (1 object, 50k-token long-term bank)',
@@ -253,9 +352,9 @@ def long4k(args, net, rank, world, device, dist):
             'ms_per_step': 1e3 / fps, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[4]: one synthetic 3840x2160 clip, 1 object, long-term memory '
-                                   'pre-filled to 50 000 tokens; bank replicated, memory read sharded by query column',
-                       'bank_tokens_at_end': bank,
-                       'parallelism': f'query-sharded memory read x{world} (all-gather read-out, all-reduce usage)'},
+                                   'pre-filled to 50 000 tokens',
+                       'bank_tokens_at_end': bank, 'parallelism': f'{what} x{world}',
+                       'collective_bytes_per_frame_rank0': comm},
         }))
     if dist is not None:
         dist.barrier()
@@ -271,6 +370,8 @@ def main():
     ap.add_argument('--width', type=int, default=854)
     ap.add_argument('--objects', type=int, default=5)
     ap.add_argument('--workload', choices=['clips', 'long4k'], default='clips')
+    ap.add_argument('--long4k_mode', choices=['owner', 'queries', 'bank'], default='owner')
+    ap.add_argument('--cpu_frames', type=int, default=10, help='propagated frames per CPU-baseline run (3 runs)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_extra', action='store_true')
     args = ap.parse_args()
@@ -328,71 +429,76 @@ def main():
     }
 
     if rank == 0:
-        # ---- roofline of the dominant kernel, instrumented pass continuing the same clip
-        extra_frames = make_clip(args.height, args.width, 5, seed=999, device=device)
+        # ---- roofline of the dominant kernel: event-timed replay of as many frames, continuing the same clip
+        # (un-synchronised events, see ConvTimer); warm the replay with two frames first
+        replay = make_clip(args.height, args.width, args.steps + 2, seed=999, device=device)
+        for f in replay[:2]:
+            core.step(f)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         with ConvTimer() as ct:
-            for f in extra_frames:
+            for f in replay[2:]:
                 core.step(f)
-        flops, ms, launches = ct.summary()
+        replay_ms = (time.perf_counter() - t0) * 1e3 / args.steps
+        flops, ms, launches, alg_bytes = ct.summary()
+        n_replay = args.steps
         if os.environ.get('DEVA_BENCH_LAYERS'):
             with open(os.environ['DEVA_BENCH_LAYERS'], 'w') as f:
-                json.dump(ct.per_layer(len(extra_frames)), f, indent=1)
+                json.dump(ct.per_layer(n_replay), f, indent=1)
         ach = flops / (ms * 1e-3) / 1e12
         result['roofline'] = {
-            'kernel': 'conv_igemm_kernel (deva_conv2d, fp32 MFMA implicit GEMM)',
+            'kernel': 'conv_igemm_kernel (+ splitk_reduce_kernel / conv_cout1 kernels of the same deva_conv2d call), '
+                      'fp32 MFMA implicit GEMM',
             'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MATRIX_TFLOPS, 'unit': 'TFLOP/s',
             'frac': ach / PEAK_FP32_MATRIX_TFLOPS, 'traffic': None,
-            'launches_per_frame': launches / len(extra_frames),
-            'gflop_per_frame': flops / len(extra_frames) / 1e9,
-            'ms_in_kernel_per_frame': ms / len(extra_frames),
+            'method': 'HIP events around every deva_conv2d launch on the launch stream, no synchronisation, '
+                      f'{n_replay} frames replayed after the timed region',
+            'launches_per_frame': launches / n_replay,
+            'gflop_per_frame': flops / n_replay / 1e9,
+            'ms_in_kernel_per_frame': ms / n_replay,
+            'ms_per_frame_of_the_instrumented_replay': replay_ms,
+            'algorithmic_bytes_per_frame': alg_bytes / n_replay,
         }
-        # HBM traffic of the heaviest launch of that kernel (3x3 256->256 on the 1/4-resolution map), from
-        # the committed rocprofv3 --pmc passes (separate runs; FETCH_SIZE doubled per the gfx950 note of
-        # MI355X_MICROARCH.md).  `traffic` stays null: bench.py cannot collect PMC counters itself.
-        pmc = os.path.join(ROOT, 'profiles', 'pmc_r01', 'rowconv_per_launch.json')
+        # HBM traffic of these kernels per frame, from the committed rocprofv3 --pmc passes over this same
+        # command (tools/pmc_bench.sh; FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes)
+        pmc = os.path.join(ROOT, 'profiles', 'pmc_r02', 'conv_traffic.json')
         if os.path.exists(pmc):
             with open(pmc) as f:
                 d = json.load(f)
-            rd = [v for k, v in d.items() if k.startswith('hbm_read_bytes')][0]
-            wr = [v for k, v in d.items() if k.startswith('hbm_write_bytes')][0]
-            alg = [v for k, v in d.items() if k.startswith('algorithmic_bytes')][0]
-            result['roofline']['pmc_heaviest_launch'] = {
-                'source': 'profiles/pmc_r01/rowconv_per_launch.json', 'hbm_bytes': rd + wr, 'algorithmic_bytes': alg,
-                'mfma_util': d['mfma_util_frac'], 'l2_hit_rate': d['l2_hit_rate'],
-                'clock_adjusted_peak_tflops': d['clock_adjusted_peak_tflops']}
+            result['roofline']['traffic'] = d['hbm_bytes_per_frame']
+            result['roofline']['traffic_source'] = 'profiles/pmc_r02/conv_traffic.json'
+            result['roofline']['traffic_over_algorithmic'] = d['hbm_bytes_per_frame'] / (alg_bytes / n_replay)
         result['affinity'] = affinity_microbench(device)
-        pmc_aff = os.path.join(ROOT, 'profiles', 'pmc_r01', 'affinity_per_launch.json')
+        pmc_aff = os.path.join(ROOT, 'profiles', 'pmc_r02', 'affinity_per_launch.json')
         if os.path.exists(pmc_aff):
             with open(pmc_aff) as f:
                 d = json.load(f)['10k']
-            result['affinity']['pmc'] = {'source': 'profiles/pmc_r01/affinity_per_launch.json', 'mfma_util': d['mfma_util_frac'],
+            result['affinity']['pmc'] = {'source': 'profiles/pmc_r02/affinity_per_launch.json',
+                                         'mfma_util': d['mfma_util_frac'],
+                                         'hbm_bytes': d.get('hbm_bytes'), 'algorithmic_bytes': d.get('algorithmic_bytes'),
                                          'valu_instructions_per_tile': d['per_wave_per_tile']['SQ_INSTS_VALU'],
-                                         'mfma_instructions_per_tile': d['per_wave_per_tile']['SQ_INSTS_MFMA'],
-                                         'l2_hit_rate': d['l2_hit_rate']}
+                                         'mfma_instructions_per_tile': d['per_wave_per_tile']['SQ_INSTS_MFMA']}
         if not args.no_extra:
-            cfg_lt = synth.base_config()
-            f1080 = make_clip(1080, 1920, 12, seed=7, device=device)
-            core2 = start_clip(net, cfg_lt, f1080, 1, device, lt_prefill=10000)
-            core2.step(f1080[1])
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for f in f1080[2:]:
-                core2.step(f)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t1
-            result['extra'] = {
-                'fps_1080p_1obj_10k_longterm_bank': (len(f1080) - 2) / dt,
-                'note': 'BASELINE target line: 1920x1080 (padded 1088x1920), 1 object, long-term memory '
-                        'pre-filled with 10 000 tokens + working memory, 10 propagated frames',
-            }
-            del core2, f1080
-            fps4k, bank4k = run_long4k(net, device, steps=6, warmup=2, seed=11, shard=False, dist=None)
-            result['extra']['fps_4k_1obj_50k_longterm_bank'] = fps4k
-            result['extra']['note_4k'] = ('BASELINE configs[4] on one GPU: 3840x2160, 1 object, long-term memory '
-                                          f'pre-filled with 50 000 tokens, bank at end {bank4k}; 6 propagated frames')
+            del core
+            fps1080, state1080 = run_1080p_detections(net, device, steps=25, warmup=6)
+            fps4k, bank4k, _ = run_long4k(net, device, steps=20, warmup=5, seed=11, shard=None, dist=None)
+            result['also'] = [
+                {'metric': 'propagation FPS @1080p (detections every 5th frame, 10k-token long-term bank)',
+                 'value': fps1080, 'unit': 'frames/s', 'steps': 25, 'warmup': 6, 'ms_per_step': 1e3 / fps1080,
+                 'config': {'workload': 'BASELINE configs[2] / north-star target line: synthetic 1920x1080 clip (padded '
+                                        '1088x1920), one detected object merged through incorporate_detection every 5th '
+                                        'frame, long-term memory pre-filled to 10 000 tokens + working memory',
+                            'state_at_end': state1080},
+                 'target_fps': 30.0,
+                 'parity_gate': 'tests/test_gpu_g_fullsize.py::test_1080p_detections_10k_bank_against_oracle'},
+                {'metric': 'propagation FPS @4K (1 object, 50k-token long-term bank), one GPU',
+                 'value': fps4k, 'unit': 'frames/s', 'steps': 20, 'warmup': 5, 'ms_per_step': 1e3 / fps4k,
+                 'config': {'workload': 'BASELINE configs[4] on ONE GPU: synthetic 3840x2160 clip, 1 object, long-term '
+                                        'memory pre-filled to 50 000 tokens', 'bank_tokens_at_end': bank4k},
+                 'parity_gate': 'tests/test_gpu_g_fullsize.py::test_4k_lockstep + test_affinity_at_bench_shapes'},
+            ]
         if not args.no_cpu_baseline and world == 1:
-            n_cpu = 4
-            frames_cpu = [f.cpu() for f in frames[:1 + n_cpu]]
+            frames_cpu = [f.cpu() for f in frames[:1 + min(args.cpu_frames, len(frames) - 1)]]
             result['cpu_baseline'] = cpu_baseline(sd, cfg, args.height, args.width, args.objects, frames_cpu)
         print(json.dumps(result))
     if distributed:

@@ -1,0 +1,130 @@
+#!/usr/bin/env python
+"""Summarise rocprofv3 --pmc passes (one run per counter group, tools/pmc_bench.sh / pmc_affinity.sh) into
+the per-launch / per-frame JSON files committed under profiles/pmc_rNN/.
+
+    python tools/pmc_summary.py conv  gpurun_out/pmc/bench  profiles/pmc_r02/conv_traffic.json
+    python tools/pmc_summary.py aff   gpurun_out/pmc/aff    profiles/pmc_r02/affinity_per_launch.json
+
+Counters are averaged per dispatch of a kernel over all its dispatches in a pass.  FETCH_SIZE / WRITE_SIZE
+are reported in KiB by rocprofv3; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so read bytes =
+FETCH_SIZE x 1024 x 2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE x 1024 is taken as is (uncalibrated)."""
+import csv
+import glob
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def load(prefix):
+    """-> {kernel name: {counter: [sum, dispatches]}}, {kernel name: [duration sum ns, dispatches]}"""
+    counters = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    durations = defaultdict(lambda: [0.0, set()])
+    for path in sorted(glob.glob(prefix + '_g*_counter_collection.csv')):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                name = re.sub(r'\(.*', '', row['Kernel_Name']).replace('deva::(anonymous namespace)::', '')
+                name = re.sub(r'^void ', '', name)
+                c = counters[name][row['Counter_Name']]
+                c[0] += float(row['Counter_Value'])
+                c[1] += 1
+                key = (path, row['Dispatch_Id'])
+                if key not in durations[name][1]:
+                    durations[name][1].add(key)
+                    durations[name][0] += float(row['End_Timestamp']) - float(row['Start_Timestamp'])
+    return counters, {k: (v[0], len(v[1])) for k, v in durations.items()}
+
+
+def conv(prefix, out):
+    counters, durations = load(prefix)
+    is_conv = lambda n: n.startswith('conv_') or n.startswith('splitk_reduce')
+    frames = counters.get('upsample4x_softmax_kernel', {}).get('FETCH_SIZE', [0, 0])[1]
+    frames = max(frames, 1) + 1  # one decoder pass per propagated frame + the annotated first frame
+    rd = sum(c['FETCH_SIZE'][0] for n, c in counters.items() if is_conv(n) and 'FETCH_SIZE' in c) * 1024 * 2
+    wr = sum(c['WRITE_SIZE'][0] for n, c in counters.items() if is_conv(n) and 'WRITE_SIZE' in c) * 1024
+    per_kernel = {}
+    for n, c in counters.items():
+        if not is_conv(n):
+            continue
+        per_kernel[n] = {k: v[0] / v[1] for k, v in c.items()}
+        per_kernel[n]['dispatches_per_pass'] = max(v[1] for v in c.values())
+    res = {
+        'command': 'python bench.py --steps 5 --warmup 2 --no_cpu_baseline --no_extra (480p, 5 objects)',
+        'frames_in_a_pass': frames,
+        'hbm_read_bytes_per_frame (FETCH_SIZE KiB x 1024 x 2, gfx950 correction)': rd / frames,
+        'hbm_write_bytes_per_frame (WRITE_SIZE KiB x 1024)': wr / frames,
+        'hbm_bytes_per_frame': (rd + wr) / frames,
+        'kernels': 'conv_igemm_kernel*, splitk_reduce_kernel, conv_cout1 kernels (everything deva_conv2d launches)',
+        'per_dispatch_averages': per_kernel,
+    }
+    g = counters.get('conv_igemm_kernel', None) or next((c for n, c in counters.items() if n.startswith('conv_igemm')), {})
+    if 'SQ_INSTS_MFMA' in g and 'SQ_VALU_MFMA_BUSY_CYCLES' in g and 'GRBM_GUI_ACTIVE' in g:
+        # busy cycles are summed over the SIMDs: 1024 SIMDs x active cycles = 100 %
+        res['conv_igemm_mfma_util_frac'] = (g['SQ_VALU_MFMA_BUSY_CYCLES'][0] / g['SQ_VALU_MFMA_BUSY_CYCLES'][1]) / (
+            g['GRBM_GUI_ACTIVE'][0] / g['GRBM_GUI_ACTIVE'][1] / 8.0 * 1024)
+    with open(out, 'w') as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps({k: v for k, v in res.items() if k != 'per_dispatch_averages'}, indent=1))
+
+
+def aff(prefix, out):
+    counters, durations = load(prefix)
+    res = {}
+    topk = [n for n in counters if n.startswith('affinity_topk_kernel')]
+    # the microbench runs the two shapes one after the other with the same number of launches each (and
+    # possibly the same grid size): split the kernel's dispatches of every pass into first / second half
+    by_grid = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    dur = defaultdict(lambda: [0.0, 0])
+    for path in sorted(glob.glob(prefix + '_g*_counter_collection.csv')):
+        with open(path) as f:
+            rows = [r for r in csv.DictReader(f) if 'affinity_topk_kernel' in r['Kernel_Name']]
+        ids = sorted({int(r['Dispatch_Id']) for r in rows})
+        first = set(ids[:len(ids) // 2])
+        seen = set()
+        for row in rows:
+            g = 0 if int(row['Dispatch_Id']) in first else 1
+            c = by_grid[g][row['Counter_Name']]
+            c[0] += float(row['Counter_Value'])
+            c[1] += 1
+            if row['Dispatch_Id'] not in seen:
+                seen.add(row['Dispatch_Id'])
+                dur[g][0] += float(row['End_Timestamp']) - float(row['Start_Timestamp'])
+                dur[g][1] += 1
+    shapes = {'10k': (10000, 8160), '83k': (83440, 8160)}
+    grids = sorted(by_grid)
+    for tag, g in zip(shapes, grids):
+        n, hw = shapes[tag]
+        c = {k: v[0] / v[1] for k, v in by_grid[g].items()}
+        tiles_per_wave = (n / 32.0) * (hw / 32.0) / max(c.get('SQ_WAVES', 1), 1)
+        us = dur[g][0] / dur[g][1] / 1e3
+        entry = {'shape': f'N={n} x HW={hw}', 'avg_duration_us': us, 'raw_per_dispatch': c}
+        if 'GRBM_GUI_ACTIVE' in c:
+            active = c['GRBM_GUI_ACTIVE'] / 8.0  # summed over the 8 XCDs
+            entry['clock_GHz'] = active / (us * 1e3)
+            if 'SQ_VALU_MFMA_BUSY_CYCLES' in c:  # busy cycles are summed over the 1024 SIMDs
+                entry['mfma_util_frac'] = c['SQ_VALU_MFMA_BUSY_CYCLES'] / (active * 1024)
+        if 'SQ_WAVES' in c:
+            entry['per_wave_per_tile'] = {k: c[k] / c['SQ_WAVES'] / tiles_per_wave for k in
+                                          ('SQ_INSTS_MFMA', 'SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_VMEM')
+                                          if k in c}
+            if 'SQ_WAVE_CYCLES' in c:
+                entry['wave_cycle_shares'] = {k: c[k] / c['SQ_WAVE_CYCLES'] for k in
+                                              ('SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_ACTIVE_INST_VALU')
+                                              if k in c}
+        if 'FETCH_SIZE' in c:
+            entry['hbm_read_bytes (FETCH_SIZE KiB x 1024 x 2)'] = c['FETCH_SIZE'] * 2048
+        if 'WRITE_SIZE' in c:
+            entry['hbm_write_bytes (WRITE_SIZE KiB x 1024)'] = c['WRITE_SIZE'] * 1024
+        if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
+            entry['hbm_bytes'] = c['FETCH_SIZE'] * 2048 + c['WRITE_SIZE'] * 1024
+            entry['algorithmic_bytes'] = 4.0 * (64 * n + n + 2 * 64 * hw) + 8.0 * 30 * hw + 4.0 * n
+        if 'TCC_HIT_sum' in c and 'TCC_MISS_sum' in c:
+            entry['l2_hit_rate'] = c['TCC_HIT_sum'] / (c['TCC_HIT_sum'] + c['TCC_MISS_sum'])
+        res[tag] = entry
+    with open(out, 'w') as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != 'raw_per_dispatch'} for k, v in res.items()}, indent=1))
+
+
+if __name__ == '__main__':
+    {'conv': conv, 'aff': aff}[sys.argv[1]](sys.argv[2], sys.argv[3])
