@@ -39,12 +39,13 @@ def main():
             if fin:
                 L.deva_affinity_finalize(part.data_ptr(), hw, k, splits, idx.data_ptr(), w.data_ptr(), None, st)
 
-        run()
+        fin_ok = not os.environ.get('DEVA_AFFINITY_ABLATE')
+        run(fin_ok)
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         for _ in range(iters):
-            run()
+            run(fin_ok)
         e.record()
         torch.cuda.synchronize()
         ms = s.elapsed_time(e) / iters

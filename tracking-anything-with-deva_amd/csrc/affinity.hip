@@ -234,6 +234,8 @@ struct AffArgs {
   int total_tiles;
   uint64_t* part;     // [splits][hw][CAP] candidate keys
   uint32_t* part_cnt;  // [splits][hw] live entries of each list
+  int ablate;          // timing probes only (DEVA_AFFINITY_ABLATE): 1 = file nothing, 2 = no key loads in the loop,
+                       // 4 = no scoring, 8 = no MFMAs; results are meaningless when non-zero
 };
 
 // key tile of the SHARED variant in LDS: [buffer][channel parity][token row][TROW floats]; a row holds
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
   // ---- per-query state in registers (the same value in both half-lanes of a query): list length and
   // the running lower bound of the k-th best score
   uint32_t cnt = 0;
-  float tau = -INFINITY;
+  float tau = (p.ablate & 1) ? INFINITY : -INFINITY;
 
   // Key rows are software-prefetched one tile ahead: lane (l31, half) reads the 256-B row of token
   // n_base + l31 while the matrix pipe works on the previous tile.  Lanes of the upper half start one
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
       __syncthreads();
       if (it + 1 < n_my) {
         cyc = advance(cyc);
-        load_shared(cyc);
+        if (!(p.ablate & 2)) load_shared(cyc);
       }
       if (!active) continue;
       prune_over((uint32_t)(LCAP - TOKT), true);
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
       if (lane < TOKT) msl[lane] = ms_buf;
       DEVA_COMPILER_FENCE();
       if (it + 1 < n_my) cyc = advance(cyc);
-      prefetch(cyc);
+      if (!(p.ablate & 2)) prefetch(cyc);
     }
 
     f32x16 accA, accB;
@@ -449,11 +451,19 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
       accA[r] = 0.0f;
       accB[r] = 0.0f;
     }
+    if (!(p.ablate & 8)) {
 #pragma unroll
-    for (int t = 0; t < CK / 2; ++t) {
-      const float a = a_op[t];
-      accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a * a, bqe[t], accA, 0, 0, 0);
-      accB = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bqk[t], accB, 0, 0, 0);
+      for (int t = 0; t < CK / 2; ++t) {
+        const float a = a_op[t];
+        accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a * a, bqe[t], accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bqk[t], accB, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        accA[r] = a_op[r];
+        accB[r] = a_op[r + 16];
+      }
     }
 
     // ---- scores of this lane: query l31, tokens n_base + (r&3) + 8*(r>>2) + 4*half, two accumulator
@@ -495,7 +505,9 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
         }
       }
     };
-    if (rows_left >= TOKT) {
+    if (p.ablate & 4) {  // keep the accumulators alive without scoring them
+      if (accA[0] + accB[15] == 12345.678f) cnt += 1;
+    } else if (rows_left >= TOKT) {
       file_rows(std::true_type{});
     } else {
       file_rows(std::false_type{});
@@ -523,6 +535,233 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
       const uint32_t token = ((off >> 5) * (uint32_t)p.splits + (uint32_t)split) * TOKT + (off & 31u);
       dst[(int64_t)ql * CAP + lane] =
           ((uint64_t)orderable(__uint_as_float(csc[ql * LSTRIDE + lane])) << 32) | (uint64_t)(~token);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Workgroup-shared candidate lists.  The four waves of a workgroup own the SAME 32 queries and split the
+// token tiles of the range among themselves (wave w visits tiles w, w+4, ... of the scrambled order);
+// they append to one set of 32 lists through LDS atomics and filter against one threshold per query.
+// Compared with four waves x four different query groups this
+//  * tightens every threshold four times faster (fewer appends: ~k(1+ln(N/k)) per query for the WHOLE
+//    range instead of per wave) and needs a quarter of the lists per workgroup, so each list gets four
+//    times the slots (LCAP 352 with two workgroups per CU, 704 with one) and is pruned 2-3 times per
+//    range instead of 4-6 -- the round-2 ablation showed appends + prunes costing 124 us of 376 us at
+//    N = 10 000 x 8 160 (one third of the kernel), ~1 us per pruned list;
+//  * gives one workgroup per 32 queries: 255 workgroups at 1080p without splitting the bank at all.
+// Appends: a lane that passes reserves a slot with ds_add_rtn (16 independent atomics per tile are issued
+// first, the entries written afterwards, so no append waits for its atomic).  Lists are checked between
+// two barriers once per tile: wave w prunes lists 8w .. 8w+7 that could overflow during the next tile
+// (at most 4 x 32 appends per query per tile).
+template <int LCAP, int MINB>
+__global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_wg_kernel(const AffArgs p) {
+  constexpr int LSTRIDE = LCAP + 1;
+  constexpr int E = (LCAP + 63) / 64;          // list entries per lane in a prune
+  constexpr int BURST = WAVES * TOKT;          // appends per query between two maintenance points
+  constexpr int QW = QT / WAVES;               // lists maintained by one wave
+  static_assert(LCAP - BURST >= 64, "a list is pruned only when every lane holds an entry");
+  static_assert(E * K_MAX <= LCAP - BURST, "one exact prune (<= E*k survivors) must get below the in-loop limit");
+  static_assert(2 * K_MAX <= CAP && CAP == 64, "hand-over: one key per lane");
+  __shared__ uint32_t s_sc[QT][LSTRIDE];  // candidate scores (fp32 bits)
+  __shared__ uint16_t s_tk[QT][LSTRIDE];  // candidate tokens (offset inside this range)
+  __shared__ uint32_t s_cnt[QT];
+  __shared__ float s_tau[QT];
+  __shared__ __attribute__((aligned(16))) float s_ms[WAVES][TOKT];
+  __shared__ __attribute__((aligned(16))) uint32_t s_rank[WAVES][64];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int l31 = lane & 31;
+  const int half = lane >> 5;
+  const int q0 = blockIdx.x * QT;
+  const int split = blockIdx.y;
+  uint32_t* srow = &s_sc[l31][0];
+  uint16_t* trow = &s_tk[l31][0];
+  float* msl = &s_ms[wave][0];
+
+  // ---- query operand (registers, whole kernel), identical in the four waves
+  const int q = min(q0 + l31, p.hw - 1);
+  float bqe[CK / 2], bqk[CK / 2];
+  float bs[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // bsq in ATen's summation order (see affinity_topk_kernel)
+#pragma unroll
+  for (int t = 0; t < CK / 2; ++t) {
+    const float e0 = p.qe[(int64_t)(2 * t) * p.hw + q], e1 = p.qe[(int64_t)(2 * t + 1) * p.hw + q];
+    const float k0 = p.qk[(int64_t)(2 * t) * p.hw + q], k1 = p.qk[(int64_t)(2 * t + 1) * p.hw + q];
+    bs[t >> 3] += e0 * (k0 * k0);
+    bs[t >> 3] += e1 * (k1 * k1);
+    bqe[t] = half ? e1 : e0;
+    bqk[t] = half ? (k1 * e1) : (k0 * e0);
+  }
+  const float bsq = ((bs[0] + bs[1]) + bs[2]) + bs[3];
+
+  // ---- this range's tiles in scrambled order (see affinity_topk_kernel); wave w takes visits w, w+4, ...
+  const int n_my = (p.total_tiles - split + p.splits - 1) / p.splits;
+  int stride = 61;
+  if (n_my % 61 == 0) stride = (n_my % 59 == 0) ? 53 : 59;
+  const int n_vis = (n_my > wave) ? (n_my - wave + WAVES - 1) / WAVES : 0;  // visits of this wave
+  const int n_iter = (n_my + WAVES - 1) / WAVES;                             // of the busiest wave
+  int cyc = (n_my > 0) ? (int)(((int64_t)wave * stride) % n_my) : 0;
+  const int step = (n_my > 0) ? (int)(((int64_t)WAVES * stride) % n_my) : 0;
+
+  if (threadIdx.x < QT) {
+    s_cnt[threadIdx.x] = 0u;
+    s_tau[threadIdx.x] = (p.ablate & 1) ? INFINITY : -INFINITY;
+  }
+
+  f32x4 xbuf[CK / 4];
+  float ms_buf;
+  auto prefetch = [&](int cyc_) {
+    const int tile = split + p.splits * cyc_;
+    const int n_mine = min(tile * TOKT + l31, p.n_total - 1);
+    const float* krow = (n_mine < p.n_long) ? (p.key_long + (int64_t)n_mine * CK)
+                                            : (p.key_work + (int64_t)(n_mine - p.n_long) * CK);
+    ms_buf = ((n_mine < p.n_long) ? p.shr_long[n_mine] : p.shr_work[n_mine - p.n_long]) * 0.125f;
+    const float* shifted = krow + half;
+#pragma unroll
+    for (int j = 0; j < CK / 4 - 1; ++j) xbuf[j] = *reinterpret_cast<const f32x4_u*>(shifted + 4 * j);
+    xbuf[CK / 4 - 1] = *reinterpret_cast<const f32x4*>(krow + CK - 4);
+  };
+  if (n_vis > 0) prefetch(cyc);
+
+  // prune list qq (c entries) of this wave: rank-counting prune, exact rounds while it is above `limit`
+  auto prune_one = [&](int qq, uint32_t c, uint32_t limit, bool fast) {
+    int kept = (int)c;
+    uint32_t thr = 0u;
+    if (fast) thr = prune_list<E>(&s_sc[qq][0], &s_tk[qq][0], c, p.k, lane, &kept, &s_rank[wave][0]);
+    while ((uint32_t)kept > limit) {
+      const uint32_t thr2 = prune_list_exact<E>(&s_sc[qq][0], &s_tk[qq][0], (uint32_t)kept, p.k, lane, &kept);
+      thr = thr2 > thr ? thr2 : thr;
+    }
+    if (lane == 0) {
+      s_cnt[qq] = (uint32_t)kept;
+      const float t_new = from_orderable(thr);
+      if (t_new > s_tau[qq]) s_tau[qq] = t_new;
+    }
+    DEVA_COMPILER_FENCE();
+  };
+
+  for (int it = 0; it < n_iter; ++it) {
+    __syncthreads();  // every append of the previous tile has landed: the list lengths are final
+    // every wave reads all 32 lengths and thresholds (one LDS access each) and takes the same decision
+    const uint32_t c_l = s_cnt[l31];
+    float tau = s_tau[l31];
+    const uint32_t need = (uint32_t)__ballot(c_l > (uint32_t)(LCAP - BURST));
+    if (need) {  // uniform over the workgroup: some list could overflow during the next tile
+      uint32_t mine = (need >> (wave * QW)) & ((1u << QW) - 1u);
+      while (mine) {
+        const int qq = wave * QW + __ffs((int)mine) - 1;
+        mine &= mine - 1;
+        prune_one(qq, (uint32_t)__builtin_amdgcn_readlane((int)c_l, qq), (uint32_t)(LCAP - BURST), true);
+      }
+      __syncthreads();  // pruned lists / raised thresholds are visible
+      tau = s_tau[l31];
+    }
+    const bool work = it < n_vis;  // the ragged last round: a wave without a tile only keeps the barriers
+    const int tile = split + p.splits * cyc;
+    const int n_base = tile * TOKT;
+    const uint32_t tok0 = (uint32_t)(cyc * TOKT + 4 * half);
+    f32x16 accA, accB;
+    if (work) {
+      if (lane < TOKT) msl[lane] = ms_buf;
+      DEVA_COMPILER_FENCE();
+      // the MFMAs read the prefetched rows in place (channel 2t + half of this lane's token is x / z of the
+      // 16-B pieces); the next tile's loads are issued after the last MFMA, under the scoring
+      const float a30 = half ? xbuf[CK / 4 - 1][1] : xbuf[CK / 4 - 1][0];
+      const float a31 = half ? xbuf[CK / 4 - 1][3] : xbuf[CK / 4 - 1][2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        accA[r] = 0.0f;
+        accB[r] = 0.0f;
+      }
+      if (!(p.ablate & 8)) {
+#pragma unroll
+        for (int t = 0; t < CK / 2; ++t) {
+          const float a = (t == CK / 2 - 2) ? a30 : (t == CK / 2 - 1) ? a31 : xbuf[t >> 1][(t & 1) * 2];
+          accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a * a, bqe[t], accA, 0, 0, 0);
+          accB = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bqk[t], accB, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          accA[r] = xbuf[r >> 2][r & 3];
+          accB[r] = xbuf[4 + (r >> 2)][r & 3];
+        }
+      }
+      DEVA_COMPILER_FENCE();
+      if (it + 1 < n_vis) {
+        cyc += step;
+        cyc = cyc >= n_my ? cyc - n_my : cyc;
+        if (!(p.ablate & 2)) prefetch(cyc);
+      }
+    }
+    // every wave has read this tile's list lengths (and taken the same pruning decision) before anyone
+    // appends again: without this barrier a fast wave's appends could change a slow wave's decision.
+    // (bare s_barrier: __syncthreads would also wait for the prefetch just issued)
+    DEVA_COMPILER_FENCE();
+    __builtin_amdgcn_s_barrier();
+    DEVA_COMPILER_FENCE();
+    if (!work) continue;
+    if (p.ablate & 4) {
+      if (accA[0] + accB[15] == 12345.678f) s_cnt[0] = 1u;
+      continue;
+    }
+
+    // ---- scores of this lane: query l31, tokens n_base + (r&3) + 8*(r>>2) + 4*half.  Phase A: compare
+    // and reserve list slots (one LDS atomic per passing lane and row, none waited for); phase B: write.
+    float4 ms4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) ms4[g] = *reinterpret_cast<const float4*>(&msl[8 * g + 4 * half]);
+    const int rows_left = p.n_total - n_base;
+    float v[16];
+    uint32_t pos[16];
+    unsigned long long okm[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float4 m4 = ms4[r >> 2];
+      const float m = (r & 3) == 0 ? m4.x : (r & 3) == 1 ? m4.y : (r & 3) == 2 ? m4.z : m4.w;
+      const float b = accB[r];
+      v[r] = (((b + b) - accA[r]) - bsq) * m;  // == ((-A + 2B) - bsq) * ms / 8, every step correctly rounded
+      const int j0 = (r & 3) + 8 * (r >> 2);
+      const bool ok = (v[r] >= tau) && (j0 + 4 * half < rows_left);
+      okm[r] = __ballot(ok);
+      pos[r] = 0u;
+      if (ok) pos[r] = atomicAdd(&s_cnt[l31], 1u);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (okm[r]) {
+        const int j0 = (r & 3) + 8 * (r >> 2);
+        if ((okm[r] >> lane) & 1ull) {
+          srow[pos[r]] = __float_as_uint(v[r]);
+          trow[pos[r]] = (uint16_t)(tok0 + j0);
+        }
+      }
+    }
+    DEVA_COMPILER_FENCE();
+  }
+
+  // every list of this wave down to at most `limit` entries (hand-over)
+  auto maintain = [&](uint32_t limit) {
+    for (int qq = wave * QW; qq < wave * QW + QW; ++qq) {
+      const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cnt[qq]);
+      if (c > limit) prune_one(qq, c, limit, true);
+    }
+  };
+
+  // ---- hand-over: wave w prunes its lists to at most CAP entries and writes them with their lengths
+  __syncthreads();
+  maintain((uint32_t)CAP);  // exact rounds, if needed, shrink 704 -> 352 -> 192 -> 96 -> 64 at worst
+  DEVA_COMPILER_FENCE();
+  for (int qq = wave * QW; qq < wave * QW + QW; ++qq) {
+    if (q0 + qq >= p.hw) break;
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cnt[qq]);
+    const int64_t list = (int64_t)split * p.hw + q0 + qq;
+    if (lane == 0) p.part_cnt[list] = c;
+    if ((uint32_t)lane < c) {
+      const uint32_t off = (uint32_t)s_tk[qq][lane];
+      const uint32_t token = ((off >> 5) * (uint32_t)p.splits + (uint32_t)split) * TOKT + (off & 31u);
+      p.part[list * CAP + lane] = ((uint64_t)orderable(__uint_as_float(s_sc[qq][lane])) << 32) | (uint64_t)(~token);
     }
   }
 }
@@ -680,24 +919,32 @@ extern "C" int64_t deva_affinity_workspace(int hw, int k, int splits) {
 
 // kernel shapes: 1 = 176-slot lists, one workgroup per CU, every lane loads its own key row;
 // 2 = 100-slot lists, two workgroups per CU (small frames: twice the resident workgroups);
-// 3 = 176-slot lists, one workgroup per CU, key tiles loaded once per workgroup through LDS.
+// 3 = 176-slot lists, one workgroup per CU, key tiles loaded once per workgroup through LDS;
+// 4 = workgroup-shared lists (4 waves x the same 32 queries), 352 slots, two workgroups per CU;
+// 5 = workgroup-shared lists, 704 slots, one workgroup per CU.
 // DEVA_AFFINITY_SHAPE overrides the choice (tuning / A-B measurements only).
 static int affinity_shape(int n_total, int hw) {
   static const int forced = [] {
     const char* e = getenv("DEVA_AFFINITY_SHAPE");
     return e ? atoi(e) : 0;
   }();
-  if (forced >= 1 && forced <= 3) return forced;
-  (void)n_total;
-  return hw >= 4096 ? 3 : 2;  // >= 32 query blocks fill the chip with one workgroup per CU
+  if (forced >= 1 && forced <= 5) return forced;
+  (void)hw;
+  // measured (profiles/r02b_affinity_shapes.txt): the workgroup-shared lists win while pruning / appending
+  // dominates (banks up to a few 10 000 tokens: 97 vs 173 us at 10 000 x 1 620, 346 vs 355 us at
+  // 10 000 x 8 160); on long banks their two barriers per tile cost more than the rarer prunes save
+  // (2 190 vs 1 830 us at 83 440 x 8 160)
+  return n_total <= 40000 ? 4 : 2;
 }
 
 extern "C" int deva_affinity_default_splits(int n_total, int hw) {
   // aim at one resident set of workgroups: 256 CUs x (1 or 2) four-wave workgroups
-  const int slots = affinity_shape(n_total, hw) == 2 ? 512 : 256;
-  const int qblocks = (int)ceil_div(hw, WAVES * QT);
+  const int shape = affinity_shape(n_total, hw);
+  const int slots = (shape == 2 || shape == 4) ? 512 : 256;
+  const int qblocks = (int)ceil_div(hw, shape >= 4 ? QT : WAVES * QT);
   const int tiles = (int)ceil_div(n_total, TOKT);
-  int s = (int)ceil_div(slots, qblocks);
+  // workgroup-shared lists: the grid should be a whole number of resident sets (round, do not overshoot)
+  int s = shape >= 4 ? (slots + qblocks / 2) / qblocks : (int)ceil_div(slots, qblocks);
   if (s > tiles / 4) s = tiles / 4;  // keep >= 4 tiles (128 tokens) per range
   if (s > MAX_SPLITS) s = MAX_SPLITS;
   if (s < 1) s = 1;
@@ -740,8 +987,20 @@ extern "C" int deva_affinity_topk(const float* key_long, const float* shr_long, 
                (int)ceil_div(a.total_tiles, splits) * TOKT);
   a.part = part_keys;
   a.part_cnt = reinterpret_cast<uint32_t*>(part_keys + (int64_t)splits * hw * CAP);
+  static const int ablate = [] {
+    const char* e = getenv("DEVA_AFFINITY_ABLATE");
+    return e ? atoi(e) : 0;
+  }();
+  a.ablate = ablate;
   dim3 grid((unsigned)ceil_div(hw, WAVES * QT), (unsigned)splits);
+  const dim3 grid_wg((unsigned)ceil_div(hw, QT), (unsigned)splits);
   switch (affinity_shape((int)n_total, hw)) {
+    case 4:
+      hipLaunchKernelGGL((affinity_topk_wg_kernel<352, 2>), grid_wg, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
+      break;
+    case 5:
+      hipLaunchKernelGGL((affinity_topk_wg_kernel<704, 1>), grid_wg, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
+      break;
     case 1:
       hipLaunchKernelGGL((affinity_topk_kernel<LCAP_WIDE, 1, false>), grid, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
       break;
