@@ -202,6 +202,48 @@ def gen_alignment(net):
                os.path.join(HERE, 'alignment.pt'))
 
 
+def gen_consensus_auto(net):
+    """find_consensus_auto_association (consensus_automatic.py:82-290) on a 3-frame window.  The 0/1
+    programme is solved by Gurobi / PuLP in the reference; neither exists here, so the reference's
+    `solve_with_pulp` is replaced by the exact enumeration of the package (the optimum is unique on this
+    window); everything else -- projection, IoU table, greedy matching, merging, painting -- is the
+    reference's own code."""
+    import importlib
+    sys.path.insert(0, os.path.join(ROOT, 'tracking-anything-with-deva_amd', 'deva', 'inference'))
+    spec = importlib.util.spec_from_file_location(
+        '_pkg_consensus', os.path.join(ROOT, 'tracking-anything-with-deva_amd', 'deva', 'inference', 'consensus_automatic.py'))
+    from deva.inference import consensus_automatic as CA
+    from deva.inference.image_feature_store import ImageFeatureStore
+    from deva.inference.object_info import ObjectInfo
+    src = open(spec.origin).read()
+    ns = {}
+    exec(src[src.index('def solve_exact'):src.index('def solve(')], {'np': np, 'List': list, 'Tuple': tuple}, ns)
+    captured = {}
+
+    def solver(iou, ind, n):
+        captured['iou'] = iou.copy()
+        return ns['solve_exact'](iou, ind, n)
+
+    CA.solve_with_pulp = solver
+    CA.use_gurobi = False
+    out = {}
+    real_alignment = CA.spatial_alignment
+    # 'network': the real projection (with recipe weights it is noise: no pair reaches IoU 0.5, which pins the
+    # plumbing and the empty-table path); 'static': the projection replaced by "the scene does not move"
+    # (scenarios.static_projection), which gives the table / matching / selection / painting real work
+    for case, sel in (('network_last', 'last'), ('static_first', 'first'), ('static_middle', 'middle')):
+        CA.spatial_alignment = real_alignment if case.startswith('network') else scenarios.static_projection
+        frames = scenarios.consensus_inputs(scenarios.CONSENSUS, lambda **kw: ObjectInfo(**kw))
+        store = ImageFeatureStore(net, no_warning=True)
+        ti, mask, info = CA.find_consensus_auto_association(frames, keyframe_selection=sel, network=net, store=store,
+                                                            config=synth.base_config())
+        out[case] = dict(ti=int(ti), mask=mask.clone(), iou=torch.from_numpy(captured['iou']),
+                         info=[dict(id=int(o.id), cats=list(o.category_ids), isthing=o.isthing, scores=list(o.scores))
+                               for o in info])
+    CA.spatial_alignment = real_alignment
+    torch.save(out, os.path.join(HERE, 'consensus_auto.pt'))
+
+
 def gen_read_memory(net):
     """DEVA.read_memory (network.py:72-92): dense full-softmax read, B=2, 2 objects, T=3 memory frames"""
     g = torch.Generator().manual_seed(31)
@@ -268,6 +310,10 @@ if __name__ == '__main__':
     if only == 'api':
         gen_api_surface()
         sys.exit(0)
+    if only == 'consensus':
+        net, _, _ = build_reference(synth.base_config())
+        gen_consensus_auto(net)
+        sys.exit(0)
     if only == 'alignment':
         net, _, _ = build_reference(synth.base_config())
         gen_alignment(net)
@@ -282,6 +328,7 @@ if __name__ == '__main__':
     gen_merge()
     gen_detection_e2e(net)
     gen_alignment(net)
+    gen_consensus_auto(net)
     gen_edge(net)
     gen_read_memory(net)
     gen_api_surface()

@@ -233,3 +233,78 @@ def run_edge_cases(make_core, device='cpu', make_info=None):
         out['vanish_counts'] = torch.tensor(counts)
         out['vanish_engaged_after_purge'] = torch.tensor(float(engaged))
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# semi-online consensus with inferred association (deva/inference/consensus_automatic.py): a window of
+# three frames with per-frame detections whose ids are unrelated between frames
+CONSENSUS = dict(H=96, W=128, frames=3)
+
+
+class WindowFrame:
+    """the fields of deva/inference/frame_utils.py:FrameInfo the consensus uses"""
+
+    def __init__(self, image, mask, segments_info, ti):
+        self.image, self.mask, self.segments_info, self.ti = image, mask, segments_info, ti
+
+
+def consensus_inputs(sc, make_info):
+    """frame t: a thing box drifting right (always detected), a stuff box (missed in frame 1), an untyped
+    box (only in frame 2), and a spurious thing detection in frame 0 only; ids differ from frame to frame"""
+    stream = synth.FrameStream(sc['H'], sc['W'], seed=12)
+    out = []
+    for t in range(sc['frames']):
+        img = stream.next()
+        m = torch.zeros(sc['H'], sc['W'], dtype=torch.long)
+        info = []
+        m[12:52, 10 + 2 * t:58 + 2 * t] = 7 + 10 * t
+        info.append(make_info(id=7 + 10 * t, category_id=2, isthing=True, score=0.9 - 0.1 * t))
+        if t != 1:
+            m[56:92, 66:122] = 3 + t
+            info.append(make_info(id=3 + t, category_id=5, isthing=False, score=0.7))
+        if t == 2:
+            m[2:10, 100:126] = 99
+            info.append(make_info(id=99, category_id=None, isthing=None, score=None))
+        if t == 0:
+            m[60:90, 4:30] = 50
+            info.append(make_info(id=50, category_id=2, isthing=True, score=0.4))
+        out.append(WindowFrame(img, m, info, ti=10 + t))
+    return out
+
+
+def static_projection(src_ti, src_image, src_mask, tar_ti, tar_image, network, store, config):
+    """stand-in for spatial_alignment in the consensus tests: 'the scene does not move' -- the source
+    segmentation with a 0.5 background plane, batch dimension in front (recipe weights project noise)"""
+    return torch.cat([torch.full_like(src_mask[0:1], 0.5), src_mask], dim=0).unsqueeze(0)
+
+
+def run_consensus_cases(network, make_store, make_info, device='cpu'):
+    """the three cases of tests/golden/consensus_auto.pt on the package under test"""
+    import deva.inference.consensus_automatic as CA
+    from workload import synth as _synth
+    real = CA.spatial_alignment
+    out = {}
+    try:
+        for case, sel in (('network_last', 'last'), ('static_first', 'first'), ('static_middle', 'middle')):
+            CA.spatial_alignment = real if case.startswith('network') else static_projection
+            frames = consensus_inputs(CONSENSUS, make_info)
+            for f in frames:
+                f.image, f.mask = f.image.to(device), f.mask.to(device)
+            ti, mask, info = CA.find_consensus_auto_association(frames, keyframe_selection=sel, network=network,
+                                                                store=make_store(), config=_synth.base_config())
+            out[case] = dict(ti=int(ti), mask=mask.cpu(),
+                             info=[dict(id=int(o.id), cats=list(o.category_ids), isthing=o.isthing, scores=list(o.scores))
+                                   for o in info])
+    finally:
+        CA.spatial_alignment = real
+    return out
+
+
+def check_consensus_cases(got, golden):
+    for case, g in golden.items():
+        assert got[case]['ti'] == g['ti'], case
+        assert got[case]['info'] == g['info'], (case, got[case]['info'], g['info'])
+        if case.startswith('static'):
+            assert torch.equal(got[case]['mask'], g['mask']), case
+        else:  # projected noise: only the decision (nothing reaches IoU 0.5) is pinned
+            assert got[case]['mask'].unique().tolist() == g['mask'].unique().tolist(), case

@@ -244,6 +244,16 @@ def test_spatial_alignment_against_reference_golden(network, golden_dir):
     assert out.shape == g['aligned'].shape and err <= 1e-3
 
 
+def test_consensus_auto_association_against_reference_golden(network, golden_dir):
+    """semi-online voting with inferred association: joint-histogram IoU table (one launch per frame pair, one
+    copy), matching, selection, painting vs the reference's find_consensus_auto_association"""
+    from deva.inference.image_feature_store import ImageFeatureStore
+    from deva.inference.object_info import ObjectInfo
+    got = scenarios.run_consensus_cases(network, lambda: ImageFeatureStore(network, no_warning=True),
+                                        lambda **kw: ObjectInfo(**kw), device=dev())
+    scenarios.check_consensus_cases(got, torch.load(os.path.join(golden_dir, 'consensus_auto.pt')))
+
+
 def test_edge_paths_against_reference_golden(network, golden_dir):
     """API edge paths (no memory yet, soft masks, cache control, empty detection round)"""
     from deva.inference.inference_core import DEVAInferenceCore

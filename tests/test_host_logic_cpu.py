@@ -192,6 +192,39 @@ def test_spatial_alignment_matches_reference(emu, golden_dir, recipe_state_dict)
     assert (out - g['aligned']).abs().max().item() <= 1e-3
 
 
+def test_consensus_auto_association_matches_reference(emu, golden_dir, recipe_state_dict):
+    """semi-online voting with inferred association (second half): the pairwise-IoU table
+    from one joint label histogram per frame pair, the greedy matching, the exact 0/1 selection and the
+    painting against the reference's find_consensus_auto_association (tests/golden/consensus_auto.pt)"""
+    from deva.inference.image_feature_store import ImageFeatureStore
+    from deva.inference.object_info import ObjectInfo
+    net = _network(recipe_state_dict)
+    got = scenarios.run_consensus_cases(net, lambda: ImageFeatureStore(net, no_warning=True), lambda **kw: ObjectInfo(**kw))
+    scenarios.check_consensus_cases(got, torch.load(os.path.join(golden_dir, 'consensus_auto.pt')))
+
+
+def test_consensus_exact_solver_is_optimal():
+    """solve_exact against brute force over all 2^n selections on random conflict graphs"""
+    import itertools
+    import numpy as np
+    from deva.inference.consensus_automatic import solve_exact
+    rs = np.random.RandomState(0)
+    for n in (1, 4, 7, 10):
+        for _ in range(5):
+            iou = np.zeros((n, n), dtype=np.float32)
+            for i in range(n):
+                for j in range(i + 1, n):
+                    if rs.rand() < 0.3:
+                        iou[i, j] = iou[j, i] = 0.5 + 0.5 * rs.rand()
+            ind = iou > 0.49
+            w = iou.sum(0) * 2 - 1
+            best = max((sum(w[i] for i in s), s) for r in range(n + 1) for s in itertools.combinations(range(n), r)
+                       if not any(ind[a, b] for a in s for b in s if a < b))
+            got = solve_exact(iou, ind, n)
+            assert not any(ind[a, b] for a in range(n) for b in range(a + 1, n) if got[a] and got[b])
+            assert abs(sum(w[i] for i in range(n) if got[i]) - best[0]) <= 1e-5
+
+
 @pytest.mark.skipif(not os.path.isdir('/root/reference/deva'), reason='needs the reference checkout behind the overlay')
 def test_established_association_consensus_through_the_overlay(emu, golden_dir, recipe_state_dict):
     """with a reference checkout behind this package on sys.path, the reference's own
