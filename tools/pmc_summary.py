@@ -23,8 +23,8 @@ def load(prefix):
     for path in sorted(glob.glob(prefix + '_g*_counter_collection.csv')):
         with open(path) as f:
             for row in csv.DictReader(f):
-                name = re.sub(r'\(.*', '', row['Kernel_Name']).replace('deva::(anonymous namespace)::', '')
-                name = re.sub(r'^void ', '', name)
+                name = re.sub(r'^void ', '', row['Kernel_Name']).replace('deva::(anonymous namespace)::', '')
+                name = re.sub(r'[<(].*', '', name)
                 c = counters[name][row['Counter_Name']]
                 c[0] += float(row['Counter_Value'])
                 c[1] += 1
@@ -77,7 +77,7 @@ def aff(prefix, out):
     dur = defaultdict(lambda: [0.0, 0])
     for path in sorted(glob.glob(prefix + '_g*_counter_collection.csv')):
         with open(path) as f:
-            rows = [r for r in csv.DictReader(f) if 'affinity_topk_kernel' in r['Kernel_Name']]
+            rows = [r for r in csv.DictReader(f) if 'affinity_topk' in r['Kernel_Name']]
         ids = sorted({int(r['Dispatch_Id']) for r in rows})
         first = set(ids[:len(ids) // 2])
         seen = set()
