@@ -250,7 +250,7 @@ constexpr int TROW = 36;
 // each, four times per workgroup): ~1 000 L1 line accesses per wave and tile against 4 100 MFMA
 // cycles -- the round-1 counters show the waves of that kernel waiting on memory for 34-51 % of their
 // cycles.  One s_barrier per tile (double-buffered tile).
-template <int LCAP, int MINB, bool SHARED>
+template <int LCAP, int MINB, bool SHARED, bool LATE = false>
 __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const AffArgs p) {
   constexpr int LSTRIDE = LCAP + 1;
   constexpr int E = (LCAP + 63) / 64;  // list entries per lane in a prune
@@ -431,7 +431,9 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
       // ---- prune lists that could overflow during this tile (at most 32 appends per query per tile)
       prune_over((uint32_t)(LCAP - TOKT), true);
 
-      // ---- this tile's operand: channel 2t + half of this lane's token, then start the next loads
+      // ---- this tile's operand: channel 2t + half of this lane's token.  Early prefetch (default): copy
+      // the operands out and start the next loads at once (a whole tile of latency cover); LATE: the MFMAs
+      // read the prefetched rows in place (no copies) and the next loads start after the last MFMA.
 #pragma unroll
       for (int j = 0; j < CK / 4 - 1; ++j) {
         a_op[2 * j] = xbuf[j][0];
@@ -441,8 +443,10 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
       a_op[CK / 2 - 1] = half ? xbuf[CK / 4 - 1][3] : xbuf[CK / 4 - 1][2];
       if (lane < TOKT) msl[lane] = ms_buf;
       DEVA_COMPILER_FENCE();
-      if (it + 1 < n_my) cyc = advance(cyc);
-      if (!(p.ablate & 2)) prefetch(cyc);
+      if (!LATE) {
+        if (it + 1 < n_my) cyc = advance(cyc);
+        if (!(p.ablate & 2)) prefetch(cyc);
+      }
     }
 
     f32x16 accA, accB;
@@ -464,6 +468,11 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
         accA[r] = a_op[r];
         accB[r] = a_op[r + 16];
       }
+    }
+    if (!SHARED && LATE) {
+      DEVA_COMPILER_FENCE();
+      if (it + 1 < n_my) cyc = advance(cyc);
+      if (!(p.ablate & 2)) prefetch(cyc);
     }
 
     // ---- scores of this lane: query l31, tokens n_base + (r&3) + 8*(r>>2) + 4*half, two accumulator
@@ -928,7 +937,7 @@ static int affinity_shape(int n_total, int hw) {
     const char* e = getenv("DEVA_AFFINITY_SHAPE");
     return e ? atoi(e) : 0;
   }();
-  if (forced >= 1 && forced <= 5) return forced;
+  if (forced >= 1 && forced <= 6) return forced;
   (void)hw;
   // measured (profiles/r02b_affinity_shapes.txt): the workgroup-shared lists win while pruning / appending
   // dominates (banks up to a few 10 000 tokens: 97 vs 173 us at 10 000 x 1 620, 346 vs 355 us at
@@ -940,11 +949,12 @@ static int affinity_shape(int n_total, int hw) {
 extern "C" int deva_affinity_default_splits(int n_total, int hw) {
   // aim at one resident set of workgroups: 256 CUs x (1 or 2) four-wave workgroups
   const int shape = affinity_shape(n_total, hw);
-  const int slots = (shape == 2 || shape == 4) ? 512 : 256;
-  const int qblocks = (int)ceil_div(hw, shape >= 4 ? QT : WAVES * QT);
+  const int slots = (shape == 2 || shape == 4 || shape == 6) ? 512 : 256;
+  const bool wg_lists = shape == 4 || shape == 5;
+  const int qblocks = (int)ceil_div(hw, wg_lists ? QT : WAVES * QT);
   const int tiles = (int)ceil_div(n_total, TOKT);
   // workgroup-shared lists: the grid should be a whole number of resident sets (round, do not overshoot)
-  int s = shape >= 4 ? (slots + qblocks / 2) / qblocks : (int)ceil_div(slots, qblocks);
+  int s = wg_lists ? (slots + qblocks / 2) / qblocks : (int)ceil_div(slots, qblocks);
   if (s > tiles / 4) s = tiles / 4;  // keep >= 4 tiles (128 tokens) per range
   if (s > MAX_SPLITS) s = MAX_SPLITS;
   if (s < 1) s = 1;
@@ -995,6 +1005,9 @@ extern "C" int deva_affinity_topk(const float* key_long, const float* shr_long, 
   dim3 grid((unsigned)ceil_div(hw, WAVES * QT), (unsigned)splits);
   const dim3 grid_wg((unsigned)ceil_div(hw, QT), (unsigned)splits);
   switch (affinity_shape((int)n_total, hw)) {
+    case 6:  // shape 2 with the early prefetch (operands copied out, next loads issued before the MFMAs) -- A/B probe
+      hipLaunchKernelGGL((affinity_topk_kernel<LCAP_DUAL, 2, false, false>), grid, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
+      break;
     case 4:
       hipLaunchKernelGGL((affinity_topk_wg_kernel<352, 2>), grid_wg, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
       break;
@@ -1004,8 +1017,8 @@ extern "C" int deva_affinity_topk(const float* key_long, const float* shr_long, 
     case 1:
       hipLaunchKernelGGL((affinity_topk_kernel<LCAP_WIDE, 1, false>), grid, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
       break;
-    case 2:
-      hipLaunchKernelGGL((affinity_topk_kernel<LCAP_DUAL, 2, false>), grid, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
+    case 2:  // key rows prefetched after the MFMAs, read in place (2-6 % faster than the early prefetch + copies)
+      hipLaunchKernelGGL((affinity_topk_kernel<LCAP_DUAL, 2, false, true>), grid, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
       break;
     default:
       hipLaunchKernelGGL((affinity_topk_kernel<LCAP_WIDE, 1, true>), grid, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
