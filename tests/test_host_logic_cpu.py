@@ -225,43 +225,24 @@ def test_consensus_exact_solver_is_optimal():
             assert abs(sum(w[i] for i in range(n) if got[i]) - best[0]) <= 1e-5
 
 
-@pytest.mark.skipif(not os.path.isdir('/root/reference/deva'), reason='needs the reference checkout behind the overlay')
-def test_established_association_consensus_through_the_overlay(emu, golden_dir, recipe_state_dict):
-    """with a reference checkout behind this package on sys.path, the reference's own
-    find_consensus_with_established_association runs on top of the fused spatial_alignment"""
-    import importlib
-    import sys
-    import types
-    import deva
-    import deva.inference
-    import deva.model
-    import deva.utils
-    sys.modules.setdefault('pulp', types.ModuleType('pulp'))
-    # what INTEGRATION.md's PYTHONPATH order does at import time, done here for the already-imported packages
-    added = []
-    for pkg, sub in ((deva, ''), (deva.model, 'model'), (deva.inference, 'inference'), (deva.utils, 'utils')):
-        d = os.path.join('/root/reference/deva', sub).rstrip('/')
-        if d not in list(pkg.__path__):
-            pkg.__path__.append(d)
-            added.append((pkg, d))
-    try:
-        import deva.inference.consensus_associated as CA
-        CA = importlib.reload(CA)
-        assert CA.find_consensus_with_established_association.__module__.endswith('_reference_consensus_associated')
-        from deva.inference.image_feature_store import ImageFeatureStore
-        net = _network(recipe_state_dict)
-        g = torch.load(os.path.join(golden_dir, 'alignment.pt'))
-        frames, masks = scenarios.alignment_inputs(scenarios.ALIGNMENT)
-        store = ImageFeatureStore(net, no_warning=True)
-        key_ti, consensus = CA.find_consensus_with_established_association(
-            [0, 1, 2], [f.clone() for f in frames], [m.clone() for m in masks], net, store, synth.base_config())
-        assert int(key_ti) == g['keyframe']
-        assert (consensus - g['consensus']).abs().max().item() <= 1e-3
-    finally:
-        for pkg, d in added:
-            pkg.__path__.remove(d)
-        for name in [n for n in sys.modules if n.startswith('deva.model.memory_utils') or n.endswith('_reference_consensus_associated')]:
-            del sys.modules[name]
+def test_established_association_consensus_matches_reference(emu, golden_dir, recipe_state_dict):
+    """find_consensus_with_established_association (keyframe choice + score-weighted projections) against the
+    reference's keyframe and consensus of the same three-frame window (tests/golden/alignment.pt)"""
+    from deva.inference.consensus_associated import find_consensus_with_established_association
+    from deva.inference.image_feature_store import ImageFeatureStore
+    net = _network(recipe_state_dict)
+    g = torch.load(os.path.join(golden_dir, 'alignment.pt'))
+    frames, masks = scenarios.alignment_inputs(scenarios.ALIGNMENT)
+    store = ImageFeatureStore(net, no_warning=True)
+    key_ti, consensus = find_consensus_with_established_association(
+        [0, 1, 2], [f.clone() for f in frames], [m.clone() for m in masks], net, store, synth.base_config())
+    assert int(key_ti) == g['keyframe']
+    assert (consensus - g['consensus']).abs().max().item() <= 1e-3
+    # explicit scores pick the best-scored frame as the keyframe
+    key_ti, _ = find_consensus_with_established_association(
+        [0, 1, 2], [f.clone() for f in frames], [m.clone() for m in masks], net, ImageFeatureStore(net, no_warning=True),
+        synth.base_config(), scores=[0.1, 0.9, 0.3])
+    assert int(key_ti) == 1
 
 
 def test_api_surface_matches_reference(golden_dir):

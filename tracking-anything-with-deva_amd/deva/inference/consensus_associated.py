@@ -5,18 +5,16 @@ similarity and affinity matrices for it (266 MB each at 1080p); here it is one f
 similarity -> top-k -> softmax pass plus a sparse read-out per object, exactly like a frame's
 memory read with N = HW.
 
-Everything else of this module (`find_consensus_with_established_association`, keyframe scoring)
-is host logic and stays the reference's: when a reference checkout follows this package on
-`sys.path` its module of the same name is loaded, its public names are re-exported
-from here, and its `spatial_alignment` is rebound to this one so that its own callers use it too.
+`find_consensus_with_established_association` (consensus_associated.py:80-160; callers: the referring /
+saliency evaluation drivers) is restated on top of it: keyframe choice with one host transfer for the whole
+window, score-weighted sum of the projections.
 """
-import importlib.util
-import os
-from typing import Dict
+from typing import Dict, List, Optional, Tuple
 
 import torch
 
 from deva.hip import ops
+from deva.utils.tensor_utils import pad_divide_by, unpad
 
 
 def spatial_alignment(src_ti: int, src_image: torch.Tensor, src_mask: torch.Tensor, tar_ti: int,
@@ -59,23 +57,39 @@ def spatial_alignment(src_ti: int, src_image: torch.Tensor, src_mask: torch.Tens
     return tar_mask
 
 
-def _adopt_reference_module() -> None:
-    """re-export the reference's host-side functions of this module, if a checkout is on the path"""
-    import deva.inference as pkg
-    here = os.path.dirname(os.path.abspath(__file__))
-    for d in list(pkg.__path__):
-        cand = os.path.join(d, 'consensus_associated.py')
-        if os.path.abspath(d) == here or not os.path.isfile(cand):
+def _keyframe_objective_from_mask(mask: torch.Tensor, score, method: str = 'high_foreground'):
+    """how good a keyframe a segmentation would make (consensus_associated.py:70-77)"""
+    if method == 'high_foreground':
+        return (mask > 0.8).float().mean()
+    if method == 'score':
+        return score
+    raise NotImplementedError
+
+
+def find_consensus_with_established_association(time_indices: List[int], images: List[torch.Tensor],
+                                                masks: List[torch.Tensor], network, store, config: Dict,
+                                                scores: Optional[List[float]] = None) -> Tuple[int, torch.Tensor]:
+    """Consensus of a window whose segments are already associated across frames (channel c is the same object
+    in every frame; consensus_associated.py:80-160): pick the keyframe (highest score, or largest confident
+    foreground), project every other frame onto it with the fused `spatial_alignment` and return the
+    score-weighted sum of the projections.  `images` / `masks` are padded in place like the reference does."""
+    pads = (0, 0, 0, 0)
+    for i in range(len(images)):
+        images[i], pads = pad_divide_by(images[i], 16)
+        masks[i], _ = pad_divide_by(masks[i], 16)
+    ranked_by_score = scores is not None
+    weights = torch.softmax(torch.tensor([1.0] * len(time_indices) if scores is None else list(scores),
+                                         dtype=torch.float32) * 2, dim=0).tolist()
+    if ranked_by_score:
+        objectives = weights
+    else:  # one reduction per frame, ONE host transfer for the whole window
+        objectives = torch.stack([_keyframe_objective_from_mask(m, None) for m in masks]).tolist()
+    key = max(range(len(time_indices)), key=lambda i: (objectives[i], -i))  # first maximum, like the reference's '>'
+    key_weight = weights[key] if ranked_by_score else weights[0]
+    total = masks[key] * key_weight
+    for i, ti in enumerate(time_indices):
+        if ti == time_indices[key]:
             continue
-        spec = importlib.util.spec_from_file_location('deva.inference._reference_consensus_associated', cand)
-        ref = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(ref)
-        ref.spatial_alignment = spatial_alignment
-        for name, obj in vars(ref).items():
-            if not name.startswith('__') and name not in globals():
-                globals()[name] = obj
-        globals()['_keyframe_objective_from_mask'] = ref._keyframe_objective_from_mask
-        return
-
-
-_adopt_reference_module()
+        projected = spatial_alignment(ti, images[i], masks[i], time_indices[key], images[key], network, store, config)
+        total += projected[0, 1:] * weights[i]
+    return time_indices[key], unpad(total, pads)
