@@ -119,6 +119,42 @@ class CompiledGraph:
         for name, t in sd.items():
             if '.ChannelGate.mlp.' in name:
                 self.vecs[name] = t.detach().float().contiguous().to(device)
+        # Convolutions over cat(image feature broadcast to every object, per-object feature): by linearity
+        # W.[x; g] = Wx.x + Wg.g, and Wx.x is the same for all objects.  With two or more objects the image
+        # part is computed ONCE (batch 1) and enters the per-object convolution as its fused residual; the
+        # reference (group_modules.py:141-146, big_modules.py:96-101) expands x and convolves it per object.
+        # Saves (no-1)/no of 7.6 GF per object in each fuser's first 3x3 convolution at 480p.
+        self.split: Dict[str, Tuple[PackedConv, PackedConv]] = {}
+        x_dim = sd['pixel_encoder.proj1.weight'].shape[0]  # channels of the image feature fed to both fusers
+        for base, cx in (('mask_decoder.fuser.block1.conv1', x_dim), ('mask_decoder.fuser.block1.downsample', x_dim),
+                         ('mask_encoder.fuser.block1.conv1', x_dim), ('mask_encoder.fuser.block1.downsample', x_dim),
+                         ('mask_encoder.conv1', 3)):
+            if base + '.weight' in sd:
+                self.split[base] = self._split_pack(base, cx)
+
+    def _split_pack(self, base: str, cx: int) -> Tuple[PackedConv, PackedConv]:
+        """(image part without bias, per-object part with the bias) of convolution `base`, BatchNorm folded"""
+        w = self.sd[base + '.weight'].detach().float()
+        b = self.sd.get(base + '.bias')
+        b = None if b is None else b.detach().float()
+        bn = self._bn_after(base)
+        if bn is not None:
+            gamma, beta, mean, var, eps = (t.detach().float() if torch.is_tensor(t) else t for t in bn)
+            scale = gamma / torch.sqrt(var + eps)
+            shift = beta - mean * scale
+            w = w * scale.view(-1, 1, 1, 1)
+            b = shift if b is None else b * scale + shift
+        return (ops.pack_conv(w[:, :cx].contiguous(), None, None, self.device),
+                ops.pack_conv(w[:, cx:].contiguous(), b, None, self.device))
+
+    def _conv_shared_x(self, base: str, x, g, **kw):
+        """conv over the virtual cat(x broadcast, g): one launch for a single object, otherwise the image
+        part once + the per-object part with it as the fused residual"""
+        if g.shape[0] < 2 or x.shape[0] != 1 or base not in self.split:
+            return ops.conv2d(self.convs[base], x, g, **kw)
+        wx, wg = self.split[base]
+        shared = ops.conv2d(wx, x, **kw)
+        return ops.conv2d(wg, g, residual=shared, **kw)
 
     def _bn_after(self, conv: str):
         """the BatchNorm that follows `conv` in the ResNets: convN -> bnN, downsample.0 -> downsample.1"""
@@ -156,12 +192,12 @@ class CompiledGraph:
     def _res_block(self, pre: str, g0, g1=None):
         """relu -> 3x3 -> relu -> 3x3, plus (1x1-projected) input; input = virtual cat(g0, g1)"""
         c = self.convs
-        t = ops.conv2d(c[pre + '.conv1'], g0, g1, pad=1, relu_in=True)
-        if (pre + '.downsample') in c:
-            skip = ops.conv2d(c[pre + '.downsample'], g0, g1)
+        if g1 is not None:
+            t = self._conv_shared_x(pre + '.conv1', g0, g1, pad=1, relu_in=True)
+            skip = self._conv_shared_x(pre + '.downsample', g0, g1)
         else:
-            assert g1 is None
-            skip = g0
+            t = ops.conv2d(c[pre + '.conv1'], g0, pad=1, relu_in=True)
+            skip = ops.conv2d(c[pre + '.downsample'], g0) if (pre + '.downsample') in c else g0
         return ops.conv2d(c[pre + '.conv2'], t, pad=1, relu_in=True, residual=skip)
 
     def _fusion(self, pre: str, x, g):
@@ -196,7 +232,7 @@ class CompiledGraph:
         """image [1,3,H,W]; masks [no,1,H,W]; sensory [no,C,h,w] -> value [no,C,h,w], sensory'"""
         c = self.convs
         me = 'mask_encoder'
-        g = ops.conv2d(c[me + '.conv1'], image, masks, stride=2, pad=3)
+        g = self._conv_shared_x(me + '.conv1', image, masks, stride=2, pad=3)
         g = ops.maxpool3x3s2(g, relu_after=True)
         g = self._stage(me + '.layer1', g, 2, 1, self._basic)
         g = self._stage(me + '.layer2', g, 2, 2, self._basic)
