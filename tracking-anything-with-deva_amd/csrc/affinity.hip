@@ -234,8 +234,8 @@ struct AffArgs {
   int total_tiles;
   uint64_t* part;     // [splits][hw][CAP] candidate keys
   uint32_t* part_cnt;  // [splits][hw] live entries of each list
-  int ablate;          // timing probes only (DEVA_AFFINITY_ABLATE): 1 = file nothing, 2 = no key loads in the loop,
-                       // 4 = no scoring, 8 = no MFMAs; results are meaningless when non-zero
+  int ablate;          // timing probes, builds with -DDEVA_AFFINITY_PROBES only (0 otherwise): 1 = file nothing,
+                       // 2 = no key loads in the loop, 4 = no scoring, 8 = no MFMAs; results are meaningless when non-zero
 };
 
 // key tile of the SHARED variant in LDS: [buffer][channel parity][token row][TROW floats]; a row holds
@@ -997,11 +997,15 @@ extern "C" int deva_affinity_topk(const float* key_long, const float* shr_long, 
                (int)ceil_div(a.total_tiles, splits) * TOKT);
   a.part = part_keys;
   a.part_cnt = reinterpret_cast<uint32_t*>(part_keys + (int64_t)splits * hw * CAP);
+#ifdef DEVA_AFFINITY_PROBES  // `make PROBES=1`: timing probes for the ablation table (profiles/r02b_affinity_shapes.txt)
   static const int ablate = [] {
     const char* e = getenv("DEVA_AFFINITY_ABLATE");
     return e ? atoi(e) : 0;
   }();
   a.ablate = ablate;
+#else
+  a.ablate = 0;
+#endif
   dim3 grid((unsigned)ceil_div(hw, WAVES * QT), (unsigned)splits);
   const dim3 grid_wg((unsigned)ceil_div(hw, QT), (unsigned)splits);
   switch (affinity_shape((int)n_total, hw)) {
