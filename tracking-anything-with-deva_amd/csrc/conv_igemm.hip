@@ -634,8 +634,20 @@ int launch_tile(const ConvArgs& a, hipStream_t st) {
   p.per_split = ksteps_total;
   const int64_t blocks = (int64_t)p.tiles_m * p.tiles_n;
   p.splits = 1;
-  if (a.ws && blocks < 256 && ksteps_total >= 8) {
-    int64_t sp = ceil_div(512, blocks);
+  int64_t target_blocks = 512;
+#ifdef DEVA_CONV_PROBES
+  {
+    static const int forced = [] {
+      const char* e = getenv("DEVA_CONV_SPLIT_TARGET");  // 0 = no split-K at all
+      return e ? atoi(e) : -1;
+    }();
+    if (forced >= 0) target_blocks = forced;
+  }
+#endif
+  // measured on the batch-1 key-encoder layers (profiles/r02d_conv_small_layers.txt): the reduction launch costs
+  // ~7 us, so a layer that already has >= 128 tiles is split only when its K loop is long (>= 32 steps)
+  if (a.ws && blocks < 256 && ksteps_total >= (blocks >= 128 ? 32 : 8) && target_blocks > 0) {
+    int64_t sp = ceil_div(target_blocks, blocks);
     if (sp > ksteps_total / 4) sp = ksteps_total / 4;
     if (sp > 16) sp = 16;
     const int64_t fit = a.ws_elems / ((int64_t)a.cout * a.n_total);
@@ -780,8 +792,22 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
   }
   // Tile choice (all tiles run 32-deep K steps):
   const int64_t blocks128 = ceil_div(a.cout, 128) * ceil_div(a.n_total, 128);
+#ifdef DEVA_CONV_PROBES  // `make PROBES=1`: A/B runs of the tile policy (tools/conv_microbench.py)
+  {
+    static const int forced = [] {
+      const char* e = getenv("DEVA_CONV_TILE");
+      return e ? atoi(e) : 0;
+    }();
+    if (forced == 64 && a.cout > 32) return launch_tile<64, 64, 32, 2, 2>(a, st);
+    if (forced == 128 && a.cout >= 128) return launch_tile<128, 128, 32, 2, 4>(a, st);
+  }
+#endif
   if (a.cout <= 32) return launch_tile<32, 128, 32, 1, 4>(a, st);
   // measured: the 8-wave 128x128 tile beats the 64x64 tile from ~64 tiles up (split-K tops the grid up)
-  if (a.cout >= 128 && blocks128 >= 64) return launch_tile<128, 128, 32, 2, 4>(a, st);
+  // ... except where the 128-wide tiles would need split-K while the 64-wide ones fill the chip on their own
+  // (1x1 256->1024 on a 30x54 map: 20 vs 29 us)
+  const int64_t blocks64 = ceil_div(a.cout, 64) * ceil_div(a.n_total, 64);
+  if (a.cout >= 128 && blocks128 >= 64 && !(blocks128 < 256 && blocks64 >= 256 && a.K <= 512))
+    return launch_tile<128, 128, 32, 2, 4>(a, st);
   return launch_tile<64, 64, 32, 2, 2>(a, st);
 }

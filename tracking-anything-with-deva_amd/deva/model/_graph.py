@@ -242,8 +242,9 @@ class CompiledGraph:
             sensory = self._gru(me + '.sensory_update.transform', value, sensory)
         return value, sensory
 
-    def decode(self, ms_features, readout, sensory, last_mask16, update_sensory: bool):
-        """readout/sensory [no,C,h,w]; last_mask16 [no,1,h,w] -> sensory', object logits [no,1,4h,4w]"""
+    def decode_masks(self, ms_features, readout, sensory, last_mask16):
+        """readout/sensory [no,C,h,w]; last_mask16 [no,1,h,w] -> decoder pyramid p16, p8, p4 and the object
+        logits [no,1,4h,4w] (everything `segment` returns except the new sensory state)"""
         c = self.convs
         md = 'mask_decoder'
         f16, f8, f4 = ms_features
@@ -254,11 +255,20 @@ class CompiledGraph:
         p8 = self._res_block(md + '.up_16_8.out_conv', ops.upsample2x_add(p16, d8))
         p4 = self._res_block(md + '.up_8_4.out_conv', ops.upsample2x_add(p8, d4))
         logits = ops.conv2d(c[md + '.pred'], p4, pad=1, relu_in=True)
+        return p16, p8, p4, logits
+
+    def sensory_update(self, p16, p8, p4, logits, sensory):
+        """the decoder's GRU update of the sensory memory (modules.py:121-151): needed by the NEXT frame only"""
+        c = self.convs
+        su = 'mask_decoder.sensory_update'
+        g = ops.conv2d(c[su + '.g16_conv'], p16)
+        g = ops.conv2d(c[su + '.g8_conv'], ops.area_downsample(p8, 2), residual=g)
+        g = ops.conv2d(c[su + '.g4_conv'], ops.area_downsample(p4, 4), ops.area_downsample(logits, 4), residual=g)
+        return self._gru(su + '.transform', g, sensory)
+
+    def decode(self, ms_features, readout, sensory, last_mask16, update_sensory: bool):
+        """readout/sensory [no,C,h,w]; last_mask16 [no,1,h,w] -> sensory', object logits [no,1,4h,4w]"""
+        p16, p8, p4, logits = self.decode_masks(ms_features, readout, sensory, last_mask16)
         if update_sensory:
-            su = md + '.sensory_update'
-            g = ops.conv2d(c[su + '.g16_conv'], p16)
-            g = ops.conv2d(c[su + '.g8_conv'], ops.area_downsample(p8, 2), residual=g)
-            g = ops.conv2d(c[su + '.g4_conv'], ops.area_downsample(p4, 4), ops.area_downsample(logits, 4),
-                           residual=g)
-            sensory = self._gru(su + '.transform', g, sensory)
+            sensory = self.sensory_update(p16, p8, p4, logits, sensory)
         return sensory, logits
