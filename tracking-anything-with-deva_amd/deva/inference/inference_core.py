@@ -40,20 +40,6 @@ class DEVAInferenceCore:
         self.last_mask = None
         self.pad = None
         self.frame_buffer = []  # online / semi-online processing
-        # Frame pipelining (not in the reference): the decoder's sensory GRU update is only read by the NEXT
-        # frame, so it runs on a side stream beside the next frame's key encoder.  Effective when the caller
-        # does not synchronise the device after every frame; DEVA_PIPELINE=0 (or pipeline_sensory = False)
-        # keeps everything on one stream.
-        import os
-        self.pipeline_sensory = os.environ.get('DEVA_PIPELINE', '1') != '0'
-        self._side_stream = None
-        self._sensory_ready = None  # event after which memory.sensory may be read on the current stream
-
-    def _join_side(self) -> None:
-        """make the current stream wait for the sensory update launched on the side stream, if any"""
-        if self._sensory_ready is not None:
-            torch.cuda.current_stream().wait_event(self._sensory_ready)
-            self._sensory_ready = None
 
     def enabled_long_id(self) -> None:
         # short ids 1..255 (palette PNG) by default; long ids 256..255**3 for panoptic RGB masks
@@ -73,7 +59,6 @@ class DEVAInferenceCore:
             warnings.warn('Empty object mask!', RuntimeWarning)
             return
         ids = self.object_manager.all_obj_ids
-        self._join_side()
         self.memory.initialize_sensory_if_needed(key, ids)
         value, sensory = self.network.encode_mask(image, ms_features, self.memory.get_sensory(ids), prob,
                                                   is_deep_update=is_deep_update,
@@ -93,15 +78,6 @@ class DEVAInferenceCore:
         ids = self.object_manager.all_obj_ids
         readout = self.memory.match_memory(key, selection)
         readout = self.object_manager.realize_dict(readout).unsqueeze(0)
-        self._join_side()
-        if (self.pipeline_sensory and update_sensory and key.is_cuda
-                and (self.chunk_size < 1 or self.chunk_size >= len(ids))):
-            if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(device=key.device)
-            sensory, prob, self._sensory_ready = self.network.segment_pipelined(
-                ms_features, readout, self.memory.get_sensory(ids), self.last_mask, self._side_stream)
-            self.memory.update_sensory(sensory, ids)
-            return prob[0]
         sensory, _, prob = self.network.segment(ms_features, readout, self.memory.get_sensory(ids),
                                                 self.last_mask, chunk_size=self.chunk_size,
                                                 update_sensory=update_sensory)

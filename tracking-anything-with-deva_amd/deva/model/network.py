@@ -151,38 +151,6 @@ class DEVA(nn.Module):
         logits_up, prob = ops.upsample4x_softmax(agg)
         return new_sens.unsqueeze(0), logits_up.unsqueeze(0), prob.unsqueeze(0)
 
-    def segment_pipelined(self, multi_scale_features: Iterable[torch.Tensor], memory_readout: torch.Tensor,
-                          sensory: torch.Tensor, last_mask: torch.Tensor, side_stream):
-        """`segment` with the sensory GRU update moved off the critical path (not part of the reference's
-        interface; used by `DEVAInferenceCore`): masks / logits / probabilities are computed on the current
-        stream, the update of the sensory memory -- which only the NEXT frame reads -- is launched on
-        `side_stream` as soon as the decoder pyramid exists, so that its large batched convolutions (2.5 ms at
-        480p with 5 objects) run beside the next frame's key encoder (1.6 ms of small, latency-bound batch-1
-        kernels).  Returns (sensory' [1,no,C,h,w] -- valid on the current stream only after waiting for the
-        returned event --, prob [1,no+1,H,W], event)."""
-        assert memory_readout.shape[0] == 1
-        g = self.graph()
-        ms = tuple(multi_scale_features)
-        readout_all, sens_all = _f32c(memory_readout)[0], _f32c(sensory)[0]
-        last16 = ops.area_downsample(_f32c(last_mask)[0], last_mask.shape[-1] // readout_all.shape[-1]).unsqueeze(1)
-        main = torch.cuda.current_stream()
-        p16, p8, p4, lg = g.decode_masks(ms, readout_all, sens_all, last16)
-        ready = torch.cuda.Event()
-        ready.record(main)
-        with torch.cuda.stream(side_stream):
-            side_stream.wait_event(ready)
-            new_sens = g.sensory_update(p16, p8, p4, lg, sens_all)
-            done = torch.cuda.Event()
-            done.record(side_stream)
-        # caching-allocator bookkeeping: these blocks are read by kernels of another stream than the one they
-        # were allocated on; their memory must not be handed out again before those kernels have run
-        for t in (p16, p8, p4, lg, sens_all):
-            t.record_stream(side_stream)
-        new_sens.record_stream(main)
-        agg = ops.aggregate(lg[:, 0], apply_sigmoid=True)
-        _, prob = ops.upsample4x_softmax(agg, need_logits=False)
-        return new_sens.unsqueeze(0), prob.unsqueeze(0), done
-
     def forward(self, mode: str, *args, **kwargs):
         # network.py:175-187
         if mode == 'encode_image':
