@@ -336,9 +336,17 @@ def run_1080p(net, device, steps, warmup, detections, seed=7):
         run(t)
     elapsed = timed_region(lambda: [run(t) for t in range(1 + warmup, n_frames)], None, device)
     mem = core.memory
-    return steps / elapsed, {'long': {b: mem.long_mem.size(b) for b in mem.long_mem.buckets},
-                             'work': {b: mem.work_mem.size(b) for b in mem.work_mem.buckets},
-                             'objects': core.object_manager.num_obj}
+    state = {'long': {b: mem.long_mem.size(b) for b in mem.long_mem.buckets},
+             'work': {b: mem.work_mem.size(b) for b in mem.work_mem.buckets},
+             'objects': core.object_manager.num_obj}
+    if os.environ.get('DEVA_BENCH_LAYERS_1080') and not detections:  # per-layer table of this line (tuning aid)
+        more = make_clip(H, W, 6, seed=seed + 1, device=device)
+        with ConvTimer() as ct:
+            for f in more:
+                core.step(f)
+        with open(os.environ['DEVA_BENCH_LAYERS_1080'], 'w') as f:
+            json.dump(ct.per_layer(len(more)), f, indent=1)
+    return steps / elapsed, state
 
 
 def long4k(args, net, rank, world, device, dist):
