@@ -190,6 +190,12 @@ int deva_affinity_select(const uint64_t* part_keys, int hw, int k, int splits, i
                          uint64_t* out_keys, uint32_t* out_counts, void* stream);
 int deva_affinity_merge(const uint64_t* keys, const uint32_t* counts, int hw, int k, int lists, int32_t* idx,
                         float* weight, uint64_t* usage_fix, void* stream);
+/* Tuning / test hook: force one of the kernel shapes of deva_affinity_topk (1, 6: per-wave candidate lists, one / two
+ * workgroups per CU with early key prefetch; 2: two per CU, late prefetch; 3: key tiles shared through LDS; 4, 5:
+ * workgroup-shared lists, two / one workgroup per CU); 0 = automatic choice by bank size (the default; the environment
+ * variable DEVA_AFFINITY_SHAPE sets the initial value).  All shapes give bit-identical results.  Call between
+ * deva_affinity_default_splits / deva_affinity_workspace / deva_affinity_topk sequences, not inside one. */
+int deva_affinity_force_shape(int shape);
 /* workspace query: number of uint64 elements part_keys must hold */
 int64_t deva_affinity_workspace(int hw, int k, int splits);
 /* splits the library would pick for a bank/query size (>= 1) */

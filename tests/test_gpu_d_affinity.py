@@ -109,6 +109,26 @@ def test_larger_shapes_against_cpu(n, hw, scale, k):
                 'result depends on the split count'
 
 
+@pytest.mark.parametrize('shape', [1, 2, 3, 4, 5, 6])
+def test_every_kernel_shape_gives_the_same_result(shape):
+    """the kernel shapes of deva_affinity_topk (per-wave / workgroup-shared lists, one / two workgroups per CU,
+    shared key tiles, early / late prefetch) forced in turn: identical indices, weights and usage counters as the
+    automatic choice, on a bank with a long-term part, ragged sizes and enough tokens for several prune rounds"""
+    from deva.hip import check, lib
+    cases = [(5000, 1620, 2.0, 30, 1200), (999, 129, 0.2, 7, 0), (20000, 257, 1.0, 30, 333), (33, 1, 1.0, 30, 0)]
+    try:
+        for n, hw, scale, k, n_long in cases:
+            mk, ms, qk, qe = synth.affinity_inputs(n, hw, seed=n + hw + 1, key_scale=scale)
+            check(lib().deva_affinity_force_shape(0), 'force_shape')
+            want = _run(mk, ms, qk, qe, k, n_long)
+            check(lib().deva_affinity_force_shape(shape), 'force_shape')
+            got = _run(mk, ms, qk, qe, k, n_long)
+            assert torch.equal(got[0], want[0]) and torch.equal(torch.nan_to_num(got[1], nan=-1.0), torch.nan_to_num(want[1], nan=-1.0))
+            assert torch.equal(got[2], want[2]), (shape, n, hw)
+    finally:
+        lib().deva_affinity_force_shape(0)
+
+
 def test_determinism_and_usage_clear():
     mk, ms, qk, qe = synth.affinity_inputs(3000, 500, seed=9, key_scale=2.0)
     a = _run(mk, ms, qk, qe, 30)

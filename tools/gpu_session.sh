@@ -23,17 +23,10 @@ if has tests; then
     rc=$?
     if [ $rc -ge 124 ]; then echo "hang/crash in $f -- stopping"; exit 1; fi
     if [ $rc -ne 0 ]; then grep -E "^(FAILED|ERROR)|Error|assert" gpurun_out/$f.log | head -12; fi
-    if [ "$f" = "test_gpu_d_affinity" ] && [ $rc -ne 0 ] && [ -f tools/probe/affinity_fallback.hip.txt ]; then
-      echo "affinity kernel failed its tests: rebuilding the previous kernel for the remaining files"
-      cp tracking-anything-with-deva_amd/csrc/affinity.hip gpurun_out/affinity_failed.hip.txt
-      cp tools/probe/affinity_fallback.hip.txt tracking-anything-with-deva_amd/csrc/affinity.hip
-      python __graft_entry__.py > gpurun_out/build_fallback.log 2>&1; echo "fallback build exit $?"
-      AFF_FALLBACK=1
-    fi
   done
 fi
 if has affshapes; then  # the affinity tests with every kernel shape forced in turn
-  for shape in 1 2 3; do
+  for shape in 1 2 3 4 5; do
     DEVA_AFFINITY_SHAPE=$shape timeout -k 10 300 python -m pytest tests/test_gpu_d_affinity.py -m gpu -q -p no:cacheprovider > gpurun_out/test_gpu_d_affinity_shape$shape.log 2>&1
     echo "test_gpu_d_affinity with shape $shape exit $? : $(tail -1 gpurun_out/test_gpu_d_affinity_shape$shape.log)"
   done
@@ -41,8 +34,8 @@ fi
 if has custom; then
   eval "$CUSTOM_CMD"
 fi
-if has affinity && [ -z "$AFF_FALLBACK" ]; then
-  for shape in ${AFF_SHAPE_LIST:-1 2 3}; do
+if has affinity; then
+  for shape in ${AFF_SHAPE_LIST:-2 4}; do
     DEVA_AFFINITY_SHAPE=$shape SHAPES=${AFF_SHAPES:-1620x1620,8100x1620,10000x1620,24580x1620,10000x8160,83440x8160,50000x32400} ITERS=10 \
       timeout -k 10 200 python tools/affinity_microbench.py > gpurun_out/affinity_shape$shape.txt 2>&1
     echo "--- affinity shape $shape"; cat gpurun_out/affinity_shape$shape.txt

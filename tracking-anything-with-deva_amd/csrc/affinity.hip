@@ -932,18 +932,27 @@ extern "C" int64_t deva_affinity_workspace(int hw, int k, int splits) {
 // 4 = workgroup-shared lists (4 waves x the same 32 queries), 352 slots, two workgroups per CU;
 // 5 = workgroup-shared lists, 704 slots, one workgroup per CU.
 // DEVA_AFFINITY_SHAPE overrides the choice (tuning / A-B measurements only).
+static int g_forced_shape = -1;  // -1: not initialised (DEVA_AFFINITY_SHAPE is read on first use)
+
 static int affinity_shape(int n_total, int hw) {
-  static const int forced = [] {
+  if (g_forced_shape < 0) {
     const char* e = getenv("DEVA_AFFINITY_SHAPE");
-    return e ? atoi(e) : 0;
-  }();
-  if (forced >= 1 && forced <= 6) return forced;
+    const int v = e ? atoi(e) : 0;
+    g_forced_shape = (v >= 1 && v <= 6) ? v : 0;
+  }
+  if (g_forced_shape) return g_forced_shape;
   (void)hw;
   // measured (profiles/r02b_affinity_shapes.txt): the workgroup-shared lists win while pruning / appending
   // dominates (banks up to a few 10 000 tokens: 97 vs 173 us at 10 000 x 1 620, 346 vs 355 us at
   // 10 000 x 8 160); on long banks their two barriers per tile cost more than the rarer prunes save
   // (2 190 vs 1 830 us at 83 440 x 8 160)
   return n_total <= 40000 ? 4 : 2;
+}
+
+extern "C" int deva_affinity_force_shape(int shape) {
+  DEVA_REQUIRE(shape >= 0 && shape <= 6, "deva_affinity_force_shape: shape must be 0 (automatic) .. 6");
+  g_forced_shape = shape;
+  return 0;
 }
 
 extern "C" int deva_affinity_default_splits(int n_total, int hw) {

@@ -56,6 +56,7 @@ SIGNATURES = {
                                    c_int, c_int, c_int, c_void_p, c_void_p]),
     'deva_affinity_finalize': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'deva_affinity_workspace': (c_int64, [c_int, c_int, c_int]),
+    'deva_affinity_force_shape': (c_int, [c_int]),
     'deva_affinity_default_splits': (c_int, [c_int, c_int]),
     'deva_usage_update': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p]),
     'deva_readout_sparse': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
