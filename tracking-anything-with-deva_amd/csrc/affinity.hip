@@ -75,7 +75,14 @@ __device__ __forceinline__ float from_orderable(uint32_t o) {
 // 64-bit candidate keys handed to the merge kernel: order-preserving score bits << 32 | ~token index,
 // so a larger key is a better candidate (higher score first, then lower token index).
 
-#define DEVA_COMPILER_FENCE() asm volatile("" ::: "memory")
+// Hand-over point of cross-lane communication through LDS inside one wave: a wavefront-scope acquire-release fence (the
+// LDS pipeline executes a wave's accesses in order, so the fence costs no instruction; it is what makes the
+// ordering part of the program instead of an assumption about the compiler) plus a wave barrier for the scheduler.
+#define DEVA_COMPILER_FENCE()                               \
+  do {                                                      \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                        \
+  } while (0)
 
 __device__ __forceinline__ int wave_count(bool pred) { return __popcll(__ballot(pred)); }
 // number of set bits of a wave ballot below this lane
