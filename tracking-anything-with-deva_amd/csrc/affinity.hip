@@ -19,23 +19,31 @@
 // of the k-th best are appended (~k*(1+ln(n/k)) appends per query over n tokens); a list that could
 // overflow is pruned to the entries >= the k-th largest of its 64 per-lane maxima (at least k entries
 // are >= that value, so the final result stays exact).  That k-th largest is found by rank counting
-// over the 64 lane values (64 independent readlane / compare / add triples, ~200 VALU issue slots)
-// instead of a ballot bisection, whose ~10-30 dependent VALU->SALU->branch round trips cost ~3 700
-// cycles per list and, at three prune rounds of 32 lists per range, a third of the kernel at the
-// N = 10 000 shape (round-1 profile).  grid.y splits the bank into token ranges so small frames still
+// over the 64 lane values through a 256-B LDS row (128 independent compare / add pairs) instead of a
+// ballot bisection, whose ~10-30 dependent VALU->SALU->branch round trips cost ~3 700 cycles per list
+// and, at three prune rounds of 32 lists per range, a third of the kernel at the N = 10 000 shape
+// (round-1 profile); the exact bisection on unique (score, token) keys remains as the fallback for
+// banks full of identical scores.  grid.y splits the bank into token ranges so small frames still
 // fill the chip; every range hands over its (pruned, <= CAP entries) lists with their lengths and a
 // second kernel (one wave per query) selects the exact top-k over all ranges, applies exp/normalise
 // and accumulates the usage counters.
 //
-// Issue model that shaped the loop (tools/probe/README.md): VALU instructions do not overlap the
-// wave's own MFMAs (~4.5 cycles each with one wave per SIMD, ~2 with two), so the kernel comes in two
-// shapes: 176-slot lists with one workgroup per CU (long ranges: few prunes), and 100-slot lists with
-// two workgroups per CU (two waves per SIMD: the other wave's MFMAs run under this wave's scoring /
-// pruning).  Rows are filed only when some lane passes (one ballot + one scalar branch per row
-// otherwise), list positions come from the ballot instead of atomics, accumulators stay in VGPRs
-// (-amdgpu-mfma-vgpr-form, see the Makefile), operand rows are loaded with a per-half-lane offset
-// instead of being selected, and the scrambled tile order is advanced incrementally (a 64-bit modulo
-// per tile was ~300 scalar instructions on the critical path).
+// What the round-2 measurements say about this part (profiles/r02b_affinity_shapes.txt, tools/probe):
+// fp32 MFMAs and VALU work do not overlap -- kernel time ~ MFMA cycles + VALU issue cycles + exposed
+// waits at any occupancy -- and the exposed waits are the prunes' LDS round trips (per-wave lists) or
+// the skew collected by workgroup barriers (shared lists).  Hence the kernel shapes (see
+// deva_affinity_force_shape in the header; the automatic choice is by bank size):
+//   affinity_topk_wg_kernel   banks <= 40 000 tokens: the four waves of a workgroup share 32 queries'
+//                             lists (LDS-atomic appends, one threshold per query, 352 slots, two
+//                             workgroups per CU, two barriers per tile) -- fewest appends and prunes;
+//   affinity_topk_kernel      longer banks: four waves x four query groups, 100-slot per-wave lists, two
+//                             workgroups per CU, no barriers, key rows prefetched after the last MFMA
+//                             and read in place.
+// Common to both: rows are filed only when some lane passes, accumulators stay in VGPRs
+// (-amdgpu-mfma-vgpr-form, see the Makefile), operand rows are loaded with a per-half-lane offset instead
+// of being selected, appends store raw fp32 bits (ordered only when a list is pruned / handed over), and
+// the scrambled tile order is advanced incrementally (a 64-bit modulo per tile was ~300 scalar
+// instructions on the critical path).
 #include <math.h>
 
 #include <type_traits>
