@@ -131,6 +131,13 @@ class CompiledGraph:
                          ('mask_encoder.conv1', 3)):
             if base + '.weight' in sd:
                 self.split[base] = self._split_pack(base, cx)
+        # the two 1x1 projections of the key encoder read the same feature map: one launch with their output
+        # channels side by side (big_modules.py:42-51 runs them one after the other)
+        w1, w2 = sd['pixel_encoder.proj1.weight'], sd['pixel_encoder.proj2.weight']
+        self.proj_split = w1.shape[0]
+        self.convs['pixel_encoder.proj12'] = ops.pack_conv(
+            torch.cat([w1, w2], 0), torch.cat([sd['pixel_encoder.proj1.bias'], sd['pixel_encoder.proj2.bias']], 0), None,
+            device)
 
     def _split_pack(self, base: str, cx: int) -> Tuple[PackedConv, PackedConv]:
         """(image part without bias, per-object part with the bias) of convolution `base`, BatchNorm folded"""
@@ -220,7 +227,8 @@ class CompiledGraph:
         f4 = self._stage(pe + '.res2', x, 3, 1, self._bottleneck)
         f8 = self._stage(pe + '.layer2', f4, 4, 2, self._bottleneck)
         f16 = self._stage(pe + '.layer3', f8, 6, 2, self._bottleneck)
-        return (ops.conv2d(c[pe + '.proj1'], f16), f8, f4), ops.conv2d(c[pe + '.proj2'], f16)
+        both = ops.conv2d(c[pe + '.proj12'], f16)  # batch 1: the two channel ranges are contiguous tensors
+        return (both[:, :self.proj_split], f8, f4), both[:, self.proj_split:]
 
     def transform_key(self, feat, need_s: bool, need_e: bool):
         c = self.convs
