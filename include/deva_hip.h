@@ -192,7 +192,8 @@ int deva_affinity_merge(const uint64_t* keys, const uint32_t* counts, int hw, in
                         float* weight, uint64_t* usage_fix, void* stream);
 /* Tuning / test hook: force one of the kernel shapes of deva_affinity_topk (1, 6: per-wave candidate lists, one / two
  * workgroups per CU with early key prefetch; 2: two per CU, late prefetch; 3: key tiles shared through LDS; 4, 5:
- * workgroup-shared lists, two / one workgroup per CU); 0 = automatic choice by bank size (the default; the environment
+ * workgroup-shared lists, two / one 4-wave workgroup per CU; 7: ping-pong phases; 8: workgroup-shared lists, one 8-wave
+ * workgroup per CU); 0 = automatic choice by frame and bank size (the default; the environment
  * variable DEVA_AFFINITY_SHAPE sets the initial value).  All shapes give bit-identical results.  Call between
  * deva_affinity_default_splits / deva_affinity_workspace / deva_affinity_topk sequences, not inside one. */
 int deva_affinity_force_shape(int shape);

@@ -74,4 +74,7 @@ def test_version_and_argument_errors_without_a_gpu(library):
     # pure host-side helpers
     assert L.deva_affinity_workspace(1620, 30, 4) == 4 * 1620 * 64 + 4 * 1620 // 2  # keys + 32-bit list lengths
     assert 1 <= L.deva_affinity_default_splits(10000, 8160) <= 32
-    assert L.deva_affinity_default_splits(1620, 1620) == 26  # <= 64 tokens per range: no filtering needed
+    assert L.deva_affinity_default_splits(1620, 1620) == 3  # small frame, short bank: one 8-wave workgroup per CU
+    assert L.deva_affinity_force_shape(2) == 0
+    assert L.deva_affinity_default_splits(1620, 1620) == 26  # per-wave lists: <= 64 tokens per range, no filtering needed
+    assert L.deva_affinity_force_shape(9) != 0 and L.deva_affinity_force_shape(0) == 0

@@ -109,7 +109,7 @@ def test_larger_shapes_against_cpu(n, hw, scale, k):
                 'result depends on the split count'
 
 
-@pytest.mark.parametrize('shape', [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize('shape', [1, 2, 3, 4, 5, 6, 7, 8])
 def test_every_kernel_shape_gives_the_same_result(shape):
     """the kernel shapes of deva_affinity_topk (per-wave / workgroup-shared lists, one / two workgroups per CU,
     shared key tiles, early / late prefetch) forced in turn: identical indices, weights and usage counters as the

@@ -26,7 +26,7 @@ if has tests; then
   done
 fi
 if has affshapes; then  # the affinity tests with every kernel shape forced in turn
-  for shape in 1 2 3 4 5; do
+  for shape in ${AFF_TEST_SHAPES:-1 2 3 4 5 6 7 8}; do
     DEVA_AFFINITY_SHAPE=$shape timeout -k 10 300 python -m pytest tests/test_gpu_d_affinity.py -m gpu -q -p no:cacheprovider > gpurun_out/test_gpu_d_affinity_shape$shape.log 2>&1
     echo "test_gpu_d_affinity with shape $shape exit $? : $(tail -1 gpurun_out/test_gpu_d_affinity_shape$shape.log)"
   done

@@ -33,13 +33,19 @@
 // waits at any occupancy -- and the exposed waits are the prunes' LDS round trips (per-wave lists) or
 // the skew collected by workgroup barriers (shared lists).  Hence the kernel shapes (see
 // deva_affinity_force_shape in the header; the automatic choice is by bank size):
-//   affinity_topk_wg_kernel   banks <= 40 000 tokens: the four waves of a workgroup share 32 queries'
-//                             lists (LDS-atomic appends, one threshold per query, 352 slots, two
-//                             workgroups per CU, two barriers per tile) -- fewest appends and prunes;
+//   affinity_topk_wg_kernel   short banks (<= 20 000 - 30 000 tokens): the waves of a workgroup share 32
+//                             queries' lists (LDS-atomic appends, one threshold per query, two barriers per
+//                             tile) -- fewest appends and prunes.  Four waves, 352 slots, two workgroups per
+//                             CU on large frames; eight waves, 704 slots, one workgroup per CU on small
+//                             frames (half the token ranges, so half the lists to merge afterwards);
 //   affinity_topk_kernel      longer banks: four waves x four query groups, 100-slot per-wave lists, two
 //                             workgroups per CU, no barriers, key rows prefetched after the last MFMA
-//                             and read in place.
-// Common to both: rows are filed only when some lane passes, accumulators stay in VGPRs
+//                             and read in place;
+//   affinity_topk_pp_kernel   (A/B only) eight waves in two groups alternating a matrix and a scoring phase:
+//                             bit-identical, slower -- the fp32 MFMAs share the VALU data path, so there is
+//                             nothing for the other group's scoring to overlap with.
+// Common to all: the prefetched key rows keep their registers reserved until the MFMAs read them
+// (DEVA_KEEP_ROWS: otherwise the scoring phase waits for the loads it is supposed to cover); rows are filed only when some lane passes, accumulators stay in VGPRs
 // (-amdgpu-mfma-vgpr-form, see the Makefile), operand rows are loaded with a per-half-lane offset instead
 // of being selected, appends store raw fp32 bits (ordered only when a list is pruned / handed over), and
 // the scrambled tile order is advanced incrementally (a 64-bit modulo per tile was ~300 scalar
@@ -91,6 +97,18 @@ __device__ __forceinline__ float from_orderable(uint32_t o) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
     __builtin_amdgcn_wave_barrier();                        \
   } while (0)
+
+// The prefetched key rows sit in registers for a whole tile while their loads are in flight.  Only two of
+// the four floats of a 16-B piece are MFMA operands, and the register allocator would hand the other two to
+// unrelated values of the scoring phase -- writing such a register has to wait (s_waitcnt vmcnt) for the load
+// that targets it, which exposes the memory latency the prefetch is there to hide.  Naming every piece as an
+// asm input right before its first use keeps all four registers reserved until then (no instruction emitted).
+// For the same reason nothing is computed from the prefetched shrinkage until it is stored to LDS.
+#define DEVA_KEEP_ROWS(rows)                                     \
+  _Pragma("unroll") for (int j_ = 0; j_ < CK / 4; ++j_) {        \
+    asm volatile("" ::"v"(rows[j_]));                            \
+  }
+
 
 __device__ __forceinline__ int wave_count(bool pred) { return __popcll(__ballot(pred)); }
 // number of set bits of a wave ballot below this lane
@@ -355,7 +373,7 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
     const float* krow = (n_mine < p.n_long) ? (p.key_long + (int64_t)n_mine * CK)
                                             : (p.key_work + (int64_t)(n_mine - p.n_long) * CK);
     // 1/sqrt(CK) folded into the shrinkage: (x * ms) * 0.125 == x * (ms * 0.125) exactly
-    ms_buf = ((n_mine < p.n_long) ? p.shr_long[n_mine] : p.shr_work[n_mine - p.n_long]) * 0.125f;
+    ms_buf = ((n_mine < p.n_long) ? p.shr_long[n_mine] : p.shr_work[n_mine - p.n_long]);  // scaled when stored: see DEVA_KEEP_ROWS
     const float* shifted = krow + half;
 #pragma unroll
     for (int j = 0; j < CK / 4 - 1; ++j) xbuf[j] = *reinterpret_cast<const f32x4_u*>(shifted + 4 * j);
@@ -449,6 +467,7 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
       // ---- this tile's operand: channel 2t + half of this lane's token.  Early prefetch (default): copy
       // the operands out and start the next loads at once (a whole tile of latency cover); LATE: the MFMAs
       // read the prefetched rows in place (no copies) and the next loads start after the last MFMA.
+      DEVA_KEEP_ROWS(xbuf);
 #pragma unroll
       for (int j = 0; j < CK / 4 - 1; ++j) {
         a_op[2 * j] = xbuf[j][0];
@@ -456,7 +475,7 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
       }
       a_op[CK / 2 - 2] = half ? xbuf[CK / 4 - 1][1] : xbuf[CK / 4 - 1][0];
       a_op[CK / 2 - 1] = half ? xbuf[CK / 4 - 1][3] : xbuf[CK / 4 - 1][2];
-      if (lane < TOKT) msl[lane] = ms_buf;
+      if (lane < TOKT) msl[lane] = ms_buf * 0.125f;  // 1/sqrt(CK) folded in (exact)
       DEVA_COMPILER_FENCE();
       if (!LATE) {
         if (it + 1 < n_my) cyc = advance(cyc);
@@ -578,12 +597,13 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
 // first, the entries written afterwards, so no append waits for its atomic).  Lists are checked between
 // two barriers once per tile: wave w prunes lists 8w .. 8w+7 that could overflow during the next tile
 // (at most 4 x 32 appends per query per tile).
-template <int LCAP, int MINB>
-__global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_wg_kernel(const AffArgs p) {
+template <int LCAP, int MINB, int NW>
+__global__ __launch_bounds__(NW * 64, MINB) void affinity_topk_wg_kernel(const AffArgs p) {
   constexpr int LSTRIDE = LCAP + 1;
   constexpr int E = (LCAP + 63) / 64;          // list entries per lane in a prune
-  constexpr int BURST = WAVES * TOKT;          // appends per query between two maintenance points
-  constexpr int QW = QT / WAVES;               // lists maintained by one wave
+  constexpr int BURST = NW * TOKT;          // appends per query between two maintenance points
+  constexpr int QW = QT / NW;               // lists maintained by one wave
+  constexpr bool MS_EARLY = (E <= 6);
   static_assert(LCAP - BURST >= 64, "a list is pruned only when every lane holds an entry");
   static_assert(E * K_MAX <= LCAP - BURST, "one exact prune (<= E*k survivors) must get below the in-loop limit");
   static_assert(2 * K_MAX <= CAP && CAP == 64, "hand-over: one key per lane");
@@ -591,8 +611,8 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_wg_kernel(cons
   __shared__ uint16_t s_tk[QT][LSTRIDE];  // candidate tokens (offset inside this range)
   __shared__ uint32_t s_cnt[QT];
   __shared__ float s_tau[QT];
-  __shared__ __attribute__((aligned(16))) float s_ms[WAVES][TOKT];
-  __shared__ __attribute__((aligned(16))) uint32_t s_rank[WAVES][64];
+  __shared__ __attribute__((aligned(16))) float s_ms[NW][TOKT];
+  __shared__ __attribute__((aligned(16))) uint32_t s_rank[NW][64];
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -623,10 +643,10 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_wg_kernel(cons
   const int n_my = (p.total_tiles - split + p.splits - 1) / p.splits;
   int stride = 61;
   if (n_my % 61 == 0) stride = (n_my % 59 == 0) ? 53 : 59;
-  const int n_vis = (n_my > wave) ? (n_my - wave + WAVES - 1) / WAVES : 0;  // visits of this wave
-  const int n_iter = (n_my + WAVES - 1) / WAVES;                             // of the busiest wave
+  const int n_vis = (n_my > wave) ? (n_my - wave + NW - 1) / NW : 0;  // visits of this wave
+  const int n_iter = (n_my + NW - 1) / NW;                             // of the busiest wave
   int cyc = (n_my > 0) ? (int)(((int64_t)wave * stride) % n_my) : 0;
-  const int step = (n_my > 0) ? (int)(((int64_t)WAVES * stride) % n_my) : 0;
+  const int step = (n_my > 0) ? (int)(((int64_t)NW * stride) % n_my) : 0;
 
   if (threadIdx.x < QT) {
     s_cnt[threadIdx.x] = 0u;
@@ -640,7 +660,7 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_wg_kernel(cons
     const int n_mine = min(tile * TOKT + l31, p.n_total - 1);
     const float* krow = (n_mine < p.n_long) ? (p.key_long + (int64_t)n_mine * CK)
                                             : (p.key_work + (int64_t)(n_mine - p.n_long) * CK);
-    ms_buf = ((n_mine < p.n_long) ? p.shr_long[n_mine] : p.shr_work[n_mine - p.n_long]) * 0.125f;
+    ms_buf = ((n_mine < p.n_long) ? p.shr_long[n_mine] : p.shr_work[n_mine - p.n_long]);  // scaled when stored: see DEVA_KEEP_ROWS
     const float* shifted = krow + half;
 #pragma unroll
     for (int j = 0; j < CK / 4 - 1; ++j) xbuf[j] = *reinterpret_cast<const f32x4_u*>(shifted + 4 * j);
@@ -686,11 +706,13 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_wg_kernel(cons
     const int n_base = tile * TOKT;
     const uint32_t tok0 = (uint32_t)(cyc * TOKT + 4 * half);
     f32x16 accA, accB;
+    float4 ms4[4];  // scaled shrinkage in accumulator-row order: rows 4g..4g+3 <-> tokens 8g+4*half..+3
     if (work) {
-      if (lane < TOKT) msl[lane] = ms_buf;
+      if (lane < TOKT) msl[lane] = ms_buf * 0.125f;  // 1/sqrt(CK) folded in (exact)
       DEVA_COMPILER_FENCE();
       // the MFMAs read the prefetched rows in place (channel 2t + half of this lane's token is x / z of the
       // 16-B pieces); the next tile's loads are issued after the last MFMA, under the scoring
+      DEVA_KEEP_ROWS(xbuf);
       const float a30 = half ? xbuf[CK / 4 - 1][1] : xbuf[CK / 4 - 1][0];
       const float a31 = half ? xbuf[CK / 4 - 1][3] : xbuf[CK / 4 - 1][2];
 #pragma unroll
@@ -718,6 +740,12 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_wg_kernel(cons
         cyc = cyc >= n_my ? cyc - n_my : cyc;
         if (!(p.ablate & 2)) prefetch(cyc);
       }
+      // this wave's own shrinkage row, read back before the barrier so that its LDS latency is not exposed after
+      // it (the 8-wave instantiation has no registers to spare for that and reads it after the barrier)
+      if (MS_EARLY) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) ms4[g] = *reinterpret_cast<const float4*>(&msl[8 * g + 4 * half]);
+      }
     }
     // every wave has read this tile's list lengths (and taken the same pruning decision) before anyone
     // appends again: without this barrier a fast wave's appends could change a slow wave's decision.
@@ -733,9 +761,10 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_wg_kernel(cons
 
     // ---- scores of this lane: query l31, tokens n_base + (r&3) + 8*(r>>2) + 4*half.  Phase A: compare
     // and reserve list slots (one LDS atomic per passing lane and row, none waited for); phase B: write.
-    float4 ms4[4];
+    if (!MS_EARLY) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) ms4[g] = *reinterpret_cast<const float4*>(&msl[8 * g + 4 * half]);
+      for (int g = 0; g < 4; ++g) ms4[g] = *reinterpret_cast<const float4*>(&msl[8 * g + 4 * half]);
+    }
     const int rows_left = p.n_total - n_base;
     float v[16];
     uint32_t pos[16];
@@ -749,17 +778,16 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_wg_kernel(cons
       const int j0 = (r & 3) + 8 * (r >> 2);
       const bool ok = (v[r] >= tau) && (j0 + 4 * half < rows_left);
       okm[r] = __ballot(ok);
-      pos[r] = 0u;
+      // lanes that do not pass write to the spare slot LCAP of their row (never read): no predicate in phase B
+      pos[r] = (uint32_t)LCAP;
       if (ok) pos[r] = atomicAdd(&s_cnt[l31], 1u);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       if (okm[r]) {
         const int j0 = (r & 3) + 8 * (r >> 2);
-        if ((okm[r] >> lane) & 1ull) {
-          srow[pos[r]] = __float_as_uint(v[r]);
-          trow[pos[r]] = (uint16_t)(tok0 + j0);
-        }
+        srow[pos[r]] = __float_as_uint(v[r]);
+        trow[pos[r]] = (uint16_t)(tok0 + j0);
       }
     }
     DEVA_COMPILER_FENCE();
@@ -790,6 +818,230 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_wg_kernel(cons
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Ping-pong variant of the workgroup-shared lists: EIGHT waves (two per SIMD) share 32 queries; waves 0-3
+// (group A) and 4-7 (group B) alternate between a matrix phase (P: 64 MFMAs of one tile) and a scoring
+// phase (Q: scores, appends) separated by workgroup barriers, so that in every slot each SIMD runs the
+// MFMAs of one wave beside the scoring of the other:
+//      slot 1:  A: P(tile a_i)   B: Q(tile b_i-1)   | barrier |   slot 2:  A: Q(tile a_i)   B: P(tile b_i)   | barrier
+// Each group owns its own set of 32 lists (two lists per query are handed over per range), which gives
+// every list a quiescent window: a group's lists are pruned at the start of its P phase, when none of its
+// waves appends (the other group appends to its own lists), and the result is picked up after the barrier
+// that precedes its Q phase.  List lengths are kept in registers (V, identical in the waves of a group);
+// the appends of phase Q(j) count into s_delta[group][j & 1], read at the start of P(j+1) and cleared at
+// the start of P(j+2).  The filter threshold of a query is the larger of the two groups' bounds.
+constexpr int PP_WAVES = 8;
+template <int LCAP>
+__global__ __launch_bounds__(PP_WAVES * 64, 1) void affinity_topk_pp_kernel(const AffArgs p) {
+  constexpr int LSTRIDE = LCAP + 1;
+  constexpr int E = (LCAP + 63) / 64;
+  constexpr int GW = PP_WAVES / 2;             // waves per group
+  constexpr int BURST = GW * TOKT;             // appends per query and group in one Q phase
+  constexpr int QW = QT / GW;                  // lists maintained by one wave of a group
+  static_assert(LCAP - BURST >= 64, "a list is pruned only when every lane holds an entry");
+  static_assert(2 * K_MAX <= CAP && CAP == 64, "hand-over: one key per lane");
+  __shared__ uint32_t s_sc[2][QT][LSTRIDE];
+  __shared__ uint16_t s_tk[2][QT][LSTRIDE];
+  __shared__ uint32_t s_delta[2][2][QT];
+  __shared__ uint32_t s_len[2][QT];
+  __shared__ float s_tau[2][QT];
+  __shared__ __attribute__((aligned(16))) float s_ms[PP_WAVES][TOKT];
+  __shared__ __attribute__((aligned(16))) uint32_t s_rank[PP_WAVES][64];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int grp = wave / GW;
+  const int gw = wave % GW;
+  const int l31 = lane & 31;
+  const int half = lane >> 5;
+  const int q0 = blockIdx.x * QT;
+  const int split = blockIdx.y;          // token range; its two lists are 2*split + grp
+  const int ranges = p.splits / 2;
+  uint32_t* srow = &s_sc[grp][l31][0];
+  uint16_t* trow = &s_tk[grp][l31][0];
+  float* msl = &s_ms[wave][0];
+
+  const int q = min(q0 + l31, p.hw - 1);
+  float bqe[CK / 2], bqk[CK / 2];
+  float bs[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // bsq in ATen's summation order (see affinity_topk_kernel)
+#pragma unroll
+  for (int t = 0; t < CK / 2; ++t) {
+    const float e0 = p.qe[(int64_t)(2 * t) * p.hw + q], e1 = p.qe[(int64_t)(2 * t + 1) * p.hw + q];
+    const float k0 = p.qk[(int64_t)(2 * t) * p.hw + q], k1 = p.qk[(int64_t)(2 * t + 1) * p.hw + q];
+    bs[t >> 3] += e0 * (k0 * k0);
+    bs[t >> 3] += e1 * (k1 * k1);
+    bqe[t] = half ? e1 : e0;
+    bqk[t] = half ? (k1 * e1) : (k0 * e0);
+  }
+  const float bsq = ((bs[0] + bs[1]) + bs[2]) + bs[3];
+
+  // tiles of this range in scrambled order; wave w takes visits w, w+8, ...
+  const int n_my = (p.total_tiles - split + ranges - 1) / ranges;
+  int stride = 61;
+  if (n_my % 61 == 0) stride = (n_my % 59 == 0) ? 53 : 59;
+  const int n_vis = (n_my > wave) ? (n_my - wave + PP_WAVES - 1) / PP_WAVES : 0;
+  const int n_iter = (n_my + PP_WAVES - 1) / PP_WAVES;
+  int cyc = (n_my > 0) ? (int)(((int64_t)wave * stride) % n_my) : 0;
+  const int step = (n_my > 0) ? (int)(((int64_t)PP_WAVES * stride) % n_my) : 0;
+
+  if (threadIdx.x < 2 * QT) {
+    const int g = threadIdx.x / QT, qq = threadIdx.x % QT;
+    s_delta[g][0][qq] = 0u;
+    s_delta[g][1][qq] = 0u;
+    s_tau[g][qq] = (p.ablate & 1) ? INFINITY : -INFINITY;
+  }
+  uint32_t V = 0u;          // length of this group's list l31 (identical in the four waves of the group)
+  uint32_t pruned = 0u;     // lists of this group pruned in the last P phase
+
+  f32x4 xbuf[CK / 4];
+  float ms_buf;
+  auto prefetch = [&](int cyc_) __attribute__((always_inline)) {
+    const int tile = split + ranges * cyc_;
+    const int n_mine = min(tile * TOKT + l31, p.n_total - 1);
+    const float* krow = (n_mine < p.n_long) ? (p.key_long + (int64_t)n_mine * CK)
+                                            : (p.key_work + (int64_t)(n_mine - p.n_long) * CK);
+    ms_buf = ((n_mine < p.n_long) ? p.shr_long[n_mine] : p.shr_work[n_mine - p.n_long]);  // scaled when stored: see DEVA_KEEP_ROWS
+    const float* shifted = krow + half;
+#pragma unroll
+    for (int j = 0; j < CK / 4 - 1; ++j) xbuf[j] = *reinterpret_cast<const f32x4_u*>(shifted + 4 * j);
+    xbuf[CK / 4 - 1] = *reinterpret_cast<const f32x4*>(krow + CK - 4);
+  };
+  if (n_vis > 0) prefetch(cyc);
+
+  auto prune_one = [&](int qq, uint32_t c, uint32_t limit) __attribute__((always_inline)) {
+    int kept = (int)c;
+    uint32_t thr = prune_list<E>(&s_sc[grp][qq][0], &s_tk[grp][qq][0], c, p.k, lane, &kept, &s_rank[wave][0]);
+    while ((uint32_t)kept > limit) {
+      const uint32_t thr2 = prune_list_exact<E>(&s_sc[grp][qq][0], &s_tk[grp][qq][0], (uint32_t)kept, p.k, lane, &kept);
+      thr = thr2 > thr ? thr2 : thr;
+    }
+    if (lane == 0) {
+      s_len[grp][qq] = (uint32_t)kept;
+      const float t_new = from_orderable(thr);
+      if (t_new > s_tau[grp][qq]) s_tau[grp][qq] = t_new;
+    }
+    DEVA_COMPILER_FENCE();
+  };
+  auto prune_mine = [&](uint32_t need, uint32_t limit) __attribute__((always_inline)) {
+    uint32_t mine = (need >> (gw * QW)) & ((1u << QW) - 1u);
+    while (mine) {
+      const int qq = gw * QW + __ffs((int)mine) - 1;
+      mine &= mine - 1;
+      prune_one(qq, (uint32_t)__builtin_amdgcn_readlane((int)V, qq), limit);
+    }
+  };
+
+  f32x16 accA, accB;
+  int tile_cyc = 0;  // cyclic index of the tile whose scores sit in the accumulators
+
+  // ---- matrix phase of visit j
+  auto phase_p = [&](int j) __attribute__((always_inline)) {
+    if (j > 0) V += s_delta[grp][(j - 1) & 1][l31];                    // appends of Q(j-1): final
+    if (gw == 0 && lane < QT) s_delta[grp][j & 1][lane] = 0u;         // read at P(j-1), next used by Q(j)
+    // the phase after the last visit prunes for the hand-over
+    const uint32_t limit = (j == n_iter) ? (uint32_t)CAP : (uint32_t)(LCAP - BURST);
+    const uint32_t need = (uint32_t)__ballot(V > limit);
+    pruned = need;
+    if (need) prune_mine(need, limit);                                 // nobody appends to this group's lists now
+    if (j >= n_vis) return;
+    if (lane < TOKT) msl[lane] = ms_buf * 0.125f;  // 1/sqrt(CK) folded in (exact)
+    tile_cyc = cyc;
+    DEVA_KEEP_ROWS(xbuf);
+    const float a30 = half ? xbuf[CK / 4 - 1][1] : xbuf[CK / 4 - 1][0];
+    const float a31 = half ? xbuf[CK / 4 - 1][3] : xbuf[CK / 4 - 1][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      accA[r] = 0.0f;
+      accB[r] = 0.0f;
+    }
+#pragma unroll
+    for (int t = 0; t < CK / 2; ++t) {
+      const float a = (t == CK / 2 - 2) ? a30 : (t == CK / 2 - 1) ? a31 : xbuf[t >> 1][(t & 1) * 2];
+      accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a * a, bqe[t], accA, 0, 0, 0);
+      accB = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bqk[t], accB, 0, 0, 0);
+    }
+    DEVA_COMPILER_FENCE();
+    if (j + 1 < n_vis) {
+      cyc += step;
+      cyc = cyc >= n_my ? cyc - n_my : cyc;
+      prefetch(cyc);
+    }
+  };
+  // ---- scoring phase of visit j
+  auto phase_q = [&](int j) __attribute__((always_inline)) {
+    if ((pruned >> l31) & 1u) V = s_len[grp][l31];
+    pruned = 0u;
+    if (j >= n_vis) return;
+    const float tau = fmaxf(s_tau[0][l31], s_tau[1][l31]);
+    const int tile = split + ranges * tile_cyc;
+    const int rows_left = p.n_total - tile * TOKT;
+    const uint32_t tok0 = (uint32_t)(tile_cyc * TOKT + 4 * half);
+    uint32_t* dcount = &s_delta[grp][j & 1][l31];
+    float4 ms4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) ms4[g] = *reinterpret_cast<const float4*>(&msl[8 * g + 4 * half]);
+    float v[16];
+    uint32_t pos[16];
+    unsigned long long okm[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float4 m4 = ms4[r >> 2];
+      const float m = (r & 3) == 0 ? m4.x : (r & 3) == 1 ? m4.y : (r & 3) == 2 ? m4.z : m4.w;
+      const float b = accB[r];
+      v[r] = (((b + b) - accA[r]) - bsq) * m;  // == ((-A + 2B) - bsq) * ms / 8, every step correctly rounded
+      const int j0 = (r & 3) + 8 * (r >> 2);
+      const bool ok = (v[r] >= tau) && (j0 + 4 * half < rows_left);
+      okm[r] = __ballot(ok);
+      pos[r] = 0u;
+      if (ok) pos[r] = V + atomicAdd(dcount, 1u);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (okm[r]) {
+        const int j0 = (r & 3) + 8 * (r >> 2);
+        if ((okm[r] >> lane) & 1ull) {
+          srow[pos[r]] = __float_as_uint(v[r]);
+          trow[pos[r]] = (uint16_t)(tok0 + j0);
+        }
+      }
+    }
+    DEVA_COMPILER_FENCE();
+  };
+
+  __syncthreads();  // list state initialised
+  // group B runs one slot behind group A; phase 2j is P(j), phase 2j+1 is Q(j), phase 2*n_iter the hand-over prune
+  for (int s = 0; s <= 2 * n_iter + 1; ++s) {
+    const int ph = s - grp;
+    if (ph >= 0 && ph <= 2 * n_iter) {
+      if (ph & 1) {
+        phase_q(ph >> 1);
+      } else {
+        phase_p(ph >> 1);
+      }
+    }
+    // LDS traffic of this slot retired, but NOT the key rows just requested (__syncthreads waits for those too)
+    DEVA_COMPILER_FENCE();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    DEVA_COMPILER_FENCE();
+  }
+
+  // ---- hand-over: every wave writes the lists it maintains (at most CAP entries each after the last prune)
+  if ((pruned >> l31) & 1u) V = s_len[grp][l31];
+  DEVA_COMPILER_FENCE();
+  for (int qq = gw * QW; qq < gw * QW + QW; ++qq) {
+    if (q0 + qq >= p.hw) break;
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)V, qq);
+    const int64_t list = ((int64_t)(2 * split + grp)) * p.hw + q0 + qq;
+    if (lane == 0) p.part_cnt[list] = c;
+    if ((uint32_t)lane < c) {
+      const uint32_t off = (uint32_t)s_tk[grp][qq][lane];
+      const uint32_t token = ((off >> 5) * (uint32_t)ranges + (uint32_t)split) * TOKT + (off & 31u);
+      p.part[list * CAP + lane] = ((uint64_t)orderable(__uint_as_float(s_sc[grp][qq][lane])) << 32) | (uint64_t)(~token);
+    }
+  }
+}
+
 // one wave per query: exact top-k over the candidate lists of all ranges (lane l holds entry l of every
 // range's list: ME >= splits keys per lane), sorted by rank counting, then exp / normalise / usage.
 // With out_keys != NULL the sorted top-k is instead written back in the hand-over format (token index
@@ -816,9 +1068,10 @@ __global__ __launch_bounds__(256) void affinity_finalize_kernel(const uint64_t* 
 #pragma unroll
   for (int i = 0; i < ME; ++i) {
     uint64_t v = 0ull;
-    if (i < splits) {
-      const int64_t list = (int64_t)i * hw + q;
-      if ((uint32_t)lane < part_cnt[list]) v = part[list * CAP + lane];
+    if (i < splits) {  // key and length loads are independent (one memory round trip): slots past the length are
+      const int64_t list = (int64_t)i * hw + q;  // allocated workspace, read and discarded
+      const uint64_t key = part[list * CAP + lane];
+      v = ((uint32_t)lane < part_cnt[list]) ? key : 0ull;
     }
     e[i] = v;
   }
@@ -945,7 +1198,9 @@ extern "C" int64_t deva_affinity_workspace(int hw, int k, int splits) {
 // 2 = 100-slot lists, two workgroups per CU (small frames: twice the resident workgroups);
 // 3 = 176-slot lists, one workgroup per CU, key tiles loaded once per workgroup through LDS;
 // 4 = workgroup-shared lists (4 waves x the same 32 queries), 352 slots, two workgroups per CU;
-// 5 = workgroup-shared lists, 704 slots, one workgroup per CU.
+// 5 = workgroup-shared lists, 704 slots, one workgroup per CU;
+// 6 = shape 2 with the early prefetch; 7 = ping-pong (8 waves in two groups alternating matrix / scoring phases);
+// 8 = workgroup-shared lists, EIGHT waves x the same 32 queries, 704 slots, one workgroup per CU.
 // DEVA_AFFINITY_SHAPE overrides the choice (tuning / A-B measurements only).
 static int g_forced_shape = -1;  // -1: not initialised (DEVA_AFFINITY_SHAPE is read on first use)
 
@@ -953,19 +1208,23 @@ static int affinity_shape(int n_total, int hw) {
   if (g_forced_shape < 0) {
     const char* e = getenv("DEVA_AFFINITY_SHAPE");
     const int v = e ? atoi(e) : 0;
-    g_forced_shape = (v >= 1 && v <= 6) ? v : 0;
+    g_forced_shape = (v >= 1 && v <= 8) ? v : 0;
   }
   if (g_forced_shape) return g_forced_shape;
-  (void)hw;
-  // measured (profiles/r02b_affinity_shapes.txt): the workgroup-shared lists win while pruning / appending
-  // dominates (banks up to a few 10 000 tokens: 97 vs 173 us at 10 000 x 1 620, 346 vs 355 us at
-  // 10 000 x 8 160); on long banks their two barriers per tile cost more than the rarer prunes save
-  // (2 190 vs 1 830 us at 83 440 x 8 160)
-  return n_total <= 40000 ? 4 : 2;
+  // measured (profiles/r02e_affinity_shapes.txt, total us of filter + finalize):
+  //   few query blocks (480p, hw = 1 620): the 8-wave workgroups need half the token ranges for the same number
+  //   of workgroups, i.e. half the lists to merge: 42 vs 71 (N = 1 620), 83 vs 94 (8 100), 192 vs 200 (24 580);
+  //   from ~30 000 tokens on the 4-wave shape is ahead (286 vs 300 at 40 000) and stays ahead of the per-wave lists
+  //   (518 vs 624 at 83 440);
+  //   many query blocks (1080p / 4K): shared lists while appends / prunes dominate (312 vs 362 at 10 000 x 8 160,
+  //   1 114 vs 1 195 at 10 000 x 32 400), per-wave lists without barriers on longer banks (829 vs 859 at 30 000,
+  //   1 039 vs 1 118 at 40 000, 1 873 vs 2 128 at 83 440 x 8 160).
+  if (hw <= 4096) return n_total <= 30000 ? 8 : 4;
+  return n_total <= 20000 ? 4 : 2;
 }
 
 extern "C" int deva_affinity_force_shape(int shape) {
-  DEVA_REQUIRE(shape >= 0 && shape <= 6, "deva_affinity_force_shape: shape must be 0 (automatic) .. 6");
+  DEVA_REQUIRE(shape >= 0 && shape <= 8, "deva_affinity_force_shape: shape must be 0 (automatic) .. 8");
   g_forced_shape = shape;
   return 0;
 }
@@ -974,8 +1233,29 @@ extern "C" int deva_affinity_default_splits(int n_total, int hw) {
   // aim at one resident set of workgroups: 256 CUs x (1 or 2) four-wave workgroups
   const int shape = affinity_shape(n_total, hw);
   const int slots = (shape == 2 || shape == 4 || shape == 6) ? 512 : 256;
-  const bool wg_lists = shape == 4 || shape == 5;
+  const bool wg_lists = shape == 4 || shape == 5 || shape == 7 || shape == 8;
   const int qblocks = (int)ceil_div(hw, wg_lists ? QT : WAVES * QT);
+  if (shape == 8) {
+    // one 8-wave workgroup per CU, every token range hands over one list per query
+    const int tiles8 = (int)ceil_div(n_total, TOKT);
+    int r = (256 + qblocks / 2) / qblocks;
+    if (r > tiles8 / 16) r = tiles8 / 16;  // >= 2 tiles per wave and range
+    if (r > MAX_SPLITS) r = MAX_SPLITS;
+    if (r < 1) r = 1;
+    while (r < MAX_SPLITS && ceil_div(tiles8, r) > 2047) ++r;
+    return r;
+  }
+  if (shape == 7) {
+    // ping-pong kernel: one 8-wave workgroup per CU; every token range hands over TWO lists per query, and
+    // `splits` counts lists
+    const int tiles7 = (int)ceil_div(n_total, TOKT);
+    int r = (256 + qblocks / 2) / qblocks;
+    if (r > tiles7 / 16) r = tiles7 / 16;  // >= 2 tiles per wave and range
+    if (r > MAX_SPLITS / 2) r = MAX_SPLITS / 2;
+    if (r < 1) r = 1;
+    while (r < MAX_SPLITS / 2 && ceil_div(tiles7, r) > 2047) ++r;
+    return 2 * r;
+  }
   const int tiles = (int)ceil_div(n_total, TOKT);
   // workgroup-shared lists: the grid should be a whole number of resident sets (round, do not overshoot)
   int s = wg_lists ? (slots + qblocks / 2) / qblocks : (int)ceil_div(slots, qblocks);
@@ -1032,15 +1312,24 @@ extern "C" int deva_affinity_topk(const float* key_long, const float* shr_long, 
 #endif
   dim3 grid((unsigned)ceil_div(hw, WAVES * QT), (unsigned)splits);
   const dim3 grid_wg((unsigned)ceil_div(hw, QT), (unsigned)splits);
-  switch (affinity_shape((int)n_total, hw)) {
+  int shape = affinity_shape((int)n_total, hw);
+  if (shape == 7 && (splits % 2 != 0 || ceil_div(a.total_tiles, splits / 2) > 2047)) shape = 4;  // needs list pairs
+  switch (shape) {
+    case 7:
+      hipLaunchKernelGGL((affinity_topk_pp_kernel<352>), dim3((unsigned)ceil_div(hw, QT), (unsigned)(splits / 2)),
+                         dim3(PP_WAVES * 64), 0, (hipStream_t)stream, a);
+      break;
+    case 8:
+      hipLaunchKernelGGL((affinity_topk_wg_kernel<704, 1, 8>), grid_wg, dim3(8 * 64), 0, (hipStream_t)stream, a);
+      break;
     case 6:  // shape 2 with the early prefetch (operands copied out, next loads issued before the MFMAs) -- A/B probe
       hipLaunchKernelGGL((affinity_topk_kernel<LCAP_DUAL, 2, false, false>), grid, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
       break;
     case 4:
-      hipLaunchKernelGGL((affinity_topk_wg_kernel<352, 2>), grid_wg, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
+      hipLaunchKernelGGL((affinity_topk_wg_kernel<352, 2, WAVES>), grid_wg, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
       break;
     case 5:
-      hipLaunchKernelGGL((affinity_topk_wg_kernel<704, 1>), grid_wg, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
+      hipLaunchKernelGGL((affinity_topk_wg_kernel<704, 1, WAVES>), grid_wg, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
       break;
     case 1:
       hipLaunchKernelGGL((affinity_topk_kernel<LCAP_WIDE, 1, false>), grid, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
