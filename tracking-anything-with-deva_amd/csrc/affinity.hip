@@ -110,7 +110,7 @@ __device__ __forceinline__ float from_orderable(uint32_t o) {
   }
 
 
-__device__ __forceinline__ int wave_count(bool pred) { return __popcll(__ballot(pred)); }
+__device__ __forceinline__ int wave_count(bool pred) { return __popcll(__builtin_amdgcn_ballot_w64(pred)); }
 // number of set bits of a wave ballot below this lane
 __device__ __forceinline__ int prefix_below(unsigned long long b) {
   return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
@@ -177,7 +177,7 @@ __device__ __forceinline__ uint32_t kth_lane_value(uint32_t m, int k, int lane, 
     rank += (o.w > u) ? 1 : 0;
   }
   DEVA_COMPILER_FENCE();
-  const unsigned long long b = __ballot(rank == k - 1);  // exactly one lane: the values are unique
+  const unsigned long long b = __builtin_amdgcn_ballot_w64(rank == k - 1);  // exactly one lane: the values are unique
   return (uint32_t)__builtin_amdgcn_readlane((int)u, __ffsll(b) - 1) & ~63u;
 }
 
@@ -200,12 +200,13 @@ __device__ __forceinline__ uint32_t prune_list(uint32_t* sc, uint16_t* tk, uint3
     m = e[i] > m ? e[i] : m;
   }
   const uint32_t thr = kth_lane_value(m, k, lane, scratch);
+  const uint32_t thr1 = thr ? thr : 1u;  // empty slots (0) never pass: one compare per entry
   DEVA_COMPILER_FENCE();
   int base = 0;
 #pragma unroll
   for (int i = 0; i < E; ++i) {
-    const bool keep = e[i] >= thr && e[i] != 0u;
-    const unsigned long long b = __ballot(keep);
+    const bool keep = e[i] >= thr1;
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(keep);
     if (keep) {
       const int w = base + prefix_below(b);
       sc[w] = raw[i];
@@ -239,7 +240,7 @@ __device__ __forceinline__ uint32_t prune_list_exact(uint32_t* sc, uint16_t* tk,
 #pragma unroll
   for (int i = 0; i < E; ++i) {
     const bool keep = e[i] >= thr && e[i] != 0ull;
-    const unsigned long long b = __ballot(keep);
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(keep);
     if (keep) {
       const int w = base + prefix_below(b);
       sc[w] = __float_as_uint(from_orderable((uint32_t)(e[i] >> 32)));
@@ -269,7 +270,19 @@ struct AffArgs {
   uint32_t* part_cnt;  // [splits][hw] live entries of each list
   int ablate;          // timing probes, builds with -DDEVA_AFFINITY_PROBES only (0 otherwise): 1 = file nothing,
                        // 2 = no key loads in the loop, 4 = no scoring, 8 = no MFMAs; results are meaningless when non-zero
+  uint64_t* probe;     // probe builds: cycle stamps of the first workgroups' phases (tools/probe/affinity_phases.py)
 };
+
+#ifdef DEVA_AFFINITY_PROBES
+#define DEVA_STAMP(slot)                                                                    \
+  do {                                                                                      \
+    if (pb && it < 64 && lane == 0) pb[it * 8 + (slot)] = __builtin_readcyclecounter();     \
+  } while (0)
+#else
+#define DEVA_STAMP(slot) \
+  do {                   \
+  } while (0)
+#endif
 
 // key tile of the SHARED variant in LDS: [buffer][channel parity][token row][TROW floats]; a row holds
 // the 32 even (or odd) channels of one token; 36-float stride: 16-B aligned rows whose bank groups rotate
@@ -414,7 +427,7 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
   // fast = rank-counting prune first; the exact prune runs if that left the list above the limit (or
   // alone if !fast).  One exact prune leaves <= E*k <= limit entries in the tile loop.
   auto prune_over = [&](uint32_t limit, bool fast) {
-    uint64_t need = __ballot(cnt > limit) & 0xffffffffull;
+    uint64_t need = __builtin_amdgcn_ballot_w64(cnt > limit) & 0xffffffffull;
     while (need) {
       const int qq = __ffsll((unsigned long long)need) - 1;
       need &= need - 1;
@@ -534,7 +547,7 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
           const float v = v2[h];
           bool ok = v >= tau;
           if (!full_tile) ok = ok && (j0 + 4 * half < rows_left);
-          const unsigned long long b = __ballot(ok);
+          const unsigned long long b = __builtin_amdgcn_ballot_w64(ok);
           if (b) {
             // the two half-lanes of query l31 are lanes l31 and 32 + l31: one 32-bit bit-field extract each
             const uint32_t ok_lo = ((uint32_t)b >> l31) & 1u, ok_hi = ((uint32_t)(b >> 32) >> l31) & 1u;
@@ -685,22 +698,38 @@ __global__ __launch_bounds__(NW * 64, MINB) void affinity_topk_wg_kernel(const A
     DEVA_COMPILER_FENCE();
   };
 
+#ifdef DEVA_AFFINITY_PROBES
+  uint64_t* pb = (p.probe && blockIdx.x < 8 && blockIdx.y == 0) ? p.probe + (size_t)(blockIdx.x * NW + wave) * 64 * 8 : nullptr;
+#endif
   for (int it = 0; it < n_iter; ++it) {
+    DEVA_STAMP(0);
     __syncthreads();  // every append of the previous tile has landed: the list lengths are final
     // every wave reads all 32 lengths and thresholds (one LDS access each) and takes the same decision
     const uint32_t c_l = s_cnt[l31];
     float tau = s_tau[l31];
-    const uint32_t need = (uint32_t)__ballot(c_l > (uint32_t)(LCAP - BURST));
+    const uint32_t need = (uint32_t)__builtin_amdgcn_ballot_w64(c_l > (uint32_t)(LCAP - BURST));
+    // every wave has read this tile's list lengths (and taken the same pruning decision) before anyone appends
+    // again: without this barrier a fast wave's appends could change a slow wave's decision.  It follows the
+    // first barrier directly, so the skew of a whole tile (MFMAs, scoring, appends) is collected once per tile.
+    DEVA_COMPILER_FENCE();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the reads above
+    __builtin_amdgcn_s_barrier();
+    DEVA_COMPILER_FENCE();
+    DEVA_STAMP(1);
     if (need) {  // uniform over the workgroup: some list could overflow during the next tile
-      uint32_t mine = (need >> (wave * QW)) & ((1u << QW) - 1u);
-      while (mine) {
-        const int qq = wave * QW + __ffs((int)mine) - 1;
-        mine &= mine - 1;
-        prune_one(qq, (uint32_t)__builtin_amdgcn_readlane((int)c_l, qq), (uint32_t)(LCAP - BURST), true);
+      // the lists to prune are dealt out round-robin (any wave can prune any list of the workgroup)
+      uint32_t todo = need;
+      int nth = 0;
+      while (todo) {
+        const int qq = __ffs((int)todo) - 1;
+        todo &= todo - 1;
+        if ((nth++ % NW) == wave)
+          prune_one(qq, (uint32_t)__builtin_amdgcn_readlane((int)c_l, qq), (uint32_t)(LCAP - BURST), true);
       }
       __syncthreads();  // pruned lists / raised thresholds are visible
       tau = s_tau[l31];
     }
+    DEVA_STAMP(2);
     const bool work = it < n_vis;  // the ragged last round: a wave without a tile only keeps the barriers
     const int tile = split + p.splits * cyc;
     const int n_base = tile * TOKT;
@@ -708,7 +737,9 @@ __global__ __launch_bounds__(NW * 64, MINB) void affinity_topk_wg_kernel(const A
     f32x16 accA, accB;
     float4 ms4[4];  // scaled shrinkage in accumulator-row order: rows 4g..4g+3 <-> tokens 8g+4*half..+3
     if (work) {
-      if (lane < TOKT) msl[lane] = ms_buf * 0.125f;  // 1/sqrt(CK) folded in (exact)
+      // 1/sqrt(CK) folded in (exact); NaN past the end of the bank: such a score fails every threshold test, so
+      // the ragged last tile needs no per-row bound check
+      if (lane < TOKT) msl[lane] = (n_base + lane < p.n_total) ? ms_buf * 0.125f : __builtin_nanf("");
       DEVA_COMPILER_FENCE();
       // the MFMAs read the prefetched rows in place (channel 2t + half of this lane's token is x / z of the
       // 16-B pieces); the next tile's loads are issued after the last MFMA, under the scoring
@@ -735,6 +766,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void affinity_topk_wg_kernel(const A
         }
       }
       DEVA_COMPILER_FENCE();
+      DEVA_STAMP(3);
       if (it + 1 < n_vis) {
         cyc += step;
         cyc = cyc >= n_my ? cyc - n_my : cyc;
@@ -747,12 +779,9 @@ __global__ __launch_bounds__(NW * 64, MINB) void affinity_topk_wg_kernel(const A
         for (int g = 0; g < 4; ++g) ms4[g] = *reinterpret_cast<const float4*>(&msl[8 * g + 4 * half]);
       }
     }
-    // every wave has read this tile's list lengths (and taken the same pruning decision) before anyone
-    // appends again: without this barrier a fast wave's appends could change a slow wave's decision.
-    // (bare s_barrier: __syncthreads would also wait for the prefetch just issued)
     DEVA_COMPILER_FENCE();
-    __builtin_amdgcn_s_barrier();
-    DEVA_COMPILER_FENCE();
+    DEVA_STAMP(4);
+    DEVA_STAMP(5);
     if (!work) continue;
     if (p.ablate & 4) {
       if (accA[0] + accB[15] == 12345.678f) s_cnt[0] = 1u;
@@ -765,23 +794,29 @@ __global__ __launch_bounds__(NW * 64, MINB) void affinity_topk_wg_kernel(const A
 #pragma unroll
       for (int g = 0; g < 4; ++g) ms4[g] = *reinterpret_cast<const float4*>(&msl[8 * g + 4 * half]);
     }
-    const int rows_left = p.n_total - n_base;
     float v[16];
     uint32_t pos[16];
     unsigned long long okm[16];
+    const f32x2 bsq2 = {bsq, bsq};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float4 m4 = ms4[r >> 2];
-      const float m = (r & 3) == 0 ? m4.x : (r & 3) == 1 ? m4.y : (r & 3) == 2 ? m4.z : m4.w;
-      const float b = accB[r];
-      v[r] = (((b + b) - accA[r]) - bsq) * m;  // == ((-A + 2B) - bsq) * ms / 8, every step correctly rounded
-      const int j0 = (r & 3) + 8 * (r >> 2);
-      const bool ok = (v[r] >= tau) && (j0 + 4 * half < rows_left);
-      okm[r] = __ballot(ok);
-      // lanes that do not pass write to the spare slot LCAP of their row (never read): no predicate in phase B
-      pos[r] = (uint32_t)LCAP;
-      if (ok) pos[r] = atomicAdd(&s_cnt[l31], 1u);
+    for (int r2 = 0; r2 < 8; ++r2) {  // two accumulator rows per packed-fp32 instruction
+      const f32x2 a2 = {accA[2 * r2], accA[2 * r2 + 1]};
+      const f32x2 b2 = {accB[2 * r2], accB[2 * r2 + 1]};
+      const float4 m4 = ms4[r2 >> 1];
+      const f32x2 m2 = (r2 & 1) ? f32x2{m4.z, m4.w} : f32x2{m4.x, m4.y};
+      const f32x2 v2 = (((b2 + b2) - a2) - bsq2) * m2;  // == ((-A + 2B) - bsq) * ms / 8, every step correctly rounded
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int r = 2 * r2 + h;
+        v[r] = v2[h];
+        const bool ok = v[r] >= tau;
+        okm[r] = __builtin_amdgcn_ballot_w64(ok);
+        // lanes that do not pass write to the spare slot LCAP of their row (never read): no predicate in phase B
+        pos[r] = (uint32_t)LCAP;
+        if (ok) pos[r] = atomicAdd(&s_cnt[l31], 1u);
+      }
     }
+    DEVA_STAMP(6);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       if (okm[r]) {
@@ -791,6 +826,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void affinity_topk_wg_kernel(const A
       }
     }
     DEVA_COMPILER_FENCE();
+    DEVA_STAMP(7);
   }
 
   // every list of this wave down to at most `limit` entries (hand-over)
@@ -940,7 +976,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 1) void affinity_topk_pp_kernel(cons
     if (gw == 0 && lane < QT) s_delta[grp][j & 1][lane] = 0u;         // read at P(j-1), next used by Q(j)
     // the phase after the last visit prunes for the hand-over
     const uint32_t limit = (j == n_iter) ? (uint32_t)CAP : (uint32_t)(LCAP - BURST);
-    const uint32_t need = (uint32_t)__ballot(V > limit);
+    const uint32_t need = (uint32_t)__builtin_amdgcn_ballot_w64(V > limit);
     pruned = need;
     if (need) prune_mine(need, limit);                                 // nobody appends to this group's lists now
     if (j >= n_vis) return;
@@ -991,7 +1027,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 1) void affinity_topk_pp_kernel(cons
       v[r] = (((b + b) - accA[r]) - bsq) * m;  // == ((-A + 2B) - bsq) * ms / 8, every step correctly rounded
       const int j0 = (r & 3) + 8 * (r >> 2);
       const bool ok = (v[r] >= tau) && (j0 + 4 * half < rows_left);
-      okm[r] = __ballot(ok);
+      okm[r] = __builtin_amdgcn_ballot_w64(ok);
       pos[r] = 0u;
       if (ok) pos[r] = V + atomicAdd(dcount, 1u);
     }
@@ -1082,7 +1118,7 @@ __global__ __launch_bounds__(256) void affinity_finalize_kernel(const uint64_t* 
   for (int i = 0; i < ME; ++i) {
     if (i < n_live) {
       const bool keep = e[i] >= thr && e[i] != 0ull;
-      const unsigned long long b = __ballot(keep);
+      const unsigned long long b = __builtin_amdgcn_ballot_w64(keep);
       if (keep) unsorted[base + prefix_below(b)] = e[i];
       base += __popcll(b);
     }
@@ -1229,6 +1265,15 @@ extern "C" int deva_affinity_force_shape(int shape) {
   return 0;
 }
 
+#ifdef DEVA_AFFINITY_PROBES
+static uint64_t* g_probe = nullptr;
+// probe builds only (not part of the ABI): device buffer of 8 workgroups x 8 waves x 64 tiles x 8 cycle stamps
+extern "C" int deva_affinity_set_probe(uint64_t* buf) {
+  g_probe = buf;
+  return 0;
+}
+#endif
+
 extern "C" int deva_affinity_default_splits(int n_total, int hw) {
   // aim at one resident set of workgroups: 256 CUs x (1 or 2) four-wave workgroups
   const int shape = affinity_shape(n_total, hw);
@@ -1307,8 +1352,10 @@ extern "C" int deva_affinity_topk(const float* key_long, const float* shr_long, 
     return e ? atoi(e) : 0;
   }();
   a.ablate = ablate;
+  a.probe = g_probe;
 #else
   a.ablate = 0;
+  a.probe = nullptr;
 #endif
   dim3 grid((unsigned)ceil_div(hw, WAVES * QT), (unsigned)splits);
   const dim3 grid_wg((unsigned)ceil_div(hw, QT), (unsigned)splits);
