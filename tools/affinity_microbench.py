@@ -6,7 +6,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tracking-anything-with-deva_amd'))
 import torch  # noqa: E402
+from deva import hip  # noqa: E402
 from deva.hip import lib, ops  # noqa: E402
+
+if os.environ.get('DEVA_HIP_LIB'):  # e.g. the probe build tools/probe/libdeva_hip_probes.so
+    hip.LIB_PATH = os.path.abspath(os.environ['DEVA_HIP_LIB'])
 
 SHAPES = [(10000, 1620), (24580, 1620), (10000, 8160), (83440, 8160)]
 

@@ -752,12 +752,24 @@ __global__ __launch_bounds__(NW * 64, MINB) void affinity_topk_wg_kernel(const A
         accB[r] = 0.0f;
       }
       if (!(p.ablate & 8)) {
+#ifdef DEVA_AFFINITY_PROBES  // issue-priority experiments (profiles/r02e_affinity_shapes.txt item 10)
+        if (p.ablate & 32) {
+          if (blockIdx.y & 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);
+        } else if (p.ablate & 64) {
+          __builtin_amdgcn_s_setprio(3);
+        } else if (p.ablate & 128) {
+          if (blockIdx.y & 1) __builtin_amdgcn_s_setprio(3);
+        }
+#endif
 #pragma unroll
         for (int t = 0; t < CK / 2; ++t) {
           const float a = (t == CK / 2 - 2) ? a30 : (t == CK / 2 - 1) ? a31 : xbuf[t >> 1][(t & 1) * 2];
           accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a * a, bqe[t], accA, 0, 0, 0);
           accB = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bqk[t], accB, 0, 0, 0);
         }
+#ifdef DEVA_AFFINITY_PROBES
+        if (p.ablate & (32 | 64 | 128)) __builtin_amdgcn_s_setprio(0);
+#endif
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
