@@ -480,11 +480,11 @@ def main():
             result['roofline']['traffic_source'] = 'profiles/pmc_r02/conv_traffic.json'
             result['roofline']['traffic_over_algorithmic'] = d['hbm_bytes_per_frame'] / (alg_bytes / n_replay)
         result['affinity'] = affinity_microbench(device)
-        pmc_aff = os.path.join(ROOT, 'profiles', 'pmc_r02', 'affinity_per_launch_r02e.json')
+        pmc_aff = os.path.join(ROOT, 'profiles', 'pmc_r02', 'affinity_per_launch_r02f.json')
         if os.path.exists(pmc_aff):
             with open(pmc_aff) as f:
                 d = json.load(f)['10k']
-            result['affinity']['pmc'] = {'source': 'profiles/pmc_r02/affinity_per_launch_r02e.json',
+            result['affinity']['pmc'] = {'source': 'profiles/pmc_r02/affinity_per_launch_r02f.json',
                                          'mfma_util': d['mfma_util_frac'],
                                          'hbm_bytes': d.get('hbm_bytes'), 'algorithmic_bytes': d.get('algorithmic_bytes'),
                                          'valu_instructions_per_tile': d['per_wave_per_tile']['SQ_INSTS_VALU'],
