@@ -274,6 +274,12 @@ struct AffArgs {
 };
 
 #ifdef DEVA_AFFINITY_PROBES
+#define DEVA_ABLATE(bit) ((p.ablate & (bit)) != 0)
+#else
+#define DEVA_ABLATE(bit) false  // the probe paths are compiled out of the product build
+#endif
+
+#ifdef DEVA_AFFINITY_PROBES
 #define DEVA_STAMP(slot)                                                                    \
   do {                                                                                      \
     if (pb && it < 64 && lane == 0) pb[it * 8 + (slot)] = __builtin_readcyclecounter();     \
@@ -370,7 +376,7 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
   // ---- per-query state in registers (the same value in both half-lanes of a query): list length and
   // the running lower bound of the k-th best score
   uint32_t cnt = 0;
-  float tau = (p.ablate & 1) ? INFINITY : -INFINITY;
+  float tau = DEVA_ABLATE(1) ? INFINITY : -INFINITY;
 
   // Key rows are software-prefetched one tile ahead: lane (l31, half) reads the 256-B row of token
   // n_base + l31 while the matrix pipe works on the previous tile.  Lanes of the upper half start one
@@ -459,7 +465,7 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
       __syncthreads();
       if (it + 1 < n_my) {
         cyc = advance(cyc);
-        if (!(p.ablate & 2)) load_shared(cyc);
+        if (!DEVA_ABLATE(2)) load_shared(cyc);
       }
       if (!active) continue;
       prune_over((uint32_t)(LCAP - TOKT), true);
@@ -492,7 +498,7 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
       DEVA_COMPILER_FENCE();
       if (!LATE) {
         if (it + 1 < n_my) cyc = advance(cyc);
-        if (!(p.ablate & 2)) prefetch(cyc);
+        if (!DEVA_ABLATE(2)) prefetch(cyc);
       }
     }
 
@@ -502,7 +508,7 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
       accA[r] = 0.0f;
       accB[r] = 0.0f;
     }
-    if (!(p.ablate & 8)) {
+    if (!DEVA_ABLATE(8)) {
 #pragma unroll
       for (int t = 0; t < CK / 2; ++t) {
         const float a = a_op[t];
@@ -519,7 +525,7 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
     if (!SHARED && LATE) {
       DEVA_COMPILER_FENCE();
       if (it + 1 < n_my) cyc = advance(cyc);
-      if (!(p.ablate & 2)) prefetch(cyc);
+      if (!DEVA_ABLATE(2)) prefetch(cyc);
     }
 
     // ---- scores of this lane: query l31, tokens n_base + (r&3) + 8*(r>>2) + 4*half, two accumulator
@@ -561,7 +567,7 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
         }
       }
     };
-    if (p.ablate & 4) {  // keep the accumulators alive without scoring them
+    if (DEVA_ABLATE(4)) {  // keep the accumulators alive without scoring them
       if (accA[0] + accB[15] == 12345.678f) cnt += 1;
     } else if (rows_left >= TOKT) {
       file_rows(std::true_type{});
@@ -663,12 +669,12 @@ __global__ __launch_bounds__(NW * 64, MINB) void affinity_topk_wg_kernel(const A
 
   if (threadIdx.x < QT) {
     s_cnt[threadIdx.x] = 0u;
-    s_tau[threadIdx.x] = (p.ablate & 1) ? INFINITY : -INFINITY;
+    s_tau[threadIdx.x] = DEVA_ABLATE(1) ? INFINITY : -INFINITY;
   }
 
   f32x4 xbuf[CK / 4];
   float ms_buf;
-  auto prefetch = [&](int cyc_) {
+  auto prefetch = [&](int cyc_) __attribute__((always_inline)) {
     const int tile = split + p.splits * cyc_;
     const int n_mine = min(tile * TOKT + l31, p.n_total - 1);
     const float* krow = (n_mine < p.n_long) ? (p.key_long + (int64_t)n_mine * CK)
@@ -681,11 +687,8 @@ __global__ __launch_bounds__(NW * 64, MINB) void affinity_topk_wg_kernel(const A
   };
   if (n_vis > 0) prefetch(cyc);
 
-  // prune list qq (c entries) of this wave: rank-counting prune, exact rounds while it is above `limit`
-  auto prune_one = [&](int qq, uint32_t c, uint32_t limit, bool fast) {
-    int kept = (int)c;
-    uint32_t thr = 0u;
-    if (fast) thr = prune_list<E>(&s_sc[qq][0], &s_tk[qq][0], c, p.k, lane, &kept, &s_rank[wave][0]);
+  // after the rank-counting prune of list qq: exact rounds while it is above `limit`, then publish length / threshold
+  auto finish_prune = [&](int qq, int kept, uint32_t thr, uint32_t limit) __attribute__((always_inline)) {
     while ((uint32_t)kept > limit) {
       const uint32_t thr2 = prune_list_exact<E>(&s_sc[qq][0], &s_tk[qq][0], (uint32_t)kept, p.k, lane, &kept);
       thr = thr2 > thr ? thr2 : thr;
@@ -696,6 +699,22 @@ __global__ __launch_bounds__(NW * 64, MINB) void affinity_topk_wg_kernel(const A
       if (t_new > s_tau[qq]) s_tau[qq] = t_new;
     }
     DEVA_COMPILER_FENCE();
+  };
+  auto prune_one = [&](int qq, uint32_t c, uint32_t limit) __attribute__((always_inline)) {
+    int kept = (int)c;
+    const uint32_t thr = prune_list<E>(&s_sc[qq][0], &s_tk[qq][0], c, p.k, lane, &kept, &s_rank[wave][0]);
+    finish_prune(qq, kept, thr, limit);
+  };
+  // the lists of `todo` this wave takes (every NW-th, starting with the wave-th: any wave can prune any list of the
+  // workgroup); lengths from lane qq of c_l.  (Pruning two lists at a time, interleaved to cover each other's LDS round
+  // trips, was measured: bit-identical, no faster -- profiles/r02e_affinity_shapes.txt item 11.)
+  auto prune_share = [&](uint32_t todo, uint32_t c_l, uint32_t limit) __attribute__((always_inline)) {
+    int nth = 0;
+    while (todo) {
+      const int qq = __ffs((int)todo) - 1;
+      todo &= todo - 1;
+      if ((nth++ % NW) == wave) prune_one(qq, (uint32_t)__builtin_amdgcn_readlane((int)c_l, qq), limit);
+    }
   };
 
 #ifdef DEVA_AFFINITY_PROBES
@@ -717,15 +736,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void affinity_topk_wg_kernel(const A
     DEVA_COMPILER_FENCE();
     DEVA_STAMP(1);
     if (need) {  // uniform over the workgroup: some list could overflow during the next tile
-      // the lists to prune are dealt out round-robin (any wave can prune any list of the workgroup)
-      uint32_t todo = need;
-      int nth = 0;
-      while (todo) {
-        const int qq = __ffs((int)todo) - 1;
-        todo &= todo - 1;
-        if ((nth++ % NW) == wave)
-          prune_one(qq, (uint32_t)__builtin_amdgcn_readlane((int)c_l, qq), (uint32_t)(LCAP - BURST), true);
-      }
+      prune_share(need, c_l, (uint32_t)(LCAP - BURST));
       __syncthreads();  // pruned lists / raised thresholds are visible
       tau = s_tau[l31];
     }
@@ -751,13 +762,13 @@ __global__ __launch_bounds__(NW * 64, MINB) void affinity_topk_wg_kernel(const A
         accA[r] = 0.0f;
         accB[r] = 0.0f;
       }
-      if (!(p.ablate & 8)) {
+      if (!DEVA_ABLATE(8)) {
 #ifdef DEVA_AFFINITY_PROBES  // issue-priority experiments (profiles/r02e_affinity_shapes.txt item 10)
-        if (p.ablate & 32) {
+        if (DEVA_ABLATE(32)) {
           if (blockIdx.y & 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);
-        } else if (p.ablate & 64) {
+        } else if (DEVA_ABLATE(64)) {
           __builtin_amdgcn_s_setprio(3);
-        } else if (p.ablate & 128) {
+        } else if (DEVA_ABLATE(128)) {
           if (blockIdx.y & 1) __builtin_amdgcn_s_setprio(3);
         }
 #endif
@@ -782,7 +793,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void affinity_topk_wg_kernel(const A
       if (it + 1 < n_vis) {
         cyc += step;
         cyc = cyc >= n_my ? cyc - n_my : cyc;
-        if (!(p.ablate & 2)) prefetch(cyc);
+        if (!DEVA_ABLATE(2)) prefetch(cyc);
       }
       // this wave's own shrinkage row, read back before the barrier so that its LDS latency is not exposed after
       // it (the 8-wave instantiation has no registers to spare for that and reads it after the barrier)
@@ -795,7 +806,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void affinity_topk_wg_kernel(const A
     DEVA_STAMP(4);
     DEVA_STAMP(5);
     if (!work) continue;
-    if (p.ablate & 4) {
+    if (DEVA_ABLATE(4)) {
       if (accA[0] + accB[15] == 12345.678f) s_cnt[0] = 1u;
       continue;
     }
@@ -841,17 +852,15 @@ __global__ __launch_bounds__(NW * 64, MINB) void affinity_topk_wg_kernel(const A
     DEVA_STAMP(7);
   }
 
-  // every list of this wave down to at most `limit` entries (hand-over)
-  auto maintain = [&](uint32_t limit) {
-    for (int qq = wave * QW; qq < wave * QW + QW; ++qq) {
-      const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cnt[qq]);
-      if (c > limit) prune_one(qq, c, limit, true);
-    }
-  };
-
-  // ---- hand-over: wave w prunes its lists to at most CAP entries and writes them with their lengths
+  // ---- hand-over: every list down to at most CAP entries (exact rounds, if needed, shrink 704 -> 352 -> 192 -> 96 ->
+  // 64 at worst), then wave w writes lists w*QW .. with their lengths
   __syncthreads();
-  maintain((uint32_t)CAP);  // exact rounds, if needed, shrink 704 -> 352 -> 192 -> 96 -> 64 at worst
+  {
+    const uint32_t c_l = s_cnt[l31];
+    const uint32_t over = (uint32_t)__builtin_amdgcn_ballot_w64(c_l > (uint32_t)CAP);
+    prune_share(over, c_l, (uint32_t)CAP);
+  }
+  __syncthreads();  // lists pruned by other waves are visible
   DEVA_COMPILER_FENCE();
   for (int qq = wave * QW; qq < wave * QW + QW; ++qq) {
     if (q0 + qq >= p.hw) break;
@@ -936,7 +945,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 1) void affinity_topk_pp_kernel(cons
     const int g = threadIdx.x / QT, qq = threadIdx.x % QT;
     s_delta[g][0][qq] = 0u;
     s_delta[g][1][qq] = 0u;
-    s_tau[g][qq] = (p.ablate & 1) ? INFINITY : -INFINITY;
+    s_tau[g][qq] = DEVA_ABLATE(1) ? INFINITY : -INFINITY;
   }
   uint32_t V = 0u;          // length of this group's list l31 (identical in the four waves of the group)
   uint32_t pruned = 0u;     // lists of this group pruned in the last P phase
