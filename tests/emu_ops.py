@@ -122,37 +122,19 @@ def _bank(key_long, n_long, key_work, n_work):
     return torch.cat(parts, 0)
 
 
-def _topk_contract(sim, k):
-    """top-k per column with the kernels' tie rule: higher score first, then LOWER token index (torch.topk's tie order is
-    unspecified).  -> (vals [k,hw], idx [k,hw])"""
-    n = sim.shape[0]
-    k2 = min(n, k + 16)
-    vals, idx = torch.topk(sim, k=k2, dim=0)
-    if k2 < n and bool((vals[k2 - 1] == vals[k - 1]).any()):  # a tie run reaches past the margin: order everything
-        k2 = n
-        vals, idx = torch.sort(sim, dim=0, descending=True, stable=True)
-    by_token = idx.argsort(dim=0, stable=True)
-    vals, idx = vals.gather(0, by_token), idx.gather(0, by_token)
-    by_score = (-vals).argsort(dim=0, stable=True)
-    return vals.gather(0, by_score)[:k].contiguous(), idx.gather(0, by_score)[:k].contiguous()
-
-
 def affinity_topk(key_long, shr_long, n_long, key_work, shr_work, n_work, qk, qe, k, usage_fix=None,
                   splits=None):
     mk = _bank(key_long, n_long, key_work, n_work)          # [N,64] token-major
     ms = _bank(shr_long, n_long, shr_work, n_work)          # [N]
     if mk.shape[0] < k:
         raise real.DevaHipError('selected index k out of range')
-    # accumulated in float64 and rounded once: like the kernel's, a column's (and a token's) scores do not depend on
-    # which other columns / tokens share the call (a float32 BLAS product does, through its blocking)
-    mkd, qkd, qed = mk.double(), qk.double(), qe.double()
-    a_sq = mkd.pow(2) @ qed
-    two_ab = 2 * (mkd @ (qkd * qed))
-    b_sq = (qed * qkd.pow(2)).sum(0, keepdim=True)
-    sim = ((-a_sq + two_ab - b_sq) * ms.double()[:, None] / 8.0).float()
-    vals, idx = _topk_contract(sim, k)                       # [k,hw]
-    w = vals.double().exp()  # float64 and one rounding: independent of the columns sharing the call (see above)
-    w = (w / w.sum(0, keepdim=True)).float()
+    a_sq = mk.pow(2) @ qe
+    two_ab = 2 * (mk @ (qk * qe))
+    b_sq = (qe * qk.pow(2)).sum(0, keepdim=True)
+    sim = (-a_sq + two_ab - b_sq) * ms[:, None] / 8.0
+    vals, idx = torch.topk(sim, k=k, dim=0)                  # [k,hw]
+    w = vals.exp()
+    w = w / w.sum(0, keepdim=True)
     idx, w = idx.t().contiguous(), w.t().contiguous()
     if usage_fix is not None:
         usage_fix.index_add_(0, idx.reshape(-1), (w.reshape(-1).double() * TWO40).long())
@@ -191,14 +173,11 @@ def affinity_candidates(key_long, shr_long, n_long, key_work, shr_work, n_work, 
                         splits=None):
     mk = _bank(key_long, n_long, key_work, n_work)
     ms = _bank(shr_long, n_long, shr_work, n_work)
-    # accumulated in float64 and rounded once: like the kernel's, a column's (and a token's) scores do not depend on
-    # which other columns / tokens share the call (a float32 BLAS product does, through its blocking)
-    mkd, qkd, qed = mk.double(), qk.double(), qe.double()
-    a_sq = mkd.pow(2) @ qed
-    two_ab = 2 * (mkd @ (qkd * qed))
-    b_sq = (qed * qkd.pow(2)).sum(0, keepdim=True)
-    sim = ((-a_sq + two_ab - b_sq) * ms.double()[:, None] / 8.0).float()
-    vals, idx = _topk_contract(sim, k)
+    a_sq = mk.pow(2) @ qe
+    two_ab = 2 * (mk @ (qk * qe))
+    b_sq = (qe * qk.pow(2)).sum(0, keepdim=True)
+    sim = (-a_sq + two_ab - b_sq) * ms[:, None] / 8.0
+    vals, idx = torch.topk(sim, k=k, dim=0)
     hw = qk.shape[1]
     keys = torch.zeros((hw, 64), dtype=torch.int64)
     token = (idx.t().long() + token_offset)
@@ -218,8 +197,8 @@ def affinity_merge(keys, counts, k, usage_fix=None):
     bits = torch.where(o >= 0x80000000, o & 0x7fffffff, (~o) & 0xffffffff)
     score = bits
     score = torch.where(score >= 0x80000000, score - (1 << 32), score).to(torch.int32).view(torch.float32)
-    w = score.double().exp()  # as in affinity_topk
-    w = (w / w.sum(1, keepdim=True)).float()
+    w = score.exp()
+    w = w / w.sum(1, keepdim=True)
     if usage_fix is not None:
         usage_fix.index_add_(0, token.reshape(-1), (w.reshape(-1).double() * TWO40).long())
     return token.int(), w

@@ -160,6 +160,13 @@ def test_readout_two_segments_ragged():
     assert max_err(out, want) <= 1e-4
 
 
+# bit-identity across differently shaped launches is a property of the kernels (fixed accumulation order per score),
+# not of the PyTorch emulation the dry run substitutes (a float32 BLAS product depends on its blocking)
+kernel_property = pytest.mark.skipif(os.environ.get('DEVA_TEST_DRYRUN') == '1',
+                                     reason='checks a property of the HIP kernels; the dry run emulates them')
+
+
+@kernel_property
 def test_query_column_slices_are_bit_identical():
     """the multi-GPU read shards the queries by column (MemoryManager.shard_queries): every column's
     result must not depend on which other columns share the launch, and the fixed-point usage
@@ -182,6 +189,7 @@ def test_query_column_slices_are_bit_identical():
         assert torch.equal(fix, full_fix), world
 
 
+@kernel_property
 @pytest.mark.parametrize('world', [2, 3, 8])
 def test_token_sharded_read_merges_to_the_unsharded_result(world):
     """bank sharded by token range (MemoryManager.shard_bank): every shard's own top-k, in the hand-over
