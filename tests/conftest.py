@@ -31,6 +31,16 @@ def recipe_state_dict():
     return weights.make_state_dict(triples, seed=0), spec
 
 
+@pytest.fixture(scope='session')
+def peaky_state_dict(recipe_state_dict):
+    """the second recipe (sharper affinities and logits; workload/weights.py:RECIPES['peaky'])"""
+    import torch
+    from workload import weights
+    _, spec = recipe_state_dict
+    triples = [(k, tuple(s), getattr(torch, d)) for k, s, d in spec['tensors']]
+    return weights.make_state_dict(triples, seed=0, recipe='peaky')
+
+
 def pytest_sessionstart(session):
     """DEVA_TEST_DRYRUN=1 (builder's container, no GPU): run the -m gpu test CODE on the CPU with the
     emulated ops so that a typo does not cost a GPU-box session.  Never set on the GPU box: there the

@@ -43,10 +43,10 @@ torch.set_grad_enabled(False)
 torch.set_num_threads(8)
 
 
-def build_reference(cfg):
+def build_reference(cfg, recipe='default'):
     net = DEVA(cfg).eval()
     spec = [(k, tuple(v.shape), v.dtype) for k, v in net.state_dict().items()]
-    sd = weights.make_state_dict(spec, seed=0)
+    sd = weights.make_state_dict(spec, seed=0, recipe=recipe)
     net.load_weights(sd)
     return net, spec, sd
 
@@ -117,6 +117,46 @@ def gen_e2e(net):
             nchan=np.array([p.shape[0] for p in outs]),
             sizes=json.dumps(sizes))
         print(name, 'frames', len(outs), 'sizes', sizes)
+
+
+def gen_peaky():
+    """the second weight recipe (workload/weights.py:RECIPES['peaky']): a plain propagation clip and the
+    tracker-consistent detection clip (workload/detections.py; matches, new buckets, purges, consolidation),
+    both run by the reference itself"""
+    from deva.inference.object_info import ObjectInfo
+    from workload import detections
+    net, _, _ = build_reference(synth.base_config(), recipe='peaky')
+    for name, sc in scenarios.E2E_PEAKY.items():
+        outs, core = scenarios.run_scenario(lambda cfg: DEVAInferenceCore(net, cfg), sc)
+        mem = core.memory
+        sizes = dict(work={b: mem.work_mem.size(b) for b in mem.work_mem.buckets},
+                     long={b: mem.long_mem.size(b) for b in mem.long_mem.buckets})
+        np.savez_compressed(os.path.join(HERE, f'e2e_{name}.npz'),
+                            **{f'prob_sub_{t}': p[:, ::2, ::2].numpy() for t, p in enumerate(outs)},
+                            argmax=np.stack([p.argmax(0).numpy().astype(np.uint8) for p in outs]),
+                            nchan=np.array([p.shape[0] for p in outs]), sizes=json.dumps(sizes))
+        print(name, 'frames', len(outs), 'sizes', sizes)
+    sc = scenarios.CONSISTENT
+    holder = {}
+
+    def make_core(cfg):
+        holder['core'] = DEVAInferenceCore(net, cfg)
+        return holder['core']
+
+    outs, core, recorded = scenarios.run_consistent_detection_scenario(
+        make_core, ObjectInfo, sc,
+        record=lambda det, rec, frame_of: detections.record_on_package(holder['core'], det, ObjectInfo, rec, frame_of))
+    mem = core.memory
+    sizes = dict(work={b: mem.work_mem.size(b) for b in mem.work_mem.buckets},
+                 long={b: mem.long_mem.size(b) for b in mem.long_mem.buckets})
+    np.savez_compressed(os.path.join(HERE, 'e2e_consistent_detections.npz'),
+                        **{f'prob_sub_{t}': p[:, ::2, ::2].numpy() for t, p in enumerate(outs)},
+                        **{f'det_mask_{t}': m.numpy().astype(np.int32) for t, (m, _) in recorded.items()},
+                        det_info=json.dumps({str(t): info for t, (_, info) in recorded.items()}),
+                        nchan=np.array([p.shape[0] for p in outs]), sizes=json.dumps(sizes),
+                        state=json.dumps(_manager_state(core.object_manager)))
+    print('consistent detections: channels per frame', [p.shape[0] for p in outs], _manager_state(core.object_manager),
+          sizes)
 
 
 def gen_vos_example(net):
@@ -314,6 +354,9 @@ if __name__ == '__main__':
         net, _, _ = build_reference(synth.base_config())
         gen_consensus_auto(net)
         sys.exit(0)
+    if only == 'peaky':
+        gen_peaky()
+        sys.exit(0)
     if only == 'alignment':
         net, _, _ = build_reference(synth.base_config())
         gen_alignment(net)
@@ -332,5 +375,6 @@ if __name__ == '__main__':
     gen_edge(net)
     gen_read_memory(net)
     gen_api_surface()
+    gen_peaky()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -119,32 +119,60 @@ def explain_flips(tag: str, hip_read: Dict, ref_read: Dict, slack: float = 4.0):
     return len(flipped), (worst_excess if flipped else 0.0), slack
 
 
-def margin_aware_mismatch(got: torch.Tensor, ref: torch.Tensor, err: float) -> int:
-    """argmax mismatches at pixels whose reference top-1/top-2 margin exceeds 2*err"""
+NORTH_STAR = 1e-3  # BASELINE.json north_star: max-abs bound on the soft outputs
+
+
+def margin_aware_mismatch(got: torch.Tensor, ref: torch.Tensor, floor: float = None) -> int:
+    """argmax mismatches at pixels whose REFERENCE top-1/top-2 margin exceeds 2 x max(floor, 1e-3), where
+    `floor` is the reference's own noise on this frame (reference vs the reference under a 1e-6 relative
+    input perturbation) -- NOT the error under test (with the observed error as the margin
+    the check cannot fail).  Without a floor run the margin is the fixed 2 x 1e-3 of the north-star bound."""
+    return argmax_flips(got, ref, floor)[1]
+
+
+def argmax_flips(got: torch.Tensor, ref: torch.Tensor, floor: float = None, margin: float = None):
+    """-> (raw argmax flips, flips at pixels whose reference margin exceeds `margin`)
+    margin defaults to 2 x max(floor, 1e-3)"""
     top2 = ref.topk(2, dim=0)[0]
-    decisive = (top2[0] - top2[1]) > 2 * err
-    return int(((got.argmax(0) != ref.argmax(0)) & decisive).sum())
+    if margin is None:
+        margin = 2 * max(floor or 0.0, NORTH_STAR)
+    flipped = got.argmax(0) != ref.argmax(0)
+    return int(flipped.sum()), int((flipped & ((top2[0] - top2[1]) > margin)).sum())
 
 
 class Drift:
-    """Free-running full-resolution clips.  The bound on the soft outputs is north_star's 1e-3 max-abs
-    (or 10x the reference's own drift under a 1e-6 relative input perturbation, measured in the same
-    test, if that is larger).  It may be exceeded ONLY from a frame on in which a top-k selection of
-    the HIP run differs from the reference's and that difference is explained by a measured near-tie:
-    the reference's own score gap at the k-th/(k+1)-th boundary is within the measured score noise
-    between the two runs (tests/memory_audit.py:explain_flips).  An unexplained differing selection
-    fails the test at once; so does an exceedance without a recorded flip."""
+    """Free-running full-resolution clips, three tiers per frame (e = max-abs HIP vs reference):
+      e <= 1e-3                      the north-star bound, always fine;
+      1e-3 < e <= 10 x floor         allowed ONLY from a frame on in which a discrete decision of the HIP run
+                                     differs from the reference's and is explained: a top-k selection at a
+                                     measured near-tie (explain_flips: the reference's score gap at the
+                                     k-th/(k+1)-th boundary is within the measured score noise) or a merged
+                                     hard-mask pixel whose forward argmax differs (`note_flip`);
+      e > max(1e-3, 10 x floor)      fails unconditionally.
+    floor = the reference's own drift on this clip under a 1e-6 relative input perturbation (max over the
+    frames), measured in the same test; without a floor run (or with strict=True) the bound is 1e-3 flat.
+    Argmax: flips at pixels whose reference margin exceeds 2 x the bound must be zero (the bound does not
+    depend on the error under test); raw flips, flips above 2 x max(frame floor, 1e-3) and the reference's
+    own flips under the perturbation are printed per frame.  An unexplained differing top-k selection fails
+    at once."""
 
-    def __init__(self, tag, stride=1):
-        self.tag, self.ours, self.floor, self.stride = tag, [], [], stride
+    def __init__(self, tag, stride=1, strict=False):
+        self.tag, self.ours, self.floor, self.stride, self.strict = tag, [], [], stride, strict
         self.frames = []
+        self.pending = []  # (frame, got, ref) kept until the clip's floor is known
         self.first_flip_frame = None
         self.flips = 0
+        self.raw_flips = self.flips_above_floor = self.ref_flips = 0
 
     @staticmethod
     def _stats(a, b):
         d = (a - b).abs()
         return d.max().item(), (d > 1e-3).float().mean().item()
+
+    def note_flip(self, frame):
+        """a discrete decision differed at `frame` (and was explained by the caller)"""
+        if self.first_flip_frame is None:
+            self.first_flip_frame = frame
 
     def audit_reads(self, frame, hip_reads, ref_reads):
         """compare the top-k selections of this frame's memory reads (one per bucket)"""
@@ -153,39 +181,53 @@ class Drift:
             n, excess, slack = explain_flips(f'{self.tag} frame {frame} bucket#{bi}', hr, rr)
             assert excess <= slack, (f'{self.tag} frame {frame}: top-k selection differs from the reference and the '
                                      f'score gap is {excess:.1f}x the measured score noise: not a near-tie')
-            if n and self.first_flip_frame is None:
-                self.first_flip_frame = frame
+            if n:
+                self.note_flip(frame)
             self.flips += n
 
     def add(self, got, ref, ref_perturbed=None, frame=None):
+        frame = len(self.ours) if frame is None else frame
         err, frac = self._stats(got, ref)
-        bad = margin_aware_mismatch(got, ref, err)
-        flips = int((got.argmax(0) != ref.argmax(0)).sum())
-        self.ours.append((err, frac))
-        self.frames.append(len(self.ours) - 1 if frame is None else frame)
-        msg = (f'{self.tag} frame {len(self.ours) - 1 if frame is None else frame}: HIP vs ref max-abs {err:.2e} frac>1e-3 {frac:.2e} '
-               f'raw flips {flips} margin-aware mismatches {bad}')
+        f_err = None
+        msg = f'{self.tag} frame {frame}: HIP vs ref max-abs {err:.2e} frac>1e-3 {frac:.2e}'
         if ref_perturbed is not None:
             f_err, f_frac = self._stats(ref_perturbed, ref)
             self.floor.append((f_err, f_frac))
-            msg += (f' | ref vs ref(1e-6 input noise) max-abs {f_err:.2e} frac>1e-3 {f_frac:.2e} '
-                    f'flips {int((ref_perturbed.argmax(0) != ref.argmax(0)).sum())}')
+        raw, above = argmax_flips(got, ref, f_err)
+        msg += f' argmax flips raw {raw}, at margin > {2 * max(f_err or 0.0, NORTH_STAR):.1e}: {above}'
+        if ref_perturbed is not None:
+            r_raw, r_above = argmax_flips(ref_perturbed, ref, f_err)
+            self.ref_flips += r_raw
+            msg += f' | ref vs ref(1e-6 input noise) max-abs {f_err:.2e} frac>1e-3 {f_frac:.2e} flips raw {r_raw}'
         print(msg)
-        assert bad == 0, msg
+        self.raw_flips += raw
+        self.flips_above_floor += above
+        self.ours.append((err, frac))
+        self.frames.append(frame)
+        top2 = ref.topk(2, dim=0)[0]
+        flipped = got.argmax(0) != ref.argmax(0)
+        self.pending.append((frame, (top2[0] - top2[1])[flipped]))  # reference margins of the flipped pixels
 
     def finish(self):
         fl_err = max([e for e, _ in self.floor] + [0.0])
-        bound = max(1e-3, 10 * fl_err)
+        bound = NORTH_STAR if self.strict else max(NORTH_STAR, 10 * fl_err)
         ours_err = max(e for e, _ in self.ours)
         print(f'{self.tag}: clip max-abs {ours_err:.2e} (reference self-drift {fl_err:.2e}, bound {bound:.1e}); '
-              f'top-k selections differing from the reference: {self.flips} (all explained near-ties), first at frame '
-              f'{self.first_flip_frame}')
+              f'top-k selections differing from the reference: {self.flips} (all explained near-ties), first discrete '
+              f'difference at frame {self.first_flip_frame}; argmax flips raw {self.raw_flips} '
+              f'(reference vs itself: {self.ref_flips}), at margin > 2 x max(frame floor, 1e-3): {self.flips_above_floor}')
         for t, (e, _) in zip(self.frames, self.ours):
-            if e > bound:
+            assert e <= bound, f'{self.tag} frame {t}: max-abs {e:.2e} above the bound {bound:.1e}'
+            if e > NORTH_STAR:
                 assert self.first_flip_frame is not None and t >= self.first_flip_frame, \
-                    (f'{self.tag} frame {t}: error {e:.2e} above {bound:.1e} without a differing top-k selection '
+                    (f'{self.tag} frame {t}: error {e:.2e} above {NORTH_STAR:.0e} without a differing discrete decision '
                      'at or before this frame')
-        assert ours_err <= 5e-2, (self.tag, ours_err)
+        for t, margins in self.pending:
+            decisive = int((margins > 2 * bound).sum())
+            assert decisive == 0, (f'{self.tag} frame {t}: {decisive} argmax flips at pixels whose reference margin '
+                                   f'exceeds 2 x {bound:.1e}')
+        return dict(max_abs=ours_err, floor=fl_err, bound=bound, raw_flips=self.raw_flips, ref_flips=self.ref_flips,
+                    flips_above_floor=self.flips_above_floor, topk_flips=self.flips)
 
 
 def _cmp(name, got, ref, tol, worst):

@@ -107,6 +107,76 @@ def run_detection_scenario(make_core, make_info, sc, device='cpu'):
     return outs, core
 
 
+# ---------------------------------------------------------------------------------------------
+# the "peaky" weight recipe (workload/weights.py:RECIPES): sharper affinities and logits, so that the
+# north-star criteria (1e-3 max-abs free-running, argmax-identical masks) are testable as written
+E2E_PEAKY: Dict[str, Dict] = {
+    'peaky': dict(H=96, W=128, nobj=3, frames=14, second=None, cfg=dict(mem_every=3)),
+}
+
+# tracker-consistent detections (workload/detections.py): re-detections that match (IoU 0.875), new
+# segments that spawn objects in new buckets, objects that go unseen and are purged -- BASELINE
+# configs[2]'s merge / purge / multi-object memory path.  Peaky recipe.
+CONSISTENT = dict(H=96, W=128, frames=17, every=3, segments=4, new_per_frame=1,
+                  cfg=dict(mem_every=2, max_missed_detection_count=1, max_num_objects=-1, max_mid_term_frames=6,
+                           min_mid_term_frames=3, num_prototypes=32, max_long_term_elements=300))
+
+
+def run_consistent_detection_scenario(make_core, make_info, sc, device='cpu', record=None, replay=None,
+                                      perturb=None, on_frame=None):
+    """Drives `incorporate_detection` every `every`-th frame and `step` in between.
+    record(detector, recorded, frame_of) -> context manager (workload.detections.record_on_*) under which the
+    run GENERATES its detections from its own forward masks (they end up in the returned dict);
+    replay = {frame: (mask, info)} recorded by another run, fed through the public interface.
+    -> (per-frame outputs on the CPU, core, {frame: (mask, info)})"""
+    import numpy as np
+    from workload.detections import ConsistentDetector
+    np.random.seed(0)
+    assert (record is None) != (replay is None)
+    cfg = synth.base_config(**sc['cfg'])
+    core = make_core(cfg)
+    H, W = sc['H'], sc['W']
+    stream = synth.FrameStream(H, W, seed=sc.get('seed', 1))
+    detector = ConsistentDetector(H, W, sc['segments'], sc['new_per_frame'])
+    recorded, now, outs = {}, [0], []
+    for t in range(sc['frames']):
+        now[0] = t
+        img = stream.next()
+        if perturb is not None:
+            img = perturb(img)
+        img = img.to(device)
+        if t % sc['every'] == 0:
+            if record is not None:
+                with record(detector, recorded, lambda: now[0]):
+                    p = core.incorporate_detection(img, torch.zeros(H, W, dtype=torch.long, device=device), [])
+            else:
+                m, info = replay[t]
+                p = core.incorporate_detection(img, m.to(device), [make_info(**i) for i in info])
+        else:
+            p = core.step(img, end=(t == sc['frames'] - 1))
+        outs.append(p.detach().float().cpu())
+        if on_frame is not None:
+            on_frame(t, core)
+    return outs, core, (recorded if record is not None else replay)
+
+
+def load_consistent_golden(golden_dir):
+    """-> (npz, {frame: (mask, info)}) of tests/golden/e2e_consistent_detections.npz"""
+    import json
+    import numpy as np
+    g = np.load(os.path.join(golden_dir, 'e2e_consistent_detections.npz'))
+    info = json.loads(str(g['det_info']))
+    return g, {int(t): (torch.from_numpy(g[f'det_mask_{t}'].astype('int64')), i) for t, i in info.items()}
+
+
+def manager_state(om):
+    """the observable object table of an ObjectManager (ids in tmp order, poke counters, category votes)"""
+    return dict(ids=[int(o.id) for o in om.obj_to_tmp_id], tmp=[int(t) for t in om.obj_to_tmp_id.values()],
+                poke=[int(o.poke_count) for o in om.obj_to_tmp_id],
+                cats=[[None if c is None else int(c) for c in o.category_ids] for o in om.obj_to_tmp_id],
+                isthing=[o.isthing for o in om.obj_to_tmp_id])
+
+
 def merge_case(seed):
     """inputs of a stand-alone match_and_merge call: propagated tmp-id mask with 3 objects
     (thing / stuff / untyped), detections that match, overlap too little, are new, or overlap an

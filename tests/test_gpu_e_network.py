@@ -1,11 +1,13 @@
 """The network stages and the full frame loop on the MI355X against (a) the golden vectors produced
 by the reference itself and (b) the CPU oracle run side by side on the GPU box.
 
-Tolerances (BASELINE.json north_star): soft outputs within 1e-3 max-abs of the reference CPU path;
-hard masks argmax-identical wherever the oracle's top-1/top-2 probability margin exceeds twice the
-observed max-abs difference (margin-aware rule of SURVEY.md §7: with synthetic weights many pixels
-sit at ties that flip under any reduction-order change, including the reference against itself).
-Teacher-forced per-stage checks use a much tighter 2e-4 relative bound."""
+Tolerances (BASELINE.json north_star): soft outputs within 1e-3 max-abs of the reference CPU path; hard
+masks argmax-identical at every pixel whose reference top-1/top-2 margin exceeds twice the BOUND of the
+clip -- 1e-3, or 10x the reference's own drift under a 1e-6 input perturbation where that is larger and a
+differing discrete decision has been explained (tests/memory_audit.py:Drift; the margin never depends on
+the error under test).  With the default recipe many pixels sit at near-ties that the reference flips
+against itself; the "peaky" recipe (workload/weights.py) has a noise floor of ~3e-4 and is held to the
+north-star numbers as written (strict=True).  Teacher-forced per-stage checks use a 2e-4 relative bound."""
 import json
 import os
 
@@ -36,11 +38,19 @@ _margin_aware_mismatch = memory_audit.margin_aware_mismatch
 _Drift = memory_audit.Drift
 
 
+@pytest.fixture(scope='module')
+def peaky_network(peaky_state_dict):
+    from deva.model.network import DEVA
+    net = DEVA(synth.base_config())
+    net.load_weights(peaky_state_dict)
+    return net.to(dev()).eval()
+
+
 def _paired_clip(tag, stride, hip_frames, noisy_frames, hip_tap_marks, ref_tap_marks, hip_tap, ref_tap,
-                 reference_outputs):
+                 reference_outputs, strict=False):
     """frame-by-frame comparison of a HIP run against reference outputs, with the selection audit
     against the live oracle run (`*_marks[t]` = number of reads recorded up to and including frame t)"""
-    drift = _Drift(tag, stride=stride)
+    drift = _Drift(tag, stride=stride, strict=strict)
     for t, p in enumerate(hip_frames):
         lo_h, hi_h = (hip_tap_marks[t - 1] if t else 0), hip_tap_marks[t]
         lo_r, hi_r = (ref_tap_marks[t - 1] if t else 0), ref_tap_marks[t]
@@ -98,6 +108,88 @@ def test_e2e_against_reference_golden(network, golden_dir, recipe_state_dict, na
                                            perturb=lambda img: img * (1 + 1e-6 * torch.randn(img.shape, generator=gen)))
     _paired_clip(name, 2, [p[:, ::2, ::2] for p in outs], [p[:, ::2, ::2] for p in noisy_outs], hip_marks, ref_marks,
                  hip_tap, ref_tap, [torch.from_numpy(g[f'prob_sub_{t}']) for t in range(len(outs))])
+
+
+def test_e2e_peaky_against_reference_golden(peaky_network, golden_dir, peaky_state_dict):
+    """the peaky recipe against the reference's own outputs, held to the north-star numbers as written:
+    <= 1e-3 max-abs on every frame (no floor multiplier) and no argmax flip at a margin above 2e-3"""
+    from deva.inference.inference_core import DEVAInferenceCore
+    sc = scenarios.E2E_PEAKY['peaky']
+    hip_marks, ref_marks = [], []
+    with memory_audit.ReadTap() as hip_tap:
+        outs, core = scenarios.run_scenario(lambda cfg: DEVAInferenceCore(peaky_network, cfg), sc, device=dev(),
+                                            on_frame=lambda t, c: hip_marks.append(len(hip_tap.reads)))
+    g = np.load(os.path.join(golden_dir, 'e2e_peaky.npz'))
+    with memory_audit.OracleTap() as ref_tap:
+        scenarios.run_scenario(lambda cfg: O.OracleCore(peaky_state_dict, cfg), sc,
+                               on_frame=lambda t, c: ref_marks.append(len(ref_tap.reads)))
+    gen = torch.Generator().manual_seed(0)
+    noisy_outs, _ = scenarios.run_scenario(lambda cfg: O.OracleCore(peaky_state_dict, cfg), dict(sc),
+                                           perturb=lambda img: img * (1 + 1e-6 * torch.randn(img.shape, generator=gen)))
+    _paired_clip('peaky', 2, [p[:, ::2, ::2] for p in outs], [p[:, ::2, ::2] for p in noisy_outs], hip_marks, ref_marks,
+                 hip_tap, ref_tap, [torch.from_numpy(g[f'prob_sub_{t}']) for t in range(len(outs))], strict=True)
+
+
+def test_480p_five_objects_peaky_recipe_north_star_as_written(peaky_network, peaky_state_dict):
+    """BASELINE configs[1] shape with the peaky recipe, free-running HIP vs the CPU oracle: <= 1e-3 max-abs on
+    every frame and argmax-identical at every pixel with a reference margin above 2e-3 (strict)"""
+    from deva.inference.inference_core import DEVAInferenceCore
+    P = peaky_state_dict
+    cfg = synth.base_config(enable_long_term=False, enable_long_term_count_usage=False)
+    H, W, no, frames = 480, 854, 5, 7
+    hip, orc, noisy = DEVAInferenceCore(peaky_network, cfg), O.OracleCore(P, cfg), O.OracleCore(P, cfg)
+    stream = synth.FrameStream(H, W, seed=2)
+    mask0 = synth.box_mask(H, W, no)
+    objs = list(range(1, no + 1))
+    gen = torch.Generator().manual_seed(0)
+    drift = _Drift('480p/5obj/peaky', strict=True)
+    for t in range(frames):
+        img = stream.next()
+        img_n = img * (1 + 1e-6 * torch.randn(img.shape, generator=gen))
+        first = (mask0, objs) if t == 0 else (None, None)
+        with memory_audit.ReadTap() as hip_tap:
+            a = hip.step(img.to(dev()), None if first[0] is None else first[0].to(dev()), first[1])
+        with memory_audit.OracleTap() as ref_tap:
+            b = orc.step(img, first[0], first[1])
+        c = noisy.step(img_n, first[0], first[1])
+        drift.audit_reads(t, hip_tap.reads, ref_tap.reads)
+        drift.add(a.cpu(), b, c)
+    report = drift.finish()
+    print('480p/5obj/peaky:', json.dumps({k: float(f'{v:.3g}') for k, v in report.items()}))
+
+
+def test_consistent_detection_clip_against_reference_golden(peaky_network, golden_dir):
+    """BASELINE configs[2]'s merge / purge / multi-bucket path on the HIP kernels: the reference's recorded
+    tracker-consistent detections replayed through incorporate_detection (17 frames, 4 segments each):
+    identical object table and bank sizes; soft outputs <= 1e-3 until the first merged hard mask that differs
+    at a forward-argmax near-tie (a different hard mask is a different memory frame from there on)"""
+    from deva.inference.inference_core import DEVAInferenceCore
+    from deva.inference.object_info import ObjectInfo
+    g, golden_dets = scenarios.load_consistent_golden(golden_dir)
+    sc = scenarios.CONSISTENT
+    outs, core, _ = scenarios.run_consistent_detection_scenario(lambda cfg: DEVAInferenceCore(peaky_network, cfg),
+                                                                ObjectInfo, sc, device=dev(), replay=golden_dets)
+    assert [p.shape[0] for p in outs] == g['nchan'].tolist()
+    assert scenarios.manager_state(core.object_manager) == json.loads(str(g['state']))
+    sizes = json.loads(str(g['sizes']))
+    mem = core.memory
+    assert {str(b): mem.work_mem.size(b) for b in mem.work_mem.buckets} == sizes['work']
+    assert {str(b): mem.long_mem.size(b) for b in mem.long_mem.buckets} == sizes['long']
+    diverged = None
+    for t, p in enumerate(outs):
+        ref = torch.from_numpy(g[f'prob_sub_{t}'])
+        if t % sc['every'] == 0:
+            differ = int((p[:, ::2, ::2].argmax(0) != ref.argmax(0)).sum())
+            print(f'frame {t} (detection): merged masks differ at {differ} of {ref[0].numel()} sampled pixels')
+            assert differ <= 2e-3 * ref[0].numel() or diverged is not None, t
+            if differ and diverged is None:
+                diverged = t
+        else:
+            err = (p[:, ::2, ::2] - ref).abs().max().item()
+            print(f'frame {t}: max-abs {err:.2e}' + ('' if diverged is None else f' (hard masks differ since frame {diverged})'))
+            assert err <= 1e-3 or diverged is not None, (t, err)
+            assert err <= 0.3, (t, err)
+    assert diverged is None or diverged >= 3
 
 
 def test_vos_example_against_reference_golden(network, golden_dir, recipe_state_dict):
@@ -192,7 +284,8 @@ def test_detection_clip_against_reference_golden(network, golden_dir):
     print('detections clip: max-abs prob err per frame', ['%.1e' % e for e in errs])
     assert max(errs) <= 1e-3
     for t, p in enumerate(outs):
-        assert _margin_aware_mismatch(p[:, ::2, ::2], torch.from_numpy(g[f'prob_sub_{t}']), errs[t]) == 0, t
+        # no floor run on this clip: argmax-identical at every pixel with a reference margin above the fixed 2 x 1e-3
+        assert _margin_aware_mismatch(p[:, ::2, ::2], torch.from_numpy(g[f'prob_sub_{t}'])) == 0, t
 
 
 @pytest.mark.parametrize('mode', ['queries', 'owner', 'bank'])

@@ -178,6 +178,76 @@ def test_detection_clip_matches_reference(emu, golden_dir, recipe_state_dict):
     assert worst <= 5e-3, worst
 
 
+def _check_consistent_clip(outs, core, g, tol):
+    assert [p.shape[0] for p in outs] == g['nchan'].tolist()
+    assert scenarios.manager_state(core.object_manager) == json.loads(str(g['state']))
+    sizes = json.loads(str(g['sizes']))
+    mem = core.memory
+    assert {str(b): mem.work_mem.size(b) for b in mem.work_mem.buckets} == sizes['work']
+    assert {str(b): mem.long_mem.size(b) for b in mem.long_mem.buckets} == sizes['long']
+    every = scenarios.CONSISTENT['every']
+    # detection frames return the +-16 logits of the merged HARD masks (inference_core.py:192): they are compared as
+    # masks; once a merged mask differs at a forward-argmax near-tie the memory frames differ and only the object
+    # table / bank sizes above remain comparable
+    diverged = None
+    for t, p in enumerate(outs):
+        ref = g[f'prob_sub_{t}']
+        if t % every == 0:
+            differ = float((p[:, ::2, ::2].numpy().argmax(0) != ref.argmax(0)).mean())
+            assert differ <= 2e-3 or diverged is not None, (t, differ)
+            if differ and diverged is None:
+                diverged = t
+        elif diverged is None:
+            assert np.abs(p[:, ::2, ::2].numpy() - ref).max() <= tol, t
+    assert diverged is None or diverged >= 3
+
+
+@pytest.mark.parametrize('mode', ['replay', 'record'])
+def test_consistent_detection_clip_matches_reference(emu, golden_dir, peaky_state_dict, mode):
+    """BASELINE configs[2]'s merge / purge / multi-bucket path (workload/detections.py, peaky recipe) against the
+    reference's own run: replaying the reference's detections through the public interface, and generating
+    them from this run's forward masks through the recording hook (they must come out identical)"""
+    from deva.inference.inference_core import DEVAInferenceCore
+    from deva.inference.object_info import ObjectInfo
+    from deva.model.network import DEVA
+    from workload import detections
+    net = DEVA(synth.base_config())
+    net.load_weights(peaky_state_dict)
+    g, golden_dets = scenarios.load_consistent_golden(golden_dir)
+    holder = {}
+
+    def make(cfg):
+        holder['core'] = DEVAInferenceCore(net, cfg)
+        return holder['core']
+
+    if mode == 'replay':
+        outs, core, _ = scenarios.run_consistent_detection_scenario(make, ObjectInfo, scenarios.CONSISTENT,
+                                                                    replay=golden_dets)
+    else:
+        outs, core, recorded = scenarios.run_consistent_detection_scenario(
+            make, ObjectInfo, scenarios.CONSISTENT,
+            record=lambda det, rec, frame_of: detections.record_on_package(holder['core'], det, ObjectInfo, rec, frame_of))
+        for t, (m, info) in recorded.items():
+            assert [i['id'] for i in info] == [i['id'] for i in golden_dets[t][1]], t
+            if t <= 6:
+                # the emulated ops differ from the reference in the last bits: a few boundary pixels may move (and
+                # once a merged hard mask differs, at frame 6, the forward masks the detector sees drift apart)
+                assert (m != golden_dets[t][0]).float().mean().item() <= 2e-3, t
+    _check_consistent_clip(outs, core, g, 1e-3)
+
+
+def test_e2e_peaky_matches_reference(emu, golden_dir, peaky_state_dict):
+    """with the peaky recipe the north-star bound holds as written on the emulated ops: 1e-3 max-abs"""
+    from deva.inference.inference_core import DEVAInferenceCore
+    from deva.model.network import DEVA
+    net = DEVA(synth.base_config())
+    net.load_weights(peaky_state_dict)
+    outs, core = scenarios.run_scenario(lambda cfg: DEVAInferenceCore(net, cfg), scenarios.E2E_PEAKY['peaky'])
+    g = np.load(os.path.join(golden_dir, 'e2e_peaky.npz'))
+    worst = max(np.abs(p[:, ::2, ::2].numpy() - g[f'prob_sub_{t}']).max() for t, p in enumerate(outs))
+    assert worst <= 1e-3, worst
+
+
 def test_spatial_alignment_matches_reference(emu, golden_dir, recipe_state_dict):
     """semi-online voting: the fused one-frame memory read behind
     `spatial_alignment` against the reference's output"""

@@ -112,3 +112,42 @@ def test_detection_restatement_against_reference_golden(golden_dir, recipe_state
     assert [r['isthing'] for r in core.table] == want['isthing']
     for t, p in enumerate(outs):
         assert np.abs(p[:, ::2, ::2].numpy() - g[f'prob_sub_{t}']).max() <= 1e-5, t
+
+
+def test_e2e_peaky_recipe(golden_dir, peaky_state_dict):
+    """the oracle is pinned on the second weight recipe as well (the reference's own outputs)"""
+    sc = scenarios.E2E_PEAKY['peaky']
+    outs, core = scenarios.run_scenario(lambda cfg: O.OracleCore(peaky_state_dict, cfg), sc)
+    g = np.load(os.path.join(golden_dir, 'e2e_peaky.npz'))
+    assert [p.shape[0] for p in outs] == g['nchan'].tolist()
+    for t, p in enumerate(outs):
+        assert np.abs(p[:, ::2, ::2].numpy() - g[f'prob_sub_{t}']).max() <= 1e-4, t
+        assert (p.argmax(0).numpy() != g['argmax'][t]).mean() < 1e-4
+
+
+def test_consistent_detection_clip_against_reference_golden(golden_dir, peaky_state_dict):
+    """tracker-consistent detections (workload/detections.py): the oracle GENERATES the clip from its own
+    forward masks through the merge hook and must arrive at the detections, outputs, object table and bank
+    sizes the reference arrived at (matches, new buckets, purges, consolidation of several buckets)"""
+    from workload import detections
+    sc = scenarios.CONSISTENT
+    pad = O.pad_to_multiple(torch.zeros(1, sc['H'], sc['W']))[1]
+    outs, core, recorded = scenarios.run_consistent_detection_scenario(
+        lambda cfg: O.OracleDetectionCore(peaky_state_dict, cfg), lambda **kw: dict(kw), sc,
+        record=lambda det, rec, frame_of: detections.record_on_oracle(O, det, rec, frame_of, lambda: pad))
+    g, golden_dets = scenarios.load_consistent_golden(golden_dir)
+    assert sorted(recorded) == sorted(golden_dets)
+    for t, (m, info) in recorded.items():
+        assert info == golden_dets[t][1], t
+        assert torch.equal(m, golden_dets[t][0]), t
+    assert [p.shape[0] for p in outs] == g['nchan'].tolist()
+    want = json.loads(str(g['state']))
+    assert [r['id'] for r in core.table] == want['ids']
+    assert [r['poke'] for r in core.table] == want['poke']
+    assert [r['cats'] for r in core.table] == want['cats']
+    assert [r['isthing'] for r in core.table] == want['isthing']
+    sizes = json.loads(str(g['sizes']))
+    assert {str(b): core.memory.work.size(b) for b in core.memory.work.buckets} == sizes['work']
+    assert {str(b): core.memory.long.size(b) for b in core.memory.long.buckets} == sizes['long']
+    for t, p in enumerate(outs):
+        assert np.abs(p[:, ::2, ::2].numpy() - g[f'prob_sub_{t}']).max() <= 1e-4, t

@@ -100,3 +100,4 @@ def detection_frame(height: int, width: int, t: int, segments: int = 1):
         m[y0:y0 + bh, x0:x0 + bw] = 10 * (s + 1)
         info.append(dict(id=10 * (s + 1), category_id=s + 1, isthing=(s % 2 == 0)))
     return m, info
+
