@@ -35,6 +35,11 @@ Extra objects on the JSON line:
                 the north-star target line) and 4K / 50k-token bank (configs[4] on this one GPU).  Each
                 names the -m gpu test that gates its parity.
 
+`--gpus N` without a torchrun environment re-executes this script under `python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one rank per GPU, RCCL); the line then carries
+`rccl_ranks: N` and, in `also_multi_gpu`, the one-clip-on-N-GPUs line of BASELINE configs[4] (frame-owner mode) with
+the bytes rank 0 moved per frame.  No scaling curve has been measured by the builder (one GPU per box).
+
 `--workload long4k` runs BASELINE configs[4] instead: ONE 2160x3840 clip with a 50 000-token
 long-term bank on N GPUs, `--long4k_mode`:
   owner    (default) rank 0 alone encodes / decodes; it broadcasts the query key / selection, every rank
@@ -278,15 +283,15 @@ def whole_job_fps(steps_per_rank: int, world: int, elapsed: float) -> float:
     return world * steps_per_rank / elapsed
 
 
-def run_long4k(net, device, steps, warmup, seed, shard, dist):
+def run_long4k(net, device, steps, warmup, seed, shard, dist, size=(2160, 3840), bank_tokens=50000):
     """BASELINE configs[4]: one 4K clip, 1 object, 50 000-token long-term bank.  shard = None (one GPU) |
     'owner' | 'queries' | 'bank' (MemoryManager modes, all ranks of the group step the same clip).
     -> (FPS, bank sizes at the end, collective bytes this rank moved per timed frame)"""
     from workload import synth
-    cfg = synth.base_config(max_long_term_elements=50000)
+    cfg = synth.base_config(max_long_term_elements=bank_tokens)
     n_frames = 1 + warmup + steps
-    frames = make_clip(2160, 3840, n_frames, seed=seed, device=device)
-    core = start_clip(net, cfg, frames, 1, device, lt_prefill=50000 - cfg['num_prototypes'], shard=shard)
+    frames = make_clip(size[0], size[1], n_frames, seed=seed, device=device)
+    core = start_clip(net, cfg, frames, 1, device, lt_prefill=bank_tokens - cfg['num_prototypes'], shard=shard)
     for t in range(1, 1 + warmup):
         core.step(frames[t])
     comm0 = core.memory.comm_bytes
@@ -349,6 +354,82 @@ def run_1080p(net, device, steps, warmup, detections, seed=7):
     return steps / elapsed, state
 
 
+def run_1080p_segments(net, device, steps, warmup, segments=8, seed=7, size=(1080, 1920)):
+    """BASELINE configs[2] as SURVEY.md 8d defines it: 1920x1080, a precomputed detection with `segments` segments
+    merged every 5th frame through incorporate_detection (online setting of evaluation/eval_with_detections.py:
+    280-297, --max_missed_detection_count 1, no object cap), long-term memory pre-filled to 10 000 tokens.
+    The detections are tracker-consistent (workload/detections.py): most segments re-detect tracked objects
+    (IoU 0.875 -> matched and merged), two per detection are new (-> new objects in a new memory bucket) and
+    objects that go unseen twice are purged with their memories.  They are a function of the tracker's own
+    forward masks, so the clip is DEFINED by an untimed recording pass (hook around match_and_merge) and then
+    replayed through the public interface in the timed pass; the kernels are deterministic, so the replay
+    reproduces the recording pass (asserted on the final object table)."""
+    from workload import detections, synth
+    from deva.inference.inference_core import DEVAInferenceCore
+    from deva.inference.object_info import ObjectInfo
+    (H, W), every = size, 5
+    cfg = synth.base_config(max_missed_detection_count=1, max_num_objects=-1)
+    n_frames = 1 + warmup + steps
+    frames = make_clip(H, W, n_frames, seed=seed, device=device)
+    empty = torch.zeros(H, W, dtype=torch.long, device=device)
+
+    def prefill(core):
+        key, shr, vals = synth.prefill_bank(10000, core.object_manager.all_obj_ids, seed=1)
+        core.memory.long_mem.add(key.to(device), {o: v.to(device) for o, v in vals.items()}, shr.to(device),
+                                 selection=None, supposed_bucket_id=0)
+
+    def table(core):
+        return [(int(o.id), int(o.poke_count)) for o in core.object_manager.obj_to_tmp_id]
+
+    # pass 1 (untimed): the clip is generated
+    rec_core = DEVAInferenceCore(net, cfg)
+    detector = detections.ConsistentDetector(H, W, segments=segments, new_per_frame=2)
+    recorded, now = {}, [0]
+    for t in range(n_frames):
+        now[0] = t
+        if t % every == 0:
+            with detections.record_on_package(rec_core, detector, ObjectInfo, recorded, lambda: now[0]):
+                rec_core.incorporate_detection(frames[t], empty, [])
+        else:
+            rec_core.step(frames[t])
+        if t == 0:
+            prefill(rec_core)
+    want = table(rec_core)
+    del rec_core
+    dets = {t: (m.to(device), info) for t, (m, info) in recorded.items()}
+
+    # pass 2 (timed): replay through the public interface
+    core = DEVAInferenceCore(net, cfg)
+    live = []
+
+    def run(t):
+        if t in dets:
+            m, info = dets[t]
+            core.incorporate_detection(frames[t], m, [ObjectInfo(**i) for i in info])
+        else:
+            core.step(frames[t])
+        live.append(core.object_manager.num_obj)
+
+    run(0)
+    prefill(core)
+    for t in range(1, 1 + warmup):
+        run(t)
+    elapsed = timed_region(lambda: [run(t) for t in range(1 + warmup, n_frames)], None, device)
+    assert table(core) == want, ('the timed replay did not reproduce the recording pass', table(core), want)
+    mem = core.memory
+    timed_live = live[1 + warmup:]
+    state = {'long': {b: mem.long_mem.size(b) for b in mem.long_mem.buckets},
+             'work': {b: mem.work_mem.size(b) for b in mem.work_mem.buckets},
+             'objects': core.object_manager.num_obj,
+             'objects_per_timed_frame': {'min': min(timed_live), 'mean': sum(timed_live) / len(timed_live),
+                                         'max': max(timed_live)},
+             'detections_in_timed_region': sum(1 for t in dets if t > warmup),
+             'segments_per_detection': segments,
+             'matched_segments': sum(1 for t, (_, info) in dets.items() if t > warmup for i in info if i['id'] > 100000),
+             'object_table_at_end(id, missed detections)': table(core)}
+    return steps / elapsed, state
+
+
 def long4k(args, net, rank, world, device, dist):
     """`--workload long4k`: strong scaling of ONE clip over the GPUs of the node"""
     mode = args.long4k_mode if dist is not None else None
@@ -388,15 +469,39 @@ def main():
     args = ap.parse_args()
 
     torch.set_grad_enabled(False)
+    emulated = os.environ.get('DEVA_BENCH_EMULATED') == '1'  # tests/test_replicas_gloo.py only: launch path on CPU/gloo
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` (the driver's form without torchrun): become N ranks, one per GPU
+        if not emulated and torch.cuda.device_count() < args.gpus:
+            sys.exit(f'bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible')
+        import socket
+        with socket.socket() as sock:
+            sock.bind(('127.0.0.1', 0))
+            port = sock.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+                                  f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1', '--master-port', str(port),
+                                  os.path.abspath(__file__), *sys.argv[1:]])
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    assert world == args.gpus, f'--gpus {args.gpus} but the launcher started {world} rank(s)'
     distributed = world > 1
-    device = torch.device(f'cuda:{local_rank}')
-    torch.cuda.set_device(device)
+    if emulated:
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        import emu_ops
+
+        class _Set:
+            setattr = staticmethod(setattr)
+        emu_ops.install(_Set)
+        device = torch.device('cpu')
+        torch.cuda.synchronize = lambda *a, **k: None
+    else:
+        device = torch.device(f'cuda:{local_rank}')
+        torch.cuda.set_device(device)
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group(backend='nccl')  # RCCL on ROCm
+        dist.init_process_group(backend='gloo' if emulated else 'nccl')  # "nccl" IS RCCL on ROCm
+        assert dist.get_world_size() == args.gpus
 
     from workload import synth
     net, sd = build_network(device)
@@ -437,9 +542,23 @@ def main():
             'bank_tokens_at_end': bank,
             'parallelism': f'replicas x{world}',
         },
+        'rccl_ranks': world if distributed else 0,
     }
+    if distributed and not args.no_extra:
+        # BASELINE configs[4]: ONE 4K clip on all ranks, frame-owner mode; every rank takes part
+        steps4k = max(2, min(20, args.steps))
+        tiny = dict(size=(96, 128), bank_tokens=600) if emulated else {}  # (the CPU test of this launch path)
+        fps_own, bank_own, comm_own = run_long4k(net, device, steps=steps4k, warmup=min(5, args.warmup), seed=11,
+                                                 shard='owner', dist=dist, **tiny)
+        result['also_multi_gpu'] = [
+            {'metric': f'propagation FPS @4K (1 object, 50k-token long-term bank), ONE clip on {world} GPUs',
+             'value': fps_own, 'unit': 'frames/s', 'steps': steps4k, 'ms_per_step': 1e3 / fps_own, 'scaling': 'strong',
+             'config': {'workload': 'BASELINE configs[4]: frame owner (rank 0 encodes / decodes) + query-sharded read',
+                        'bank_tokens_at_end': bank_own, 'collective_bytes_per_frame_rank0': comm_own}}]
 
-    if rank == 0:
+    if rank == 0 and emulated:
+        print(json.dumps(result))
+    elif rank == 0:
         # ---- roofline of the dominant kernel: event-timed replay of as many frames, continuing the same clip
         # (un-synchronised events, see ConvTimer); warm the replay with two frames first
         replay = make_clip(args.height, args.width, args.steps + 2, seed=999, device=device)
@@ -493,6 +612,7 @@ def main():
             del core
             fps1080, state1080 = run_1080p(net, device, steps=25, warmup=6, detections=False)
             fps1080d, state1080d = run_1080p(net, device, steps=25, warmup=6, detections=True)
+            fps1080s, state1080s = run_1080p_segments(net, device, steps=25, warmup=6, segments=8)
             fps4k, bank4k, _ = run_long4k(net, device, steps=20, warmup=5, seed=11, shard=None, dist=None)
             gate1080 = 'tests/test_gpu_g_fullsize.py::test_1080p_detections_10k_bank_against_oracle'
             result['also'] = [
@@ -504,10 +624,21 @@ def main():
                  'target_fps': 30.0, 'parity_gate': gate1080},
                 {'metric': 'propagation FPS @1080p (detections merged every 5th frame, 1 object, 10k-token long-term bank)',
                  'value': fps1080d, 'unit': 'frames/s', 'steps': 25, 'warmup': 6, 'ms_per_step': 1e3 / fps1080d,
-                 'config': {'workload': 'BASELINE configs[2]: the same clip with the precomputed detection merged through '
-                                        'incorporate_detection every 5th frame (online setting, --max_num_objects 1)',
+                 'config': {'workload': 'the same clip with a fixed-box detection handed to incorporate_detection every 5th frame under '
+                                        '--max_num_objects 1: the detection is DISCARDED (segment_merging.py:115-122), so this line times '
+                                        'the forward pass + argmax + histogram of a detection frame, not a merge -- the 8-segment line '
+                                        'below is BASELINE configs[2]',
                             'state_at_end': state1080d},
                  'target_fps': 30.0, 'parity_gate': gate1080},
+                {'metric': 'propagation FPS @1080p (8-segment detections merged every 5th frame, ~10 live objects, '
+                           '10k-token long-term bank)',
+                 'value': fps1080s, 'unit': 'frames/s', 'steps': 25, 'warmup': 6, 'ms_per_step': 1e3 / fps1080s,
+                 'config': {'workload': 'BASELINE configs[2] as SURVEY.md 8d defines it: tracker-consistent detections with 8 '
+                                        'segments (re-detections that match and merge, 2 new objects per detection in a new '
+                                        'bucket, objects unseen twice purged), online setting, no object cap',
+                            'state_at_end': state1080s},
+                 'parity_gate': 'tests/test_gpu_g_fullsize.py::test_1080p_eight_segment_detections_against_oracle (3 segments '
+                                'at 1080p) + tests/test_gpu_e_network.py::test_consistent_detection_clip_against_reference_golden'},
                 {'metric': 'propagation FPS @4K (1 object, 50k-token long-term bank), one GPU',
                  'value': fps4k, 'unit': 'frames/s', 'steps': 20, 'warmup': 5, 'ms_per_step': 1e3 / fps4k,
                  'config': {'workload': 'BASELINE configs[4] on ONE GPU: synthetic 3840x2160 clip, 1 object, long-term '

@@ -47,6 +47,11 @@ def get_model_and_config(parser: ArgumentParser) -> Tuple['torch.nn.Module', Dic
     """-> (network on the current HIP device in eval mode, config dict, parsed args)"""
     from deva.model.network import DEVA
     args = parser.parse_args()
+    if args.amp:
+        import warnings
+        # the reference's --amp wraps the frame loop in fp16 autocast (evaluation/eval_vos.py:137); this path has one
+        # arithmetic, fp32, which is also the parity target -- say so once instead of silently ignoring the flag
+        warnings.warn('--amp is accepted for compatibility and ignored: the HIP path computes in fp32', UserWarning)
     config = dict(vars(args), enable_long_term=not args.disable_long_term)
     network = DEVA(config).cuda().eval()
     if args.model is None:

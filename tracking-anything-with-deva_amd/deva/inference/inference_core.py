@@ -123,6 +123,10 @@ class DEVAInferenceCore:
         propagate (unless the caller did), match detected segments with tracked objects by IoU, retire
         objects that went unseen for too long, and commit the merged masks as a memory frame"""
         from deva.inference.segment_merging import match_and_merge
+        if self.memory._shard_group is not None and self.memory._shard_owner is not None:
+            # frame-owner mode routes `step` only: non-owner ranks hold no encoder / decoder state to merge into
+            raise NotImplementedError('incorporate_detection is not available in frame-owner mode '
+                                      '(MemoryManager.shard_queries(owner=r)); use shard_queries() or shard_bank()')
         frame_ti, batch, ms_features, key, shrinkage, selection = self._begin_frame(image, image_ti_override)
         new_mask, _ = pad_divide_by(new_mask, 16)
 

@@ -115,7 +115,8 @@ class MemoryManager:
         owner=r   : frame-owner mode -- rank r alone runs the encoder / decoder; `DEVAInferenceCore.step`
                     broadcasts the query key / selection from it, the read-out columns are gathered to it
                     only, and on memory frames it broadcasts the new key / shrinkage / selection / value
-                    rows to the other ranks' banks."""
+                    rows to the other ranks' banks.  Only `step` is routed in this mode
+                    (`incorporate_detection` raises NotImplementedError)."""
         import torch.distributed as dist
         if not dist.is_initialized():
             raise RuntimeError('shard_queries: torch.distributed is not initialised')
@@ -137,6 +138,9 @@ class MemoryManager:
         if not dist.is_initialized():
             raise RuntimeError('shard_bank: torch.distributed is not initialised')
         self._shard_group = group if group is not None else dist.group.WORLD
+        if dist.get_world_size(self._shard_group) > 32:
+            # deva_affinity_merge takes at most 32 candidate lists (MAX_SPLITS, include/deva_hip.h)
+            raise ValueError('shard_bank: at most 32 ranks per group (one candidate list per rank is merged)')
         self._shard_mode = 'bank'
         self._shard_owner = None
         self.comm_bytes = 0
@@ -283,7 +287,7 @@ class MemoryManager:
         with_long, n_long, n_work = self._bucket_extent(bucket_id)
         n = n_long + n_work
         rank, world, per, lo = self._shard_range(n)
-        if n < 128 * world:  # first frames of a clip: a shard could hold fewer than top_k tokens
+        if n < max(128, self.top_k + world) * world:  # first frames of a clip: every shard must hold >= top_k tokens
             return self._read_bucket(bucket_id, bucket, qk, qe, rows)
         hi = min(n, lo + per)
         hw = qk.shape[1]
