@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DEVA_HIP_ABI_VERSION 2
+#define DEVA_HIP_ABI_VERSION 3
 
 int deva_hip_version(void);
 const char* deva_hip_last_error(void);
@@ -201,6 +201,31 @@ int deva_affinity_force_shape(int shape);
 int64_t deva_affinity_workspace(int hw, int k, int splits);
 /* splits the library would pick for a bank/query size (>= 1) */
 int deva_affinity_default_splits(int n_total, int hw);
+
+/* The whole read in one call, with the fp16 pre-filter where it pays (banks of >= 2 048 tokens):
+ *   every (token, query) score is first bounded from both sides with v_mfma_f32_32x32x16_f16 on fp16 copies of the
+ *   operands (1/16 of the fp32 matrix time) under a rigorous error bound, a filter threshold is derived from group
+ *   maxima of the lower bounds, and only the tokens whose upper bound reaches it (~k + 5 per query) are re-scored with
+ *   the natural-order fp32 FMA chain of deva_affinity_topk and selected exactly -- indices, weights, usage counters and
+ *   shard keys are bit-identical to deva_affinity_topk + deva_affinity_finalize / deva_affinity_select.  Inputs the
+ *   bound does not cover (negative selection, non-finite operands, flat "near-tie" banks that overflow the candidate
+ *   lists) raise a device-side flag and the fp32 kernels produce the result in the same stream.
+ * Output: either idx + weight [hw][k] (+ usage_fix), or out_keys [hw][64] + out_counts [hw] (the shard format of
+ *   deva_affinity_select, token indices shifted by token_offset).  scratch: deva_affinity_read_scratch(...) uint64
+ *   elements, private to the stream until the call's kernels have run.
+ * deva_affinity_force_prefilter(0) routes every read to the fp32 kernels (A/B measurements, tests), 1 = automatic
+ *   (default; the environment variable DEVA_AFFINITY_PREFILTER=0 sets the initial value to 0).
+ * deva_affinity_read_flag: test hook -- copies the fall-back flag of the last read on `scratch` to the host
+ *   (synchronises the stream): 0 = the pre-filter produced the result. */
+int deva_affinity_read(const float* key_long, const float* shr_long, int n_long,
+                       const float* key_work, const float* shr_work, int n_work,
+                       const float* qk, const float* qe, int hw, int k, uint64_t* scratch,
+                       int32_t* idx, float* weight, uint64_t* usage_fix,
+                       uint64_t* out_keys, uint32_t* out_counts, int64_t token_offset, void* stream);
+int64_t deva_affinity_read_scratch(int n_total, int hw, int k);
+int deva_affinity_prefilter_enabled(int n_total, int hw, int k);
+int deva_affinity_force_prefilter(int mode);
+int deva_affinity_read_flag(const uint64_t* scratch, void* stream);
 
 /* KeyValueMemoryStore.update_bucket_usage (kv_memory_store.py:118-125) for one segment:
  * use[i] += usage_fix[offset+i] * 2^-40 (if use != NULL), life[i] += 1 (if life != NULL), and

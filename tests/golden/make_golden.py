@@ -136,6 +136,9 @@ def gen_peaky():
                             argmax=np.stack([p.argmax(0).numpy().astype(np.uint8) for p in outs]),
                             nchan=np.array([p.shape[0] for p in outs]), sizes=json.dumps(sizes))
         print(name, 'frames', len(outs), 'sizes', sizes)
+    # the detection clip runs on the DEFAULT recipe: it consolidates (usage-ranked prototypes), and with the peaky
+    # recipe most usage counters underflow to exactly 0 -- ties that torch.topk breaks in an unspecified order
+    net, _, _ = build_reference(synth.base_config())
     sc = scenarios.CONSISTENT
     holder = {}
 

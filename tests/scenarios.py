@@ -116,7 +116,8 @@ E2E_PEAKY: Dict[str, Dict] = {
 
 # tracker-consistent detections (workload/detections.py): re-detections that match (IoU 0.875), new
 # segments that spawn objects in new buckets, objects that go unseen and are purged -- BASELINE
-# configs[2]'s merge / purge / multi-object memory path.  Peaky recipe.
+# configs[2]'s merge / purge / multi-object memory path.  Default recipe (it consolidates: with the peaky recipe most
+# usage counters underflow to exactly 0, ties that torch.topk ranks in an unspecified order).
 CONSISTENT = dict(H=96, W=128, frames=17, every=3, segments=4, new_per_frame=1,
                   cfg=dict(mem_every=2, max_missed_detection_count=1, max_num_objects=-1, max_mid_term_frames=6,
                            min_mid_term_frames=3, num_prototypes=32, max_long_term_elements=300))

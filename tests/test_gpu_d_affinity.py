@@ -109,6 +109,78 @@ def test_larger_shapes_against_cpu(n, hw, scale, k):
                 'result depends on the split count'
 
 
+def _both_paths(mk, ms, qk, qe, k, n_long=0):
+    """the same read through the fp32 kernels (pre-filter off) and through the automatic choice"""
+    from deva.hip import lib
+    if os.environ.get('DEVA_TEST_DRYRUN') == '1':
+        pytest.skip('kernel-path property: nothing to compare on the emulated ops')
+    out = []
+    try:
+        for mode in (0, 1):
+            lib().deva_affinity_force_prefilter(mode)
+            out.append(_run(mk, ms, qk, qe, k, n_long))
+        flag = ops.affinity_last_read_flag(dev())
+    finally:
+        lib().deva_affinity_force_prefilter(1)
+    return out[0], out[1], flag
+
+
+def _assert_identical(tag, a, b):
+    (i0, w0, u0), (i1, w1, u1) = a, b
+    assert torch.equal(i0, i1), f'{tag}: {int((i0 != i1).any(1).sum())} queries select different tokens'
+    assert torch.equal(w0.view(torch.int32), w1.view(torch.int32)), f'{tag}: weights differ'
+    assert torch.equal(u0.view(torch.int32), u1.view(torch.int32)), f'{tag}: usage counters differ'
+
+
+@pytest.mark.parametrize('n,hw,scale,k,n_long', [(2048, 100, 1.0, 30, 0), (5000, 1620, 2.0, 30, 1200), (10001, 513, 1.0, 30, 7),
+                                                 (40000, 257, 0.3, 30, 39999), (3000, 33, 30.0, 30, 0),
+                                                 (8200, 1, 1.0, 5, 100), (4096, 128, 0.01, 32, 0)])
+def test_fp16_prefilter_is_bit_identical_to_the_fp32_kernels(n, hw, scale, k, n_long):
+    """deva_affinity_read: fp16 MFMA bounds -> group-maxima threshold -> candidates -> exact fp32 re-scoring must
+    reproduce the fp32 kernels bit for bit (indices, order, weights, usage) WITHOUT falling back, on ragged sizes,
+    a long + working bank, large / tiny key magnitudes (the operand scales are data-dependent powers of two)"""
+    mk, ms, qk, qe = synth.affinity_inputs(n, hw, seed=n + hw, key_scale=scale)
+    fp32, pre, flag = _both_paths(mk, ms, qk, qe, k, n_long)
+    _assert_identical(f'n{n}hw{hw}', fp32, pre)
+    assert flag == 0, f'the pre-filter fell back (flag {flag})'
+
+
+def test_fp16_prefilter_falls_back_where_its_bound_does_not_hold():
+    """inputs outside the bound's premises must raise the device flag and still give the fp32 kernels' result:
+    a negative selection value (the Cauchy-Schwarz step needs qe >= 0), a non-finite key, and a flat bank (every
+    token identical: every score is a candidate, the sub-lists overflow)"""
+    n, hw, k = 4096, 96, 30
+    mk, ms, qk, qe = synth.affinity_inputs(n, hw, seed=5)
+    qe_neg = qe.clone()
+    qe_neg[3, 17] = -0.25
+    fp32, pre, flag = _both_paths(mk, ms, qk, qe_neg, k)
+    _assert_identical('negative selection', fp32, pre)
+    assert flag & 2, flag
+    mk_inf = mk.clone()
+    mk_inf[5, 1000] = float('inf')
+    fp32, pre, flag = _both_paths(mk_inf, ms, qk, qe, k)
+    assert flag & 1, flag
+    assert torch.equal(fp32[0], pre[0])
+    flat = mk[:, :1].repeat(1, n).contiguous()
+    fp32, pre, flag = _both_paths(flat, torch.ones_like(ms), qk, qe, k)
+    _assert_identical('flat bank', fp32, pre)
+    assert flag & 12, flag
+
+
+def test_fp16_prefilter_shard_keys_equal_the_fp32_select():
+    """the hand-over format of a bank shard (affinity_candidates) through both paths"""
+    if os.environ.get('DEVA_TEST_DRYRUN') == '1':
+        pytest.skip('kernel-path property: nothing to compare on the emulated ops')
+    n, hw, k = 6000, 200, 30
+    mk, ms, qk, qe = synth.affinity_inputs(n, hw, seed=9)
+    rows, shr = to_dev(mk.t().contiguous()), to_dev(ms.reshape(-1).contiguous())
+    new = ops.affinity_candidates(None, None, 0, rows, shr, n, to_dev(qk), to_dev(qe), k, token_offset=12345)
+    assert ops.affinity_last_read_flag(dev()) == 0  # (before the fp32 call below reuses the scratch buffer)
+    old = ops.affinity_candidates(None, None, 0, rows, shr, n, to_dev(qk), to_dev(qe), k, token_offset=12345, splits=4)
+    torch.cuda.synchronize()
+    assert torch.equal(new[1], old[1]) and torch.equal(new[0][:, :k], old[0][:, :k])
+
+
 @pytest.mark.parametrize('shape', [1, 2, 3, 4, 5, 6, 7, 8])
 def test_every_kernel_shape_gives_the_same_result(shape):
     """the kernel shapes of deva_affinity_topk (per-wave / workgroup-shared lists, one / two workgroups per CU,

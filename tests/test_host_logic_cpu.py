@@ -203,16 +203,14 @@ def _check_consistent_clip(outs, core, g, tol):
 
 
 @pytest.mark.parametrize('mode', ['replay', 'record'])
-def test_consistent_detection_clip_matches_reference(emu, golden_dir, peaky_state_dict, mode):
-    """BASELINE configs[2]'s merge / purge / multi-bucket path (workload/detections.py, peaky recipe) against the
+def test_consistent_detection_clip_matches_reference(emu, golden_dir, recipe_state_dict, mode):
+    """BASELINE configs[2]'s merge / purge / multi-bucket path (workload/detections.py) against the
     reference's own run: replaying the reference's detections through the public interface, and generating
     them from this run's forward masks through the recording hook (they must come out identical)"""
     from deva.inference.inference_core import DEVAInferenceCore
     from deva.inference.object_info import ObjectInfo
-    from deva.model.network import DEVA
     from workload import detections
-    net = DEVA(synth.base_config())
-    net.load_weights(peaky_state_dict)
+    net = _network(recipe_state_dict)
     g, golden_dets = scenarios.load_consistent_golden(golden_dir)
     holder = {}
 

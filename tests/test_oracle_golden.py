@@ -125,7 +125,7 @@ def test_e2e_peaky_recipe(golden_dir, peaky_state_dict):
         assert (p.argmax(0).numpy() != g['argmax'][t]).mean() < 1e-4
 
 
-def test_consistent_detection_clip_against_reference_golden(golden_dir, peaky_state_dict):
+def test_consistent_detection_clip_against_reference_golden(golden_dir, recipe_state_dict):
     """tracker-consistent detections (workload/detections.py): the oracle GENERATES the clip from its own
     forward masks through the merge hook and must arrive at the detections, outputs, object table and bank
     sizes the reference arrived at (matches, new buckets, purges, consolidation of several buckets)"""
@@ -133,7 +133,7 @@ def test_consistent_detection_clip_against_reference_golden(golden_dir, peaky_st
     sc = scenarios.CONSISTENT
     pad = O.pad_to_multiple(torch.zeros(1, sc['H'], sc['W']))[1]
     outs, core, recorded = scenarios.run_consistent_detection_scenario(
-        lambda cfg: O.OracleDetectionCore(peaky_state_dict, cfg), lambda **kw: dict(kw), sc,
+        lambda cfg: O.OracleDetectionCore(recipe_state_dict[0], cfg), lambda **kw: dict(kw), sc,
         record=lambda det, rec, frame_of: detections.record_on_oracle(O, det, rec, frame_of, lambda: pad))
     g, golden_dets = scenarios.load_consistent_golden(golden_dir)
     assert sorted(recorded) == sorted(golden_dets)

@@ -22,6 +22,10 @@ if has alltests; then
   for f in test_gpu_a_conv test_gpu_b_pointwise test_gpu_c_bank test_gpu_d_affinity test_gpu_f_memory_events test_gpu_e_network test_gpu_g_fullsize; do run_test $f ${TEST_TIMEOUT:-900}; done
 fi
 if has custom; then eval "$CUSTOM_CMD"; fi
+if has readcheck; then
+  SHAPES=${READ_SHAPES:-} ITERS=10 timeout -k 10 300 python tools/affinity_read_check.py > gpurun_out/affinity_read_check.txt 2>&1
+  cat gpurun_out/affinity_read_check.txt
+fi
 if has affinity; then
   SHAPES=${AFF_SHAPES:-1620x1620,8100x1620,10000x1620,24580x1620,10000x8160,83440x8160,50000x32400} ITERS=10 \
     timeout -k 10 200 python tools/affinity_microbench.py > gpurun_out/affinity_micro.txt 2>&1
@@ -34,4 +38,14 @@ fi
 if has prof; then
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o ${PROF_TAG:-r03} -- python bench.py --steps 20 --warmup 3 --no_cpu_baseline > gpurun_out/prof.log 2>&1; echo "prof exit $?"
   ls -R gpurun_out/prof | head -20
+fi
+if has readprof; then
+  SHAPES=${READ_SHAPES:-10000x8160} ITERS=10 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/readprof -o read -- python tools/affinity_read_check.py > gpurun_out/readprof.log 2>&1
+  python - <<'PY'
+import csv, glob
+for f in glob.glob('gpurun_out/readprof/**/read_kernel_stats.csv', recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    for r in rows[:14]:
+        print(f"{r['Name'][:70]:70s} calls {r['Calls']:>5s} avg {float(r['AverageNs'])/1e3:9.1f} us total {float(r['TotalDurationNs'])/1e6:8.2f} ms")
+PY
 fi

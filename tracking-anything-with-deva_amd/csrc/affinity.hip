@@ -271,6 +271,7 @@ struct AffArgs {
   int ablate;          // timing probes, builds with -DDEVA_AFFINITY_PROBES only (0 otherwise): 1 = file nothing,
                        // 2 = no key loads in the loop, 4 = no scoring, 8 = no MFMAs; results are meaningless when non-zero
   uint64_t* probe;     // probe builds: cycle stamps of the first workgroups' phases (tools/probe/affinity_phases.py)
+  const uint32_t* guard;  // != NULL: run only if *guard != 0 (the fp32 path as the fall-back of the fp16 pre-filter)
 };
 
 #ifdef DEVA_AFFINITY_PROBES
@@ -304,6 +305,7 @@ constexpr int TROW = 36;
 // cycles.  One s_barrier per tile (double-buffered tile).
 template <int LCAP, int MINB, bool SHARED, bool LATE = false>
 __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const AffArgs p) {
+  if (p.guard && *p.guard == 0u) return;  // uniform over the grid
   constexpr int LSTRIDE = LCAP + 1;
   constexpr int E = (LCAP + 63) / 64;  // list entries per lane in a prune
   static_assert(LCAP - TOKT >= 64, "a list is pruned only when every lane holds an entry");
@@ -618,6 +620,7 @@ __global__ __launch_bounds__(WAVES * 64, MINB) void affinity_topk_kernel(const A
 // (at most 4 x 32 appends per query per tile).
 template <int LCAP, int MINB, int NW>
 __global__ __launch_bounds__(NW * 64, MINB) void affinity_topk_wg_kernel(const AffArgs p) {
+  if (p.guard && *p.guard == 0u) return;  // uniform over the grid
   constexpr int LSTRIDE = LCAP + 1;
   constexpr int E = (LCAP + 63) / 64;          // list entries per lane in a prune
   constexpr int BURST = NW * TOKT;          // appends per query between two maintenance points
@@ -890,6 +893,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void affinity_topk_wg_kernel(const A
 constexpr int PP_WAVES = 8;
 template <int LCAP>
 __global__ __launch_bounds__(PP_WAVES * 64, 1) void affinity_topk_pp_kernel(const AffArgs p) {
+  if (p.guard && *p.guard == 0u) return;
   constexpr int LSTRIDE = LCAP + 1;
   constexpr int E = (LCAP + 63) / 64;
   constexpr int GW = PP_WAVES / 2;             // waves per group
@@ -1111,7 +1115,9 @@ __global__ __launch_bounds__(256) void affinity_finalize_kernel(const uint64_t* 
                                                                 float* __restrict__ weight,
                                                                 unsigned long long* __restrict__ usage_fix,
                                                                 uint64_t* __restrict__ out_keys,
-                                                                uint32_t* __restrict__ out_cnt, uint32_t token_offset) {
+                                                                uint32_t* __restrict__ out_cnt, uint32_t token_offset,
+                                                                const uint32_t* __restrict__ guard) {
+  if (guard && *guard == 0u) return;  // fall-back of the fp16 pre-filter: nothing to do
   __shared__ uint64_t s_buf[4][2][64];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -1240,6 +1246,555 @@ __global__ __launch_bounds__(256) void readout_sparse_kernel(const int32_t* __re
   }
 }
 
+// ===================================================================================================
+// fp16 pre-filter with exact fp32 re-scoring (VERDICT r2 "next" 3b).
+//
+// The fused fp32 kernels above are bound by the fp32 matrix rate (1/16 of the f16 rate on gfx950) plus
+// the VALU / LDS work of keeping exact candidate lists.  This path scores every (token, query) pair with
+// v_mfma_f32_32x32x16_f16 on fp16 copies of the operands, carries a RIGOROUS error bound per score, and
+// re-scores only the ~k+5 tokens per query that the bound cannot exclude with the natural-order fp32 FMA
+// chain (bit-identical to v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md) -- selections, weights and usage
+// counters are bit-identical to the fp32 kernels by construction, not by tolerance.
+//
+//   sim(n, q) = -m_n * (A - 2B + bsq),  m_n = ms_n / 8,  A = sum mk^2 qe,  B = sum mk qk qe,  bsq = sum qk^2 qe
+//   P = m (A + bsq) >= 0 (needs qe >= 0: checked, else fall-back), Q = 2 m B, sim = Q - P.
+//   Cauchy-Schwarz + AM-GM: sum_c |2 m mk qk qe| <= 2 m sqrt(A bsq) <= m (A + bsq) = P, so with d the relative
+//   error of a product of two fp16-rounded operands (2^-10, + fp32 accumulation; d = 1.3e-3 is used) both
+//   chains are off by at most d * P_true (+ an absolute term for operands below the fp16 normal range):
+//       lo = Q~ - (1 + d2) P~ - ABS  <=  sim_fp32 * S  <=  Q~ - (1 - d2) P~ + ABS = hi,   d2 = 2 d / (1 - d)
+//   (S = power-of-two scale of the query, see pf_query_operand; the d margin of 33 % over 2^-10 absorbs the fp32
+//   round-off of the reference chain itself, ~70 * 2^-24 relative to P).
+//
+// Five kernels, no LDS lists, no prune rounds, no workgroup barriers:
+//   pf_stats    max of mk^2 m, 2|mk| m, m over the bank -> power-of-two scales that put the largest operand
+//               just under 2^15 (fp16 max 65 504); non-finite input -> fall-back flag;
+//   pf_prep     the bank as fp16 MFMA A-operands, tile-major [tile][9 K-blocks][64 lanes][8 halfs]: every
+//               operand load of the passes is one fully coalesced 1-KiB instruction;
+//   pass A      group maxima of lo: per (token range, query) 64 groups (token slot in the tile x tile
+//               parity) of DISTINCT tokens, so the k-th largest group maximum over all ranges is a valid
+//               lower bound of the k-th best score -- with 512 groups at 1080p it sits within a few per
+//               cent of the true k-th best (expected ~k+2 tokens above it); 2 VALU per score;
+//   pf_tau      one wave per query: k-th largest of its group maxima -> filter threshold;
+//   pass B      hi >= threshold -> candidate (token, hi) into the private sub-list of the (range, query,
+//               half-lane): plain predicated stores, no atomics; 2 VALU per score;
+//   pf_rescore  one wave per query: gathers the candidates of all ranges (~35), re-scores each with the
+//               fp32 FMA chain from its key row, selects the exact top-k on (score, index) keys and
+//               finishes like affinity_finalize_kernel (softmax, usage, or the hand-over format).
+// Anything the bound does not cover (negative selection, non-finite or out-of-range operands, a sub-list
+// or the re-score buffer overflowing -- flat "near-tie" banks) raises a device flag and the fp32 kernels
+// run as the fall-back in the same stream (they return at once when the flag is clear).
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+constexpr int PF_KB = 9;                      // K-blocks of 16 halfs per token: 4 (P: mk^2 m) + 1 (P: m x bsq) + 4 (Q)
+constexpr int PF_TILE_BYTES = PF_KB * 64 * 16;  // [kb][lane][8 halfs]
+constexpr int PF_QW = 4;                      // waves (32 queries each) per workgroup, all on the same token range
+constexpr int PF_SUB = 32;                    // candidate slots per (range, query, half-lane)
+constexpr int PF_MAX_SPLITS = 32;
+constexpr int PF_GROUPS = 32;                 // group maxima per (range, query): one per token slot of the tiles
+constexpr int PF_RESC_MAX = 256;              // candidates re-scored per query (4 rounds of 64)
+constexpr float PF_D2 = 2.61e-3f;             // 2 d / (1 - d), d = 1.3e-3
+constexpr float PF_ABS = 600.0f;              // operands below 2^-14 (flushed or subnormal): 2 chains x 2^-14 x 2 x 65 x 2^15
+
+struct PfState {     // device block, zeroed before every read
+  uint32_t flag;     // != 0: the fp32 kernels take over
+  uint32_t max_p;    // float bits: max mk^2 m
+  uint32_t max_q;    // max 2 |mk| m
+  uint32_t max_m;    // max m
+};
+
+// power of two P with x * P in [2^14, 2^15)
+__device__ __forceinline__ float pf_scale(float x) {
+  if (!(x > 0.0f) || !(x < INFINITY)) return 1.0f;
+  int e;
+  (void)frexpf(x, &e);  // x = f * 2^e, f in [0.5, 1)
+  e = 15 - e;
+  e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  return ldexpf(1.0f, e);
+}
+
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+struct PfBank {
+  const float* key_long;
+  const float* shr_long;
+  int n_long;
+  const float* key_work;
+  const float* shr_work;
+  int n_total;
+};
+
+__device__ __forceinline__ const float* pf_row(const PfBank& b, int n, float* ms) {
+  if (n < b.n_long) {
+    *ms = b.shr_long[n];
+    return b.key_long + (int64_t)n * CK;
+  }
+  *ms = b.shr_work[n - b.n_long];
+  return b.key_work + (int64_t)(n - b.n_long) * CK;
+}
+
+constexpr int PF_STAT_BLOCKS = 64;
+
+// grid-stride over (token, 16 channels); every block leaves its partial maxima (and a bad-input mark) in
+// part[block][4] -- no atomics, nothing to zero beforehand
+__global__ __launch_bounds__(256) void affinity_pf_stats_kernel(const PfBank b, uint32_t* __restrict__ part) {
+  __shared__ float s_red[4][4];
+  float mp = 0.0f, mq = 0.0f, mm = 0.0f;
+  bool bad = false;
+  const int total = b.n_total * 4;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += PF_STAT_BLOCKS * 256) {
+    const int n = i >> 2;
+    float ms;
+    const float* row = pf_row(b, n, &ms) + 16 * (i & 3);
+    const float m = ms * 0.125f;
+    mm = fmaxf(mm, m);
+    bad = bad || !(m >= 0.0f && m < INFINITY);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * j);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float a = fabsf(v[u]);
+        bad = bad || !(a < INFINITY);
+        mp = fmaxf(mp, a * a * m);
+        mq = fmaxf(mq, 2.0f * a * m);
+      }
+    }
+  }
+  mp = wave_max_f(mp);
+  mq = wave_max_f(mq);
+  mm = wave_max_f(mm);
+  bad = bad || !(mp < INFINITY) || !(mq < INFINITY);
+  const float fb = __builtin_amdgcn_ballot_w64(bad) ? 1.0f : 0.0f;
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    s_red[wave][0] = mp;
+    s_red[wave][1] = mq;
+    s_red[wave][2] = mm;
+    s_red[wave][3] = fb;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const float v = fmaxf(fmaxf(s_red[0][threadIdx.x], s_red[1][threadIdx.x]), fmaxf(s_red[2][threadIdx.x], s_red[3][threadIdx.x]));
+    part[blockIdx.x * 4 + threadIdx.x] = __float_as_uint(v);
+  }
+}
+
+// one thread per (token slot of the padded bank, half-lane): writes the 9 x 16 B this MFMA lane will load
+__global__ __launch_bounds__(256) void affinity_pf_prep_kernel(const PfBank b, const uint32_t* __restrict__ part,
+                                                                PfState* st, int n_pad, uint8_t* __restrict__ a16) {
+  // every block reduces the 64 partial maxima of the stats kernel itself (one wave, 256 B); block 0 publishes
+  // them together with the cleared fall-back flag for the kernels that follow in the stream
+  __shared__ float s_max[4];
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = wave_max_f(__uint_as_float(part[lane * 4 + c]));
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s_max[c] = v[c];
+      if (blockIdx.x == 0) {
+        st->flag = v[3] > 0.0f ? 1u : 0u;
+        st->max_p = __float_as_uint(v[0]);
+        st->max_q = __float_as_uint(v[1]);
+        st->max_m = __float_as_uint(v[2]);
+      }
+    }
+  }
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int n = i >> 1, half = i & 1;
+  if (n >= n_pad) return;
+  const float sp = pf_scale(s_max[0]);
+  const float sq = pf_scale(s_max[1]);
+  const float sm = pf_scale(s_max[2]);
+  uint8_t* dst = a16 + (int64_t)(n >> 5) * PF_TILE_BYTES + ((n & 31) + 32 * half) * 16;
+  h8 out[PF_KB];
+#pragma unroll
+  for (int kb = 0; kb < PF_KB; ++kb)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[kb][e] = (_Float16)0.0f;
+  if (n < b.n_total) {
+    float ms;
+    const float* row = pf_row(b, n, &ms);
+    const float m = ms * 0.125f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(row + 16 * kb + 8 * half);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(row + 16 * kb + 8 * half + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float a = e < 4 ? v0[e] : v1[e - 4];
+        out[kb][e] = (_Float16)(a * a * m * sp);
+        out[5 + kb][e] = (_Float16)(2.0f * a * m * sq);
+      }
+    }
+    if (half == 0) out[4][0] = (_Float16)(m * sm);
+  }
+#pragma unroll
+  for (int kb = 0; kb < PF_KB; ++kb) *reinterpret_cast<h8*>(dst + kb * 1024) = out[kb];
+}
+
+struct PfArgs {
+  const uint8_t* a16;
+  int n_total;
+  int total_tiles;
+  const float* qk;
+  const float* qe;
+  int hw;
+  int splits;
+  PfState* st;
+  float* gmax;         // [splits][hw][32] group maxima of lo (pass A)
+  const float* thr;    // [hw] filter threshold (pass B)
+  uint64_t* cand;      // [splits][hw][2][PF_SUB]: hi bits << 32 | token
+  uint32_t* cand_cnt;  // [splits][hw][2]
+};
+
+// The query side of the MFMAs for lane (l31, half): channel 16 kb + 8 half + e of query q, scaled by the
+// per-query powers of two that bring P~ and Q~ to the common scale S_q = min over the three operand groups
+// of (bank scale x largest query scale that keeps the group below 2^15).  Raises the fall-back flag for a
+// negative or non-finite selection / key.
+__device__ __forceinline__ void pf_query_operand(const float* __restrict__ qk, const float* __restrict__ qe, int hw, int q,
+                                                 int half, const PfState* st, h8 (&bq)[PF_KB], bool* bad_out) {
+  float e_[32], p_[32];
+  float bsq = 0.0f, e_max = 0.0f, p_max = 0.0f;
+  bool bad = false;
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = 16 * kb + 8 * half + e;
+      const float ev = qe[(int64_t)c * hw + q], kv = qk[(int64_t)c * hw + q];
+      bad = bad || !(ev >= 0.0f && ev < INFINITY) || !(fabsf(kv) < INFINITY);
+      e_[8 * kb + e] = ev;
+      p_[8 * kb + e] = kv * ev;
+      bsq += ev * (kv * kv);
+      e_max = fmaxf(e_max, ev);
+      p_max = fmaxf(p_max, fabsf(kv * ev));
+    }
+  // both half-lanes of a query end up with the same values
+  const float bsq_o = __shfl_xor(bsq, 32, 64), e_o = __shfl_xor(e_max, 32, 64), p_o = __shfl_xor(p_max, 32, 64);
+  bsq = half ? (bsq_o + bsq) : (bsq + bsq_o);
+  e_max = fmaxf(e_max, e_o);
+  p_max = fmaxf(p_max, p_o);
+  bad = bad || !(bsq < INFINITY) || !(p_max < INFINITY);
+  const float sp = pf_scale(__uint_as_float(st->max_p));
+  const float sq = pf_scale(__uint_as_float(st->max_q));
+  const float sm = pf_scale(__uint_as_float(st->max_m));
+  const float S = fminf(fminf(sp * pf_scale(e_max), sq * pf_scale(p_max)), sm * pf_scale(bsq));
+  const float te = S / sp, tp = S / sq, tb = S / sm;  // powers of two: exact
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      bq[kb][e] = (_Float16)(e_[8 * kb + e] * te);
+      bq[5 + kb][e] = (_Float16)(p_[8 * kb + e] * tp);
+    }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bq[4][e] = (_Float16)0.0f;
+  if (half == 0) bq[4][0] = (_Float16)(bsq * tb);
+  *bad_out = bad;
+}
+
+// PASS 0: group maxima of lo; PASS 1: candidates with hi >= threshold.
+// QG query groups (of 32) per wave share every token tile the wave loads: the vector-memory path delivers 64 B per
+// clock and CU, a 32x32x16 MFMA (32 clocks) consumes a 1-KiB A fragment, so with one query group per wave the
+// passes are bound by operand delivery at ~3x the matrix time (measured: 840 clocks per tile against 288 of
+// MFMAs); two groups halve the operand bytes per MFMA.  Small frames keep QG = 1 (more workgroups).
+template <int PASS, int QG>
+__global__ __launch_bounds__(PF_QW * 64, 2) void affinity_pf_pass_kernel(const PfArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int l31 = lane & 31;
+  const int half = lane >> 5;
+  const int q0 = (blockIdx.x * PF_QW + wave) * (QT * QG);
+  if (q0 >= p.hw) return;
+  const int split = blockIdx.y;
+  h8 bq[QG][PF_KB];
+  bool q_ok[QG];
+  int q[QG];
+  float thr[QG];
+  uint32_t ccnt[QG];
+  uint64_t* my_list[QG];
+  float g[QG][16];
+  bool bad = false;
+#pragma unroll
+  for (int u = 0; u < QG; ++u) {
+    q_ok[u] = q0 + QT * u + l31 < p.hw;
+    q[u] = min(q0 + QT * u + l31, p.hw - 1);
+    bool bad_u;
+    pf_query_operand(p.qk, p.qe, p.hw, q[u], half, p.st, bq[u], &bad_u);
+    bad = bad || (bad_u && q_ok[u]);
+    thr[u] = PASS ? p.thr[q[u]] : 0.0f;
+    ccnt[u] = 0u;
+    my_list[u] = p.cand + (((int64_t)split * p.hw + q[u]) * 2 + half) * PF_SUB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g[u][r] = -INFINITY;
+  }
+  if (PASS == 0 && split == 0 && __builtin_amdgcn_ballot_w64(bad) && lane == 0) atomicOr(&p.st->flag, 2u);
+
+  const int t0 = (int)(((int64_t)p.total_tiles * split) / p.splits);
+  const int t1 = (int)(((int64_t)p.total_tiles * (split + 1)) / p.splits);
+  const uint8_t* mine = p.a16 + lane * 16;
+  auto load = [&](h8 (&x)[PF_KB], int tile) __attribute__((always_inline)) {
+    const uint8_t* base = mine + (int64_t)tile * PF_TILE_BYTES;
+#pragma unroll
+    for (int kb = 0; kb < PF_KB; ++kb) x[kb] = *reinterpret_cast<const h8*>(base + kb * 1024);
+  };
+  const float c_lo = -(1.0f + PF_D2), c_hi = -(1.0f - PF_D2);
+
+  // full: every token slot of the tile is inside the bank (all tiles but possibly the last one of the bank)
+  auto process = [&](const h8 (&x)[PF_KB], int tile, auto full) __attribute__((always_inline)) {
+    constexpr bool full_tile = decltype(full)::value;
+    const int rows_left = p.n_total - tile * TOKT;
+    const uint32_t tok0 = (uint32_t)(tile * TOKT + 4 * half);
+#pragma unroll
+    for (int u = 0; u < QG; ++u) {
+      f32x16 accP, accQ;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        accP[r] = 0.0f;
+        accQ[r] = 0.0f;
+      }
+#pragma unroll
+      for (int kb = 0; kb < 5; ++kb) accP = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[kb], bq[u][kb], accP, 0, 0, 0);
+#pragma unroll
+      for (int kb = 5; kb < PF_KB; ++kb) accQ = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[kb], bq[u][kb], accQ, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j0 = (r & 3) + 8 * (r >> 2);  // + 4 * half: token slot of accumulator row r
+        if (PASS == 0) {
+          float lo = __builtin_fmaf(accP[r], c_lo, accQ[r]);
+          if (!full_tile && j0 + 4 * half >= rows_left) lo = -INFINITY;
+          // plain v_max_f32 (fmaxf would first canonicalise both inputs: one more VALU instruction per score)
+          asm("v_max_f32 %0, %1, %2" : "=v"(g[u][r]) : "v"(g[u][r]), "v"(lo));
+        } else {
+          const float hi = __builtin_fmaf(accP[r], c_hi, accQ[r]);
+          bool ok = hi >= thr[u];
+          if (!full_tile) ok = ok && (j0 + 4 * half < rows_left);
+          if (ok) {
+            if (ccnt[u] < (uint32_t)PF_SUB)
+              my_list[u][ccnt[u]] = ((uint64_t)__float_as_uint(hi) << 32) | (uint64_t)(tok0 + j0);
+            ccnt[u] += 1u;
+          }
+        }
+      }
+      // one accumulator set: the next group's MFMAs must not be hoisted above this group's scoring (two sets in
+      // flight push pass A over the 256-register budget of two waves per SIMD -> scratch spills)
+      if (PASS == 0 && QG > 1) __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // the bank's ragged last tile (if this range holds it) is peeled off the loop
+  const bool ragged = (t1 == p.total_tiles) && (p.n_total % TOKT != 0) && (t1 > t0);
+  const int t1f = ragged ? t1 - 1 : t1;
+  h8 xa[PF_KB], xb[PF_KB];
+  int t = t0;
+  if (t < t1f) load(xa, t);
+  while (t < t1f) {
+    if (t + 1 < t1f) load(xb, t + 1);
+    process(xa, t, std::true_type{});
+    if (t + 1 >= t1f) break;
+    if (t + 2 < t1f) load(xa, t + 2);
+    process(xb, t + 1, std::true_type{});
+    t += 2;
+  }
+  if (ragged) {
+    load(xa, t1f);
+    process(xa, t1f, std::false_type{});
+  }
+
+#pragma unroll
+  for (int u = 0; u < QG; ++u) {
+    if (!q_ok[u]) continue;
+    if (PASS == 0) {
+      float* dst = p.gmax + ((int64_t)split * p.hw + q[u]) * PF_GROUPS;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[(r & 3) + 8 * (r >> 2) + 4 * half] = g[u][r];
+    } else {
+      p.cand_cnt[((int64_t)split * p.hw + q[u]) * 2 + half] = ccnt[u];
+      if (ccnt[u] > (uint32_t)PF_SUB) atomicOr(&p.st->flag, 4u);
+    }
+  }
+}
+
+// one wave per query: threshold = the k-th largest of its splits x 32 group maxima, resolved to the top 20 bits of
+// the order-preserving score bits (rounded DOWN: still a valid lower bound, 2^-12 relative below the exact value,
+// a few per cent of the bound's own width) minus the absolute slack of both sides
+constexpr int PF_TAU_E = PF_MAX_SPLITS * PF_GROUPS / 64;
+__global__ __launch_bounds__(256) void affinity_pf_tau_kernel(const float* __restrict__ gmax, int hw, int k, int splits,
+                                                              float* __restrict__ thr) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= hw) return;
+  const int total = splits * PF_GROUPS;
+  uint32_t e[PF_TAU_E];
+#pragma unroll
+  for (int i = 0; i < PF_TAU_E; ++i) {
+    const int gi = i * 64 + lane;
+    uint32_t key = 0u;
+    if (gi < total) {
+      float v = gmax[((int64_t)(gi / PF_GROUPS) * hw + q) * PF_GROUPS + (gi % PF_GROUPS)];
+      v = (v == v) ? v : -INFINITY;
+      key = orderable(v);
+    }
+    e[i] = key;
+  }
+  const int n_live = (total + 63) / 64;
+  uint32_t T = 0u;
+  for (int b = 31; b >= 12; --b) {
+    const uint32_t trial = T | (1u << b);
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < PF_TAU_E; ++i)
+      if (i < n_live) cnt += wave_count(e[i] >= trial);
+    if (cnt >= k) T = trial;
+  }
+  // T == 0 (fewer than k groups hold tokens): -inf, every score becomes a candidate and the sub-lists overflow
+  if (lane == 0) thr[q] = (T == 0u ? -INFINITY : from_orderable(T)) - 2.0f * PF_ABS;
+}
+
+struct PfRescoreArgs {
+  PfBank bank;
+  const float* qk;
+  const float* qe;
+  int hw;
+  int k;
+  int splits;
+  PfState* st;
+  const uint64_t* cand;
+  const uint32_t* cand_cnt;
+  int32_t* idx;
+  float* weight;
+  unsigned long long* usage_fix;
+  uint64_t* out_keys;
+  uint32_t* out_cnt;
+  uint32_t token_offset;
+};
+
+// one wave per query: gather candidates, exact fp32 scores (the FMA chain of v_mfma_f32_32x32x2_f32: channels in
+// natural order, mk^2 rounded before it enters the chain, qk*qe rounded likewise), exact top-k, softmax / usage
+__global__ __launch_bounds__(256) void affinity_pf_rescore_kernel(const PfRescoreArgs p) {
+  __shared__ uint32_t s_tok[4][PF_RESC_MAX];
+  __shared__ __attribute__((aligned(16))) float s_qe[4][CK];
+  __shared__ __attribute__((aligned(16))) float s_qp[4][CK];
+  __shared__ uint64_t s_buf[4][2][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int q = blockIdx.x * 4 + wave;
+  if (q >= p.hw) return;
+  if (p.st->flag != 0u) return;  // the fp32 kernels produce this read
+  const int l31 = lane & 31, half = lane >> 5;
+  const int k = p.k;
+
+  // ---- query: lane c holds channel c; bsq in ATen's summation order (four 16-channel partial sums, see above)
+  const float ev = p.qe[(int64_t)lane * p.hw + q], kv = p.qk[(int64_t)lane * p.hw + q];
+  s_qe[wave][lane] = ev;
+  s_qp[wave][lane] = kv * ev;
+  const float term = ev * (kv * kv);
+  float bs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int c = 0; c < CK; ++c) bs[c >> 4] += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(term), c));
+  const float bsq = ((bs[0] + bs[1]) + bs[2]) + bs[3];
+
+  // ---- gather the candidates of every range (lane = (half-lane sub-list, slot))
+  int total = 0;
+  for (int i = 0; i < p.splits; ++i) {
+    const int64_t sub = ((int64_t)i * p.hw + q) * 2 + half;
+    const uint32_t c = p.cand_cnt[sub];
+    const bool valid = (uint32_t)l31 < (c < (uint32_t)PF_SUB ? c : (uint32_t)PF_SUB);
+    const uint64_t ent = valid ? p.cand[sub * PF_SUB + l31] : 0ull;
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(valid);
+    if (valid) {
+      const int pos = total + prefix_below(b);
+      if (pos < PF_RESC_MAX) s_tok[wave][pos] = (uint32_t)ent;
+    }
+    total += __popcll(b);
+  }
+  if (total > PF_RESC_MAX || total < k) {  // flat bank (or a bug): the fp32 kernels take over
+    if (lane == 0) atomicOr(&p.st->flag, 8u);
+    return;
+  }
+  DEVA_COMPILER_FENCE();
+
+  // ---- exact scores, 64 candidates per round
+  uint64_t e[PF_RESC_MAX / 64];
+#pragma unroll
+  for (int rr = 0; rr < PF_RESC_MAX / 64; ++rr) {
+    e[rr] = 0ull;
+    if (rr * 64 < total) {
+      const int c = rr * 64 + lane;
+      const bool live_c = c < total;
+      const uint32_t tok = live_c ? s_tok[wave][c] : 0u;
+      float ms;
+      const float* row = pf_row(p.bank, (int)tok, &ms);
+      float accA = 0.0f, accB = 0.0f;
+#pragma unroll
+      for (int j = 0; j < CK / 4; ++j) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(row + 4 * j);
+        const f32x4 qe4 = *reinterpret_cast<const f32x4*>(&s_qe[wave][4 * j]);
+        const f32x4 qp4 = *reinterpret_cast<const f32x4*>(&s_qp[wave][4 * j]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float a = x[u];
+          accA = __builtin_fmaf(a * a, qe4[u], accA);
+          accB = __builtin_fmaf(a, qp4[u], accB);
+        }
+      }
+      const float v = (((accB + accB) - accA) - bsq) * (ms * 0.125f);
+      if (live_c) e[rr] = ((uint64_t)orderable(v) << 32) | (uint64_t)(~tok);
+    }
+  }
+  const int rounds = (total + 63) / 64;
+  const uint64_t thr = kth_largest<PF_RESC_MAX / 64>(e, rounds, k);
+  volatile uint64_t* unsorted = &s_buf[wave][0][0];
+  volatile uint64_t* sorted = &s_buf[wave][1][0];
+  int base = 0;
+#pragma unroll
+  for (int i = 0; i < PF_RESC_MAX / 64; ++i) {
+    if (i < rounds) {
+      const bool keep = e[i] >= thr && e[i] != 0ull;
+      const unsigned long long b = __builtin_amdgcn_ballot_w64(keep);
+      if (keep) unsorted[base + prefix_below(b)] = e[i];
+      base += __popcll(b);
+    }
+  }
+  DEVA_COMPILER_FENCE();
+  // ---- from here on: affinity_finalize_kernel's tail
+  const bool live = lane < k;
+  const uint64_t cand = live ? unsorted[lane] : 0ull;
+  int rank = 0;
+  for (int j = 0; j < k; ++j) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cand, j);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cand >> 32), j);
+    rank += ((((uint64_t)hi << 32) | lo) > cand) ? 1 : 0;
+  }
+  DEVA_COMPILER_FENCE();
+  if (live) sorted[rank] = cand;
+  DEVA_COMPILER_FENCE();
+  const uint64_t mine = live ? sorted[lane] : 0ull;  // lane r holds the r-th best
+  if (p.out_keys) {
+    if (live) p.out_keys[(int64_t)q * CAP + lane] = (mine & 0xffffffff00000000ull) | (uint64_t)(~(~(uint32_t)mine + p.token_offset));
+    if (lane == 0) p.out_cnt[q] = (uint32_t)k;
+    return;
+  }
+  const float score = from_orderable((uint32_t)(mine >> 32));
+  const uint32_t token = ~(uint32_t)mine;
+  const float ex = live ? expf(score) : 0.0f;
+  float sum = 0.0f;
+  for (int r = 0; r < k; ++r) sum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ex), r));
+  const float w = ex / sum;
+  if (live) {
+    p.idx[(int64_t)q * k + lane] = (int32_t)token;
+    p.weight[(int64_t)q * k + lane] = w;
+    if (p.usage_fix && w == w) atomicAdd(&p.usage_fix[token], (unsigned long long)(w * 1099511627776.0f));
+  }
+}
+
 }  // namespace
 }  // namespace deva
 
@@ -1336,9 +1891,9 @@ extern "C" int deva_affinity_default_splits(int n_total, int hw) {
   return s;
 }
 
-extern "C" int deva_affinity_topk(const float* key_long, const float* shr_long, int n_long, const float* key_work,
-                                  const float* shr_work, int n_work, const float* qk, const float* qe, int hw,
-                                  int k, int splits, uint64_t* part_keys, void* stream) {
+static int topk_fp32(const float* key_long, const float* shr_long, int n_long, const float* key_work,
+                     const float* shr_work, int n_work, const float* qk, const float* qe, int hw, int k, int splits,
+                     uint64_t* part_keys, void* stream, const uint32_t* guard) {
   DEVA_REQUIRE(qk && qe && part_keys && hw > 0, "deva_affinity_topk: bad query args");
   DEVA_REQUIRE(n_long >= 0 && n_work >= 0, "deva_affinity_topk: negative bank size");
   DEVA_REQUIRE(n_long == 0 || (key_long && shr_long), "deva_affinity_topk: null long-term segment");
@@ -1378,6 +1933,7 @@ extern "C" int deva_affinity_topk(const float* key_long, const float* shr_long, 
   a.ablate = 0;
   a.probe = nullptr;
 #endif
+  a.guard = guard;
   dim3 grid((unsigned)ceil_div(hw, WAVES * QT), (unsigned)splits);
   const dim3 grid_wg((unsigned)ceil_div(hw, QT), (unsigned)splits);
   int shape = affinity_shape((int)n_total, hw);
@@ -1411,13 +1967,20 @@ extern "C" int deva_affinity_topk(const float* key_long, const float* shr_long, 
   return check_launch("deva_affinity_topk");
 }
 
+extern "C" int deva_affinity_topk(const float* key_long, const float* shr_long, int n_long, const float* key_work,
+                                  const float* shr_work, int n_work, const float* qk, const float* qe, int hw,
+                                  int k, int splits, uint64_t* part_keys, void* stream) {
+  return topk_fp32(key_long, shr_long, n_long, key_work, shr_work, n_work, qk, qe, hw, k, splits, part_keys, stream,
+                   nullptr);
+}
+
 static int launch_merge(const uint64_t* keys, const uint32_t* cnt, int hw, int k, int lists, int32_t* idx, float* weight,
                         uint64_t* usage_fix, uint64_t* out_keys, uint32_t* out_cnt, uint32_t token_offset,
-                        void* stream, const char* what) {
+                        void* stream, const char* what, const uint32_t* guard = nullptr) {
   const dim3 grid((unsigned)ceil_div(hw, 4));
 #define DEVA_MERGE(ME)                                                                                            \
   hipLaunchKernelGGL(affinity_finalize_kernel<ME>, grid, dim3(256), 0, (hipStream_t)stream, keys, cnt, hw, k, lists, \
-                     idx, weight, (unsigned long long*)usage_fix, out_keys, out_cnt, token_offset)
+                     idx, weight, (unsigned long long*)usage_fix, out_keys, out_cnt, token_offset, guard)
   if (lists <= 4) {
     DEVA_MERGE(4);
   } else if (lists <= 8) {
@@ -1483,4 +2046,174 @@ extern "C" int deva_readout_sparse(const int32_t* idx, const float* weight, int 
   hipLaunchKernelGGL(readout_sparse_kernel, grid, dim3(256), 0, (hipStream_t)stream, idx, weight, hw, k, vl, n_long,
                      vw, cv, out, tok_lo, tok_hi);
   return check_launch("deva_readout_sparse");
+}
+
+// ------------------------------------------------------------------ fp16 pre-filter + exact re-scoring (host side)
+static int g_prefilter = -1;  // -1: DEVA_AFFINITY_PREFILTER not read yet; 0 = never, 1 = automatic (default)
+constexpr int PF_MIN_TOKENS = 2048;  // below this the five launches cost more than the fp32 kernels need
+
+static int pf_qg(int hw) { return hw >= 4096 ? 2 : 1; }  // query groups per wave (large frames: half the operand traffic)
+
+static int pf_splits(int n_total, int hw) {
+  const int tiles = (int)ceil_div(n_total, TOKT);
+  const int qblocks = (int)ceil_div(hw, PF_QW * QT * pf_qg(hw));
+  int s = (int)ceil_div(512, qblocks);  // two 4-wave workgroups per CU
+  if (s < 4) s = 4;                     // >= 128 groups per query: the k-th largest group maximum stays a tight bound
+  if (s > tiles / 2) s = tiles / 2;     // >= 2 tiles per range
+  if (s > PF_MAX_SPLITS) s = PF_MAX_SPLITS;
+  if (s < 1) s = 1;
+  return s;
+}
+
+struct PfLayout {
+  int splits, tiles, old_splits;
+  int64_t off_state, off_a16, off_gmax, off_thr, off_cand, off_cnt, off_part, bytes;
+};
+
+static PfLayout pf_layout(int n_total, int hw, int k) {
+  PfLayout L;
+  L.splits = pf_splits(n_total, hw);
+  L.tiles = (int)ceil_div(n_total, TOKT);
+  L.old_splits = deva_affinity_default_splits(n_total, hw);
+  auto align = [](int64_t b) { return (b + 255) / 256 * 256; };
+  int64_t o = 0;
+  L.off_state = o;
+  o += 2048;  // PfState, then the stats kernel's [64][4] partial maxima
+  L.off_a16 = o;
+  o += align((int64_t)L.tiles * PF_TILE_BYTES);
+  L.off_gmax = o;
+  o += align((int64_t)L.splits * hw * PF_GROUPS * 4);
+  L.off_thr = o;
+  o += align((int64_t)hw * 4);
+  L.off_cand = o;
+  o += align((int64_t)L.splits * hw * 2 * PF_SUB * 8);
+  L.off_cnt = o;
+  o += align((int64_t)L.splits * hw * 2 * 4);
+  L.off_part = o;
+  o += align(deva_affinity_workspace(hw, k, L.old_splits) * 8);
+  L.bytes = o;
+  return L;
+}
+
+extern "C" int deva_affinity_prefilter_enabled(int n_total, int hw, int k) {
+  if (g_prefilter < 0) {
+    const char* e = getenv("DEVA_AFFINITY_PREFILTER");
+    g_prefilter = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  (void)hw;
+  return g_prefilter && n_total >= PF_MIN_TOKENS && k >= 1 && k <= K_MAX;
+}
+
+extern "C" int deva_affinity_force_prefilter(int mode) {
+  DEVA_REQUIRE(mode == 0 || mode == 1, "deva_affinity_force_prefilter: 0 = fp32 kernels only, 1 = automatic");
+  g_prefilter = mode;
+  return 0;
+}
+
+extern "C" int64_t deva_affinity_read_scratch(int n_total, int hw, int k) {
+  return pf_layout(n_total, hw, k).bytes / 8;
+}
+
+extern "C" int deva_affinity_read(const float* key_long, const float* shr_long, int n_long, const float* key_work,
+                                  const float* shr_work, int n_work, const float* qk, const float* qe, int hw, int k,
+                                  uint64_t* scratch, int32_t* idx, float* weight, uint64_t* usage_fix,
+                                  uint64_t* out_keys, uint32_t* out_counts, int64_t token_offset, void* stream) {
+  DEVA_REQUIRE(qk && qe && scratch && hw > 0, "deva_affinity_read: bad query args");
+  DEVA_REQUIRE((idx && weight && !out_keys && !out_counts) || (out_keys && out_counts && !idx && !weight && !usage_fix),
+               "deva_affinity_read: pass either idx + weight (+ usage_fix) or out_keys + out_counts");
+  DEVA_REQUIRE(n_long >= 0 && n_work >= 0, "deva_affinity_read: negative bank size");
+  DEVA_REQUIRE(n_long == 0 || (key_long && shr_long), "deva_affinity_read: null long-term segment");
+  DEVA_REQUIRE(n_work == 0 || (key_work && shr_work), "deva_affinity_read: null working segment");
+  DEVA_REQUIRE(k >= 1 && k <= K_MAX, "deva_affinity_read: k=%d unsupported (1..%d)", k, K_MAX);
+  const int64_t n_total = (int64_t)n_long + n_work;
+  DEVA_REQUIRE(n_total >= k, "deva_affinity_read: selected index k out of range (bank has %lld tokens, k=%d)",
+               (long long)n_total, k);
+  DEVA_REQUIRE(n_total < (1ll << 31) - 64, "deva_affinity_read: bank too large");
+  DEVA_REQUIRE(token_offset >= 0 && token_offset < (1ll << 31), "deva_affinity_read: bad token offset");
+  hipStream_t st = (hipStream_t)stream;
+  const PfLayout L = pf_layout((int)n_total, hw, k);
+  uint8_t* base = reinterpret_cast<uint8_t*>(scratch);
+  PfState* state = reinterpret_cast<PfState*>(base + L.off_state);
+  uint64_t* part = reinterpret_cast<uint64_t*>(base + L.off_part);
+
+  if (deva_affinity_prefilter_enabled((int)n_total, hw, k)) {
+    PfBank b;
+    b.key_long = key_long ? key_long : key_work;
+    b.shr_long = shr_long ? shr_long : shr_work;
+    b.n_long = n_long;
+    b.key_work = key_work ? key_work : key_long;
+    b.shr_work = shr_work ? shr_work : shr_long;
+    b.n_total = (int)n_total;
+    uint32_t* stat_part = reinterpret_cast<uint32_t*>(base + L.off_state + 64);  // [PF_STAT_BLOCKS][4], after the state
+    hipLaunchKernelGGL(affinity_pf_stats_kernel, dim3(PF_STAT_BLOCKS), dim3(256), 0, st, b, stat_part);
+    const int n_pad = L.tiles * TOKT;
+    hipLaunchKernelGGL(affinity_pf_prep_kernel, dim3((unsigned)ceil_div((int64_t)n_pad * 2, 256)), dim3(256), 0, st, b,
+                       stat_part, state, n_pad, base + L.off_a16);
+    PfArgs a;
+    a.a16 = base + L.off_a16;
+    a.n_total = (int)n_total;
+    a.total_tiles = L.tiles;
+    a.qk = qk;
+    a.qe = qe;
+    a.hw = hw;
+    a.splits = L.splits;
+    a.st = state;
+    a.gmax = reinterpret_cast<float*>(base + L.off_gmax);
+    a.thr = reinterpret_cast<const float*>(base + L.off_thr);
+    a.cand = reinterpret_cast<uint64_t*>(base + L.off_cand);
+    a.cand_cnt = reinterpret_cast<uint32_t*>(base + L.off_cnt);
+    const int qg = pf_qg(hw);
+    const dim3 grid((unsigned)ceil_div(hw, PF_QW * QT * qg), (unsigned)L.splits);
+    if (qg == 2) {
+      hipLaunchKernelGGL((affinity_pf_pass_kernel<0, 2>), grid, dim3(PF_QW * 64), 0, st, a);
+    } else {
+      hipLaunchKernelGGL((affinity_pf_pass_kernel<0, 1>), grid, dim3(PF_QW * 64), 0, st, a);
+    }
+    hipLaunchKernelGGL(affinity_pf_tau_kernel, dim3((unsigned)ceil_div(hw, 4)), dim3(256), 0, st, a.gmax, hw, k, L.splits,
+                       reinterpret_cast<float*>(base + L.off_thr));
+    if (qg == 2) {
+      hipLaunchKernelGGL((affinity_pf_pass_kernel<1, 2>), grid, dim3(PF_QW * 64), 0, st, a);
+    } else {
+      hipLaunchKernelGGL((affinity_pf_pass_kernel<1, 1>), grid, dim3(PF_QW * 64), 0, st, a);
+    }
+    PfRescoreArgs r;
+    r.bank = b;
+    r.qk = qk;
+    r.qe = qe;
+    r.hw = hw;
+    r.k = k;
+    r.splits = L.splits;
+    r.st = state;
+    r.cand = a.cand;
+    r.cand_cnt = a.cand_cnt;
+    r.idx = idx;
+    r.weight = weight;
+    r.usage_fix = (unsigned long long*)usage_fix;
+    r.out_keys = out_keys;
+    r.out_cnt = out_counts;
+    r.token_offset = (uint32_t)token_offset;
+    hipLaunchKernelGGL(affinity_pf_rescore_kernel, dim3((unsigned)ceil_div(hw, 4)), dim3(256), 0, st, r);
+    if (check_launch("deva_affinity_read (pre-filter)")) return 1;
+    // fall-back: the fp32 kernels, which return at once while the flag is clear
+    if (int rc = topk_fp32(key_long, shr_long, n_long, key_work, shr_work, n_work, qk, qe, hw, k, L.old_splits, part, stream,
+                           &state->flag))
+      return rc;
+    const uint32_t* cnt = reinterpret_cast<const uint32_t*>(part + (int64_t)L.old_splits * hw * CAP);
+    return launch_merge(part, cnt, hw, k, L.old_splits, idx, weight, usage_fix, out_keys, out_counts, (uint32_t)token_offset,
+                        stream, "deva_affinity_read (fall-back)", &state->flag);
+  }
+  if (int rc = topk_fp32(key_long, shr_long, n_long, key_work, shr_work, n_work, qk, qe, hw, k, L.old_splits, part, stream,
+                         nullptr))
+    return rc;
+  const uint32_t* cnt = reinterpret_cast<const uint32_t*>(part + (int64_t)L.old_splits * hw * CAP);
+  return launch_merge(part, cnt, hw, k, L.old_splits, idx, weight, usage_fix, out_keys, out_counts, (uint32_t)token_offset,
+                      stream, "deva_affinity_read");
+}
+
+// test hook: the fall-back flag of the last deva_affinity_read on this scratch (device -> host copy, synchronises)
+extern "C" int deva_affinity_read_flag(const uint64_t* scratch, void* stream) {
+  uint32_t flag = 0;
+  if (hipMemcpyAsync(&flag, scratch, sizeof(flag), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return -1;
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
+  return (int)flag;
 }

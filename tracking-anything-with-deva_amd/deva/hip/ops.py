@@ -306,18 +306,35 @@ def affinity_topk(key_long, shr_long, n_long: int, key_work, shr_work, n_work: i
     if qk.shape[0] != 64 or tuple(qe.shape) != tuple(qk.shape):
         raise DevaHipError('affinity_topk: queries must be [64, hw]')
     L = lib()
+    idx = torch.empty((hw, k), dtype=torch.int32, device=qk.device)
+    weight = torch.empty((hw, k), dtype=torch.float32, device=qk.device)
     if splits is None:
-        splits = L.deva_affinity_default_splits(n_long + n_work, hw)
+        # the library picks the kernels: fp16 pre-filter + exact fp32 re-scoring on banks where it pays, else the fp32
+        # kernels (also its device-side fall-back); bit-identical results either way
+        scratch = _affinity_workspace(L.deva_affinity_read_scratch(n_long + n_work, hw, k), qk.device)
+        check(L.deva_affinity_read(_p(key_long) if n_long else None, _p(shr_long) if n_long else None, n_long,
+                                   _p(key_work) if n_work else None, _p(shr_work) if n_work else None, n_work,
+                                   _p(qk), _p(qe), hw, k, _p(scratch, torch.int64), _p(idx, torch.int32), _p(weight),
+                                   _p(usage_fix, torch.int64), None, None, 0, _stream()), 'deva_affinity_read')
+        return idx, weight
     part = _affinity_workspace(L.deva_affinity_workspace(hw, k, splits), qk.device)
     check(L.deva_affinity_topk(_p(key_long) if n_long else None, _p(shr_long) if n_long else None, n_long,
                                _p(key_work) if n_work else None, _p(shr_work) if n_work else None, n_work,
                                _p(qk), _p(qe), hw, k, splits, _p(part, torch.int64), _stream()),
           'deva_affinity_topk')
-    idx = torch.empty((hw, k), dtype=torch.int32, device=qk.device)
-    weight = torch.empty((hw, k), dtype=torch.float32, device=qk.device)
     check(L.deva_affinity_finalize(_p(part, torch.int64), hw, k, splits, _p(idx, torch.int32), _p(weight),
                                    _p(usage_fix, torch.int64), _stream()), 'deva_affinity_finalize')
     return idx, weight
+
+
+def affinity_last_read_flag(device) -> int:
+    """test hook: fall-back flag of the last pre-filtered read on the current stream of `device` (synchronises);
+    0 = the fp16 pre-filter produced the result, otherwise the fp32 kernels took over (bit 0: non-finite bank,
+    1: negative / non-finite query, 2: a candidate sub-list overflowed, 3: too many candidates to re-score)"""
+    ws = _AFF_WS.get((device, torch.cuda.current_stream(device).cuda_stream))
+    if ws is None:
+        raise DevaHipError('affinity_last_read_flag: no read has run on this stream')
+    return int(lib().deva_affinity_read_flag(_p(ws, torch.int64), _stream()))
 
 
 def usage_update(usage_fix: torch.Tensor, offset: int, use: Optional[torch.Tensor], life: torch.Tensor,
@@ -349,15 +366,21 @@ def affinity_candidates(key_long, shr_long, n_long: int, key_work, shr_work, n_w
     if qk.shape[0] != 64 or tuple(qe.shape) != tuple(qk.shape):
         raise DevaHipError('affinity_candidates: queries must be [64, hw]')
     L = lib()
+    keys = torch.zeros((hw, 64), dtype=torch.int64, device=qk.device)
+    counts = torch.empty((hw,), dtype=torch.int32, device=qk.device)
     if splits is None:
-        splits = L.deva_affinity_default_splits(n_long + n_work, hw)
+        scratch = _affinity_workspace(L.deva_affinity_read_scratch(n_long + n_work, hw, k), qk.device)
+        check(L.deva_affinity_read(_p(key_long) if n_long else None, _p(shr_long) if n_long else None, n_long,
+                                   _p(key_work) if n_work else None, _p(shr_work) if n_work else None, n_work,
+                                   _p(qk), _p(qe), hw, k, _p(scratch, torch.int64), None, None, None,
+                                   _p(keys, torch.int64), _p(counts, torch.int32), int(token_offset), _stream()),
+              'deva_affinity_read')
+        return keys, counts
     part = _affinity_workspace(L.deva_affinity_workspace(hw, k, splits), qk.device)
     check(L.deva_affinity_topk(_p(key_long) if n_long else None, _p(shr_long) if n_long else None, n_long,
                                _p(key_work) if n_work else None, _p(shr_work) if n_work else None, n_work,
                                _p(qk), _p(qe), hw, k, splits, _p(part, torch.int64), _stream()),
           'deva_affinity_topk')
-    keys = torch.zeros((hw, 64), dtype=torch.int64, device=qk.device)
-    counts = torch.empty((hw,), dtype=torch.int32, device=qk.device)
     check(L.deva_affinity_select(_p(part, torch.int64), hw, k, splits, int(token_offset), _p(keys, torch.int64),
                                  _p(counts, torch.int32), _stream()), 'deva_affinity_select')
     return keys, counts

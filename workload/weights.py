@@ -31,13 +31,15 @@ GAINS = {
 # its probabilities are far from flat.  With the default gains the 30th weight is still ~0.4x the first, so a
 # near-tie at the k-th/(k+1)-th boundary swaps a token that carries 3 % of the read-out, and 60 % of the
 # pixels have a top-1/top-2 probability margin below 1e-2: "argmax-identical" is then untestable.  Key gain
-# 30 makes the boundary tokens weightless (the reference's own drift under a 1e-6 input perturbation drops
-# from 4e-3 to 3e-4; gain 60 underflows every exp() to the reference's NaN pattern), prediction gain 1.0
-# puts 80 % of the pixels above a 1e-2 margin (gain 2.0 turns the random recurrent network chaotic: its
-# self-drift grows to 4e-2) -- probed with the oracle, 240x432, 3 objects, 12 frames.
+# 15 makes the boundary tokens weightless (the reference's own drift under a 1e-6 input perturbation drops
+# from 4e-3 to 4e-4 at 240x432; the scores grow with the gain squared: at gain 30 the best score of some
+# 480p queries falls below -103 and the reference's exp() without max subtraction returns 0/0 = NaN from
+# frame 4 on, gain 60 does so everywhere), prediction gain 1.0 puts 80 % of the pixels above a 1e-2 margin
+# (gain 2.0 turns the random recurrent network chaotic: its self-drift grows to 4e-2) -- probed with the
+# oracle, 240x432 / 3 objects / 12 frames and 480x854 / 5 objects / 7 frames.
 RECIPES = {
     'default': GAINS,
-    'peaky': {'key_proj.key_proj.weight': 30.0, 'mask_decoder.pred.weight': 1.0},
+    'peaky': {'key_proj.key_proj.weight': 15.0, 'mask_decoder.pred.weight': 1.0},
 }
 
 
