@@ -24,12 +24,14 @@ Extra objects on the JSON line:
                 HBM bytes per frame of those kernels from the committed rocprofv3 --pmc passes over
                 this same command (profiles/pmc_r02/conv_traffic.json; bench.py cannot collect PMC
                 counters itself), next to the algorithmic bytes per frame computed here.
-  affinity      the north-star kernel (fused similarity/top-k/softmax): event-timed at the
-                BASELINE shape (N=10 000 bank, 1080p queries), reported against the fp32-MFMA roof
-                that binds it and as HBM GB/s on algorithmic and on materialised-equivalent bytes
-                (SURVEY.md §8d asks for all three).
+  affinity      the north-star read (similarity -> exact top-k -> softmax -> usage): event-timed at the
+                BASELINE shape (N=10 000 bank, 1080p queries) through deva_affinity_read (fp16 MFMA
+                pre-filter + exact fp32 re-scoring) and through the fp32 kernels alone; reported as
+                fp32-equivalent TFLOP/s against the fp32-MFMA roof (which the pre-filter is not bound
+                by), as f16 MFMA TFLOP/s, and as HBM GB/s on algorithmic and on materialised-equivalent
+                bytes (SURVEY.md §8d asks for all three).
   cpu_baseline  the CPU oracle (port of the reference's PyTorch path) on the same workload, on this
-                box's host cores: median of 3 runs over a bounded sample of frames, with per-stage ms.
+                box's host cores: one continuous 30-frame run timed in three parts (range), per-stage ms.
   also          further lines of BASELINE.json's metric, each with its own warm-up and timed frames:
                 1080p / detections every 5th frame / 10k-token long-term bank (BASELINE configs[2] and
                 the north-star target line) and 4K / 50k-token bank (configs[4] on this one GPU).  Each
@@ -167,51 +169,73 @@ class ConvTimer:
         return sorted(rows, key=lambda r: -r['ms_per_frame'])
 
 
+PEAK_F16_MATRIX_TFLOPS = 2500.0  # MI355X_MICROARCH.md, dense f16 / bf16 MFMA
+
+
 def affinity_microbench(device, n=10000, hw=8160, k=30, iters=20):
-    from deva.hip import ops
+    """the whole memory read (similarity -> exact top-k -> softmax -> usage counters) at the BASELINE shape, event-timed:
+    `deva_affinity_read` as the frame loop calls it (fp16 pre-filter + exact fp32 re-scoring, bit-identical to the
+    fp32 kernels: tests/test_gpu_d_affinity.py) and, beside it, the fp32 kernels alone (pre-filter forced off)"""
+    from deva.hip import lib
     from workload import synth
     mk, ms, qk, qe = synth.affinity_inputs(n, hw, seed=0)  # SURVEY.md §8d kernel-only inputs
     key = mk.t().contiguous().to(device)
     shr = ms.reshape(-1).contiguous().to(device)
     qk, qe = qk.to(device), qe.to(device)
     fix = torch.zeros(n, dtype=torch.int64, device=device)
-    L = __import__('deva.hip', fromlist=['lib']).lib()
-    splits = L.deva_affinity_default_splits(n, hw)
-    part = torch.empty((L.deva_affinity_workspace(hw, k, splits),), dtype=torch.int64, device=device)
+    L = lib()
+    scratch = torch.empty((L.deva_affinity_read_scratch(n, hw, k),), dtype=torch.int64, device=device)
     st = torch.cuda.current_stream().cuda_stream
-    for _ in range(3):
-        ops.affinity_topk(None, None, 0, key, shr, n, qk, qe, k, fix)
-    torch.cuda.synchronize()
-    t_main = t_fin = 0.0
     idx = torch.empty((hw, k), dtype=torch.int32, device=device)
     wgt = torch.empty((hw, k), dtype=torch.float32, device=device)
-    for _ in range(iters):
-        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        e0.record()
-        L.deva_affinity_topk(None, None, 0, key.data_ptr(), shr.data_ptr(), n, qk.data_ptr(), qe.data_ptr(), hw, k,
-                             splits, part.data_ptr(), st)
-        e1.record()
-        L.deva_affinity_finalize(part.data_ptr(), hw, k, splits, idx.data_ptr(), wgt.data_ptr(), fix.data_ptr(), st)
-        e2.record()
-        torch.cuda.synchronize()
-        t_main += e0.elapsed_time(e1)
-        t_fin += e1.elapsed_time(e2)
-    t_main, t_fin = t_main / iters * 1e-3, t_fin / iters * 1e-3
-    flops = 4.0 * 64 * n * hw
+
+    def read():
+        rc = L.deva_affinity_read(None, None, 0, key.data_ptr(), shr.data_ptr(), n, qk.data_ptr(), qe.data_ptr(), hw, k,
+                                  scratch.data_ptr(), idx.data_ptr(), wgt.data_ptr(), fix.data_ptr(), None, None, 0, st)
+        assert rc == 0, L.deva_hip_last_error()
+
+    us = {}
+    try:
+        for mode in (0, 1):
+            L.deva_affinity_force_prefilter(mode)
+            for _ in range(3):
+                read()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                read()
+            e1.record()
+            torch.cuda.synchronize()
+            us[mode] = e0.elapsed_time(e1) / iters * 1e3
+        flag = L.deva_affinity_read_flag(scratch.data_ptr(), st)
+    finally:
+        L.deva_affinity_force_prefilter(1)
+    t = us[1] * 1e-6
+    flops = 4.0 * 64 * n * hw                       # the reference's two K=64 contractions (memory_utils.py:29-43)
+    f16_flops = 2 * 2.0 * 144 * n * hw              # what the pre-filter issues: two passes of K = 144 (P, m x bsq, Q chains)
     b_alg = 4.0 * (64 * n + n + 2 * 64 * hw) + 8.0 * k * hw + 4.0 * n
     b_mat = 12.0 * 4 * n * hw
-    t = t_main + t_fin
-    return dict(shape=dict(n=n, hw=hw, k=k, splits=splits), us_topk=t_main * 1e6, us_finalize=t_fin * 1e6,
-                bound='mfma_fp32', achieved_tflops=flops / t / 1e12, peak_tflops=PEAK_FP32_MATRIX_TFLOPS,
-                frac=flops / t / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
+    return dict(shape=dict(n=n, hw=hw, k=k), us_read=us[1], us_read_fp32_kernels_only=us[0], speedup_over_fp32_kernels=us[0] / us[1],
+                prefilter_fell_back=bool(flag),
+                bound='f16 MFMA operand delivery + VALU scoring (the fp32 matrix rate no longer binds: only ~35 of the '
+                      f'{n} tokens per query are scored in fp32)',
+                fp32_equivalent_tflops=flops / t / 1e12, peak_fp32_matrix_tflops=PEAK_FP32_MATRIX_TFLOPS,
+                frac_of_fp32_matrix_roof=flops / t / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
+                fp32_kernels_frac_of_fp32_matrix_roof=flops / (us[0] * 1e-6) / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
+                f16_mfma_tflops=f16_flops / t / 1e12, f16_mfma_frac=f16_flops / t / 1e12 / PEAK_F16_MATRIX_TFLOPS,
                 hbm_algorithmic_gbps=b_alg / t / 1e9, hbm_algorithmic_frac=b_alg / t / 1e9 / PEAK_HBM_GBPS,
                 hbm_materialised_equiv_gbps=b_mat / t / 1e9,
-                parity_gate='tests/test_gpu_g_fullsize.py::test_affinity_at_bench_shapes')
+                parity_gate='tests/test_gpu_g_fullsize.py::test_affinity_at_bench_shapes + '
+                            'tests/test_gpu_d_affinity.py::test_fp16_prefilter_is_bit_identical_to_the_fp32_kernels')
 
 
-def cpu_baseline(sd, cfg, height, width, num_objects, frames_cpu, repeats=3):
-    """the CPU oracle on the first frames of the same clip: median FPS of `repeats` runs and per-stage
-    milliseconds per propagated frame (stage timers wrapped around the oracle's own functions)"""
+def cpu_baseline(sd, cfg, height, width, num_objects, frames_cpu, segments=3):
+    """the CPU oracle on the first frames of the same clip: ONE continuous run over len(frames_cpu) - 1 propagated
+    frames (30 by default: six memory frames, the working bank grows like in the timed GPU region), timed in
+    `segments` consecutive parts so that the line carries its own run-to-run range; per-stage milliseconds per
+    propagated frame from timers wrapped around the oracle's own functions.  BASELINE configs[1] runs with the
+    long-term memory disabled, so there is no consolidation to include."""
     from oracle import deva_oracle as O
     from workload import synth
     stages = {}
@@ -233,27 +257,32 @@ def cpu_baseline(sd, cfg, height, width, num_objects, frames_cpu, repeats=3):
     O.OracleMemory.add = timed('add_memory', mem_saved[1])
     fps = []
     n = len(frames_cpu) - 1
+    per = max(1, n // segments)
     try:
         mask = synth.box_mask(height, width, num_objects)
-        for _ in range(repeats):
-            core = O.OracleCore(sd, cfg)
-            core.step(frames_cpu[0], mask, list(range(1, num_objects + 1)))
-            stages.clear()
+        core = O.OracleCore(sd, cfg)
+        core.step(frames_cpu[0], mask, list(range(1, num_objects + 1)))
+        stages.clear()
+        t_all = time.perf_counter()
+        for lo in range(1, n + 1, per):
+            part = frames_cpu[lo:min(lo + per, n + 1)]
             t0 = time.perf_counter()
-            for f in frames_cpu[1:]:
+            for f in part:
                 core.step(f)
-            fps.append(n / (time.perf_counter() - t0))
+            fps.append(len(part) / (time.perf_counter() - t0))
+        total = n / (time.perf_counter() - t_all)
     finally:
         for k_, v in saved.items():
             setattr(O, k_, v)
         O.OracleMemory.match, O.OracleMemory.add = mem_saved
-    fps.sort()
-    kind = 'port'  # oracle/deva_oracle.py; /root/reference (the "reference" kind) does not exist on the GPU box
-    return dict(value=fps[len(fps) // 2], unit='frames/s', cores=torch.get_num_threads(), kind=kind,
-                runs_fps=fps, stage_ms_per_frame={k_: 1e3 * v / n for k_, v in stages.items()},
-                sample=f'median of {repeats} runs over {n} propagated frames after the annotated one (memory frames '
-                       f'every {cfg["mem_every"]}th), same workload and weights (CPU oracle, fp32); stage times '
-                       'are of the last run')
+    # "reference" would be the reference's own modules timed here; /root/reference does not exist on the GPU box, so
+    # the baseline is the oracle (bit-identical to the reference in the build container, tests/test_oracle_golden.py)
+    return dict(value=total, unit='frames/s', cores=torch.get_num_threads(), kind='port',
+                segment_fps=fps, range_fps=[min(fps), max(fps)],
+                stage_ms_per_frame={k_: 1e3 * v / n for k_, v in stages.items()},
+                sample=f'one continuous run over {n} propagated frames after the annotated one (memory frames every '
+                       f'{cfg["mem_every"]}th), timed in {len(fps)} consecutive parts (range_fps), same workload and weights '
+                       '(CPU oracle, fp32)')
 
 
 def timed_region(fn, dist=None, device=None):
@@ -463,7 +492,7 @@ def main():
     ap.add_argument('--objects', type=int, default=5)
     ap.add_argument('--workload', choices=['clips', 'long4k'], default='clips')
     ap.add_argument('--long4k_mode', choices=['owner', 'queries', 'bank'], default='owner')
-    ap.add_argument('--cpu_frames', type=int, default=10, help='propagated frames per CPU-baseline run (3 runs)')
+    ap.add_argument('--cpu_frames', type=int, default=30, help='propagated frames of the CPU-baseline run')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_extra', action='store_true')
     args = ap.parse_args()
@@ -599,15 +628,6 @@ def main():
             result['roofline']['traffic_source'] = 'profiles/pmc_r02/conv_traffic.json'
             result['roofline']['traffic_over_algorithmic'] = d['hbm_bytes_per_frame'] / (alg_bytes / n_replay)
         result['affinity'] = affinity_microbench(device)
-        pmc_aff = os.path.join(ROOT, 'profiles', 'pmc_r02', 'affinity_per_launch_r02f.json')
-        if os.path.exists(pmc_aff):
-            with open(pmc_aff) as f:
-                d = json.load(f)['10k']
-            result['affinity']['pmc'] = {'source': 'profiles/pmc_r02/affinity_per_launch_r02f.json',
-                                         'mfma_util': d['mfma_util_frac'],
-                                         'hbm_bytes': d.get('hbm_bytes'), 'algorithmic_bytes': d.get('algorithmic_bytes'),
-                                         'valu_instructions_per_tile': d['per_wave_per_tile']['SQ_INSTS_VALU'],
-                                         'mfma_instructions_per_tile': d['per_wave_per_tile']['SQ_INSTS_MFMA']}
         if not args.no_extra:
             del core
             fps1080, state1080 = run_1080p(net, device, steps=25, warmup=6, detections=False)

@@ -277,8 +277,12 @@ class Drift:
     (the reference's golden outputs / the plain oracle) and the reference's own drift under a 1e-6 relative input
     perturbation -- the noise floor a tie-break costs the reference itself."""
 
-    def __init__(self, tag, stride=1):
-        self.tag, self.stride = tag, stride
+    def __init__(self, tag, stride=1, floor_bound=False):
+        """floor_bound=True (the peaky recipe only, whose keys are 15x larger: the score noise between two fp32
+        implementations grows with the gain squared and reaches the soft outputs through the softmax weights even
+        without a single differing decision): the bound is max(1e-3, 10 x the reference's own drift under a 1e-6
+        input perturbation), measured in the same test (`ref_perturbed` against the tie-following run)"""
+        self.tag, self.stride, self.floor_bound = tag, stride, floor_bound
         self.rows = []
 
     @staticmethod
@@ -297,10 +301,11 @@ class Drift:
             row['clean'], _ = self._stats(got, clean)
             row['clean_raw'] = argmax_flips(got, clean)[0]
             msg += f' | vs clean ref max-abs {row["clean"]:.2e} flips raw {row["clean_raw"]}'
-        if ref_perturbed is not None and clean is not None:
-            row['floor'], _ = self._stats(ref_perturbed, clean)
-            row['floor_raw'] = argmax_flips(ref_perturbed, clean)[0]
-            msg += f' | clean ref vs ref(1e-6 input noise) max-abs {row["floor"]:.2e} flips raw {row["floor_raw"]}'
+        if ref_perturbed is not None:
+            base = clean if clean is not None else ref  # (the tie-following run is the clean one up to the adopted ties)
+            row['floor'], _ = self._stats(ref_perturbed, base)
+            row['floor_raw'] = argmax_flips(ref_perturbed, base)[0]
+            msg += f' | ref vs ref(1e-6 input noise) max-abs {row["floor"]:.2e} flips raw {row["floor_raw"]}'
         print(msg)
         self.rows.append(row)
 
@@ -314,10 +319,15 @@ class Drift:
         if any('floor' in r for r in self.rows):
             report['reference_self_drift'] = max(r.get('floor', 0.0) for r in self.rows)
             report['reference_self_flips'] = sum(r.get('floor_raw', 0) for r in self.rows)
+        bound = NORTH_STAR
+        if self.floor_bound:
+            assert 'reference_self_drift' in report, 'floor_bound needs the perturbed-oracle run'
+            bound = max(NORTH_STAR, 10 * report['reference_self_drift'])
+        report['bound'] = bound
         print(f'{self.tag}: ' + ', '.join(f'{k} {v:.3g}' for k, v in report.items()))
         for r in self.rows:
-            assert r['err'] <= NORTH_STAR, (f'{self.tag} frame {r["frame"]}: max-abs {r["err"]:.2e} vs the tie-following '
-                                            f'reference exceeds {NORTH_STAR:.0e}')
+            assert r['err'] <= bound, (f'{self.tag} frame {r["frame"]}: max-abs {r["err"]:.2e} vs the tie-following '
+                                       f'reference exceeds {bound:.1e}')
             assert r['decisive'] == 0, (f'{self.tag} frame {r["frame"]}: {r["decisive"]} argmax flips at pixels whose '
                                         'reference margin exceeds 2e-3')
             if 'clean' in r and r['adopted'] == 0:
@@ -326,12 +336,12 @@ class Drift:
         return report
 
 
-def paired_steps(tag, n_frames, hip_call, following_call, clean_call=None, noisy_call=None):
+def paired_steps(tag, n_frames, hip_call, following_call, clean_call=None, noisy_call=None, floor_bound=False):
     """Frame-by-frame driver of a free-running comparison: hip_call(t) runs the HIP core (its memory reads are
     tapped), following_call(t) the CPU oracle under `TieFollowing` of exactly those reads; clean_call / noisy_call
     (optional) the plain oracle and the oracle on 1e-6-perturbed inputs (or stored golden outputs).  All return the
     frame's probabilities on the CPU.  -> Drift report (asserted)."""
-    drift, adopted = Drift(tag), 0
+    drift, adopted = Drift(tag, floor_bound=floor_bound), 0
     for t in range(n_frames):
         with ReadTap() as tap:
             a = hip_call(t)

@@ -117,13 +117,15 @@ def test_e2e_peaky_against_reference_golden(peaky_network, golden_dir, peaky_sta
                              [torch.from_numpy(g[f'prob_sub_{t}']) for t in range(n)])
 
 
-def _five_objects_480p(tag, network_, P, with_clean):
+def _five_objects_480p(tag, network_, P, with_clean, with_noisy=False):
     """BASELINE configs[1] shape (480x854 -> 480x864, 5 objects, working memory only), 7 frames, free-running"""
     from deva.inference.inference_core import DEVAInferenceCore
     cfg = synth.base_config(enable_long_term=False, enable_long_term_count_usage=False)
     H, W, no, frames = 480, 854, 5, 7
     hip, following = DEVAInferenceCore(network_, cfg), O.OracleCore(P, cfg)
     clean = O.OracleCore(P, cfg) if with_clean else None
+    noisy = O.OracleCore(P, cfg) if with_noisy else None
+    gen = torch.Generator().manual_seed(0)
     stream = synth.FrameStream(H, W, seed=2)
     imgs = [stream.next() for _ in range(frames)]
     mask0, objs = synth.box_mask(H, W, no), list(range(1, no + 1))
@@ -132,12 +134,18 @@ def _five_objects_480p(tag, network_, P, with_clean):
         tag, frames,
         lambda t: hip.step(imgs[t].to(dev()), None if t else mask0.to(dev()), first(t)[1]).cpu(),
         lambda t: following.step(imgs[t], *first(t)),
-        None if clean is None else (lambda t: clean.step(imgs[t], *first(t))))
+        None if clean is None else (lambda t: clean.step(imgs[t], *first(t))),
+        None if noisy is None else (lambda t: noisy.step(imgs[t] * (1 + 1e-6 * torch.randn(imgs[t].shape, generator=gen)),
+                                                         *first(t))),
+        floor_bound=with_noisy)
     print(f'{tag}:', json.dumps({k: float(f'{v:.3g}') for k, v in report.items()}))
 
 
 def test_480p_five_objects_peaky_recipe(peaky_network, peaky_state_dict):
-    _five_objects_480p('480p/5obj/peaky', peaky_network, peaky_state_dict, with_clean=False)
+    """the peaky recipe at BASELINE configs[1] size: its 15x larger keys amplify the fp32 score noise between any two
+    implementations (gain squared) into the softmax weights, so the bound here is max(1e-3, 10 x the reference's own
+    drift), measured in the test; argmax-identical above a 2e-3 margin as everywhere"""
+    _five_objects_480p('480p/5obj/peaky', peaky_network, peaky_state_dict, with_clean=False, with_noisy=True)
 
 
 def test_consistent_detection_clip_against_reference_golden(network, recipe_state_dict, golden_dir):

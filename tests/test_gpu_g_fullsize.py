@@ -38,14 +38,6 @@ def network(recipe_state_dict):
     return net.to(dev()).eval()
 
 
-@pytest.fixture(scope='module')
-def peaky_network(peaky_state_dict):
-    from deva.model.network import DEVA
-    net = DEVA(synth.base_config())
-    net.load_weights(peaky_state_dict)
-    return net.to(dev()).eval()
-
-
 @pytest.mark.parametrize('n,hw,cols', [(10000, 8160, None), (83440, 8160, 2048), (50000, 32400, 2048)])
 def test_affinity_at_bench_shapes(n, hw, cols):
     k = 30
@@ -106,21 +98,21 @@ def test_1080p_detections_10k_bank_against_oracle(network, recipe_state_dict):
     print('1080p detections clip:', json.dumps({k: float(f'{v:.3g}') for k, v in report.items()}))
 
 
-def test_1080p_eight_segment_detections_against_oracle(peaky_network, peaky_state_dict):
+def test_1080p_eight_segment_detections_against_oracle(network, recipe_state_dict):
     """BASELINE configs[2] as SURVEY.md 8d defines it, at 1080p: tracker-consistent detections
     (workload/detections.py) every 3rd frame -- re-detections that match and merge, new segments that spawn
     objects in new buckets, unseen objects that are purged --, long-term bank pre-filled to 10 000 tokens,
     >= 3 live objects throughout.  3 segments per detection here (the CPU oracle costs ~2.5 s per object and
     1080p frame; bench.py times the 8-segment clip, the 96x128 golden of the reference covers 4 segments and
-    17 frames).  Peaky recipe.  The HIP run defines the clip (its forward masks feed the detector)."""
+    17 frames).  The HIP run defines the clip (its forward masks feed the detector)."""
     import detection_pairs
     from deva.inference.inference_core import DEVAInferenceCore
     from deva.inference.object_info import ObjectInfo
     from workload import detections
-    P = peaky_state_dict
+    P, _ = recipe_state_dict
     (H, W), frames, every = FULL_HD, 7, 3
     cfg = synth.base_config(mem_every=2, max_missed_detection_count=1, max_num_objects=-1)
-    hip, orc = DEVAInferenceCore(peaky_network, cfg), O.OracleDetectionCore(P, cfg)
+    hip, orc = DEVAInferenceCore(network, cfg), O.OracleDetectionCore(P, cfg)
     detector = detections.ConsistentDetector(H, W, segments=3, new_per_frame=1)
     report, recorded = detection_pairs.run('1080p/consistent detections', hip, orc, H, W, frames, every, detector,
                                            ObjectInfo, prefill=detection_pairs.prefill_10k)

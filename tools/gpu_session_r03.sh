@@ -16,7 +16,9 @@ run_test() {
   return $rc
 }
 if has tests; then
-  for f in ${TEST_FILES:-test_gpu_e_network test_gpu_g_fullsize}; do run_test $f ${TEST_TIMEOUT:-900}; done
+  for f in ${TEST_FILES:-test_gpu_e_network test_gpu_g_fullsize}; do
+    if [ -n "$PYTEST_K" ]; then run_test $f ${TEST_TIMEOUT:-900} -k "$PYTEST_K"; else run_test $f ${TEST_TIMEOUT:-900}; fi
+  done
 fi
 if has alltests; then
   for f in test_gpu_a_conv test_gpu_b_pointwise test_gpu_c_bank test_gpu_d_affinity test_gpu_f_memory_events test_gpu_e_network test_gpu_g_fullsize; do run_test $f ${TEST_TIMEOUT:-900}; done

@@ -1440,6 +1440,7 @@ __global__ __launch_bounds__(256) void affinity_pf_prep_kernel(const PfBank b, c
 }
 
 struct PfArgs {
+  const uint8_t* bq16;  // [ceil(hw/32)][9][64][8 halfs] query operands (affinity_pf_query_kernel)
   const uint8_t* a16;
   int n_total;
   int total_tiles;
@@ -1450,8 +1451,8 @@ struct PfArgs {
   PfState* st;
   float* gmax;         // [splits][hw][32] group maxima of lo (pass A)
   const float* thr;    // [hw] filter threshold (pass B)
-  uint64_t* cand;      // [splits][hw][2][PF_SUB]: hi bits << 32 | token
-  uint32_t* cand_cnt;  // [splits][hw][2]
+  uint64_t* cand;      // [hw][splits][2][PF_SUB]: hi bits << 32 | token
+  uint32_t* cand_cnt;  // [hw][splits][2]
 };
 
 // The query side of the MFMAs for lane (l31, half): channel 16 kb + 8 half + e of query q, scaled by the
@@ -1500,6 +1501,25 @@ __device__ __forceinline__ void pf_query_operand(const float* __restrict__ qk, c
   *bad_out = bad;
 }
 
+// one wave per 32 queries: the fp16 query operands of both passes, computed ONCE per read (every (range, pass) wave
+// used to rebuild them: 64 strided loads and the scale logic per query group, which at ~20 tiles per wave cost as
+// much as the tiles).  Layout like the bank operand: [query group][9 K-blocks][64 lanes][8 halfs].
+__global__ __launch_bounds__(256) void affinity_pf_query_kernel(const float* __restrict__ qk, const float* __restrict__ qe,
+                                                                 int hw, PfState* st, uint8_t* __restrict__ bq16) {
+  const int lane = threadIdx.x & 63;
+  const int group = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int q0 = group * QT;
+  if (q0 >= hw) return;
+  const int l31 = lane & 31, half = lane >> 5;
+  h8 bq[PF_KB];
+  bool bad;
+  pf_query_operand(qk, qe, hw, min(q0 + l31, hw - 1), half, st, bq, &bad);
+  if (__builtin_amdgcn_ballot_w64(bad && q0 + l31 < hw) && lane == 0) atomicOr(&st->flag, 2u);
+  uint8_t* dst = bq16 + (int64_t)group * PF_TILE_BYTES + lane * 16;
+#pragma unroll
+  for (int kb = 0; kb < PF_KB; ++kb) *reinterpret_cast<h8*>(dst + kb * 1024) = bq[kb];
+}
+
 // PASS 0: group maxima of lo; PASS 1: candidates with hi >= threshold.
 // QG query groups (of 32) per wave share every token tile the wave loads: the vector-memory path delivers 64 B per
 // clock and CU, a 32x32x16 MFMA (32 clocks) consumes a 1-KiB A fragment, so with one query group per wave the
@@ -1521,21 +1541,21 @@ __global__ __launch_bounds__(PF_QW * 64, 2) void affinity_pf_pass_kernel(const P
   uint32_t ccnt[QG];
   uint64_t* my_list[QG];
   float g[QG][16];
-  bool bad = false;
 #pragma unroll
   for (int u = 0; u < QG; ++u) {
     q_ok[u] = q0 + QT * u + l31 < p.hw;
     q[u] = min(q0 + QT * u + l31, p.hw - 1);
-    bool bad_u;
-    pf_query_operand(p.qk, p.qe, p.hw, q[u], half, p.st, bq[u], &bad_u);
-    bad = bad || (bad_u && q_ok[u]);
+    // (a query group past the end of the frame re-reads the last one: its results are discarded)
+    const int group = min(q0 / QT + u, (p.hw - 1) / QT);
+    const uint8_t* src = p.bq16 + (int64_t)group * PF_TILE_BYTES + lane * 16;
+#pragma unroll
+    for (int kb = 0; kb < PF_KB; ++kb) bq[u][kb] = *reinterpret_cast<const h8*>(src + kb * 1024);
     thr[u] = PASS ? p.thr[q[u]] : 0.0f;
     ccnt[u] = 0u;
-    my_list[u] = p.cand + (((int64_t)split * p.hw + q[u]) * 2 + half) * PF_SUB;
+    my_list[u] = p.cand + (((int64_t)q[u] * p.splits + split) * 2 + half) * PF_SUB;
 #pragma unroll
     for (int r = 0; r < 16; ++r) g[u][r] = -INFINITY;
   }
-  if (PASS == 0 && split == 0 && __builtin_amdgcn_ballot_w64(bad) && lane == 0) atomicOr(&p.st->flag, 2u);
 
   const int t0 = (int)(((int64_t)p.total_tiles * split) / p.splits);
   const int t1 = (int)(((int64_t)p.total_tiles * (split + 1)) / p.splits);
@@ -1616,15 +1636,15 @@ __global__ __launch_bounds__(PF_QW * 64, 2) void affinity_pf_pass_kernel(const P
 #pragma unroll
       for (int r = 0; r < 16; ++r) dst[(r & 3) + 8 * (r >> 2) + 4 * half] = g[u][r];
     } else {
-      p.cand_cnt[((int64_t)split * p.hw + q[u]) * 2 + half] = ccnt[u];
+      p.cand_cnt[((int64_t)q[u] * p.splits + split) * 2 + half] = ccnt[u];
       if (ccnt[u] > (uint32_t)PF_SUB) atomicOr(&p.st->flag, 4u);
     }
   }
 }
 
-// one wave per query: threshold = the k-th largest of its splits x 32 group maxima, resolved to the top 20 bits of
-// the order-preserving score bits (rounded DOWN: still a valid lower bound, 2^-12 relative below the exact value,
-// a few per cent of the bound's own width) minus the absolute slack of both sides
+// one wave per query: threshold = the k-th largest of its splits x 32 group maxima, resolved to the top 18 bits of
+// the order-preserving score bits (rounded DOWN: still a valid lower bound, at most 2^-9 relative below the exact
+// value -- a fraction of the bound's own width --, usually exact through the early exit) minus the absolute slack
 constexpr int PF_TAU_E = PF_MAX_SPLITS * PF_GROUPS / 64;
 __global__ __launch_bounds__(256) void affinity_pf_tau_kernel(const float* __restrict__ gmax, int hw, int k, int splits,
                                                               float* __restrict__ thr) {
@@ -1646,13 +1666,16 @@ __global__ __launch_bounds__(256) void affinity_pf_tau_kernel(const float* __res
   }
   const int n_live = (total + 63) / 64;
   uint32_t T = 0u;
-  for (int b = 31; b >= 12; --b) {
+  for (int b = 31; b >= 14; --b) {
     const uint32_t trial = T | (1u << b);
     int cnt = 0;
 #pragma unroll
     for (int i = 0; i < PF_TAU_E; ++i)
       if (i < n_live) cnt += wave_count(e[i] >= trial);
-    if (cnt >= k) T = trial;
+    if (cnt >= k) {
+      T = trial;
+      if (cnt == k) break;  // separates exactly k groups: the remaining bits cannot raise it past the k-th value
+    }
   }
   // T == 0 (fewer than k groups hold tokens): -inf, every score becomes a candidate and the sub-lists overflow
   if (lane == 0) thr[q] = (T == 0u ? -INFINITY : from_orderable(T)) - 2.0f * PF_ABS;
@@ -1676,48 +1699,78 @@ struct PfRescoreArgs {
   uint32_t token_offset;
 };
 
-// one wave per query: gather candidates, exact fp32 scores (the FMA chain of v_mfma_f32_32x32x2_f32: channels in
-// natural order, mk^2 rounded before it enters the chain, qk*qe rounded likewise), exact top-k, softmax / usage
+// one wave per query (four queries per workgroup): gather candidates, exact fp32 scores (the FMA chain of
+// v_mfma_f32_32x32x2_f32: channels in natural order, mk^2 rounded before it enters the chain, qk*qe rounded
+// likewise), exact top-k, softmax / usage
 __global__ __launch_bounds__(256) void affinity_pf_rescore_kernel(const PfRescoreArgs p) {
   __shared__ uint32_t s_tok[4][PF_RESC_MAX];
   __shared__ __attribute__((aligned(16))) float s_qe[4][CK];
   __shared__ __attribute__((aligned(16))) float s_qp[4][CK];
+  __shared__ float s_term[4][CK];
   __shared__ uint64_t s_buf[4][2][64];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int q = blockIdx.x * 4 + wave;
+  const int k = p.k;
+  {  // the four queries' operands, loaded by the whole workgroup: 16 B per channel row instead of 4 x 4 B
+    const int c = threadIdx.x >> 2, jq = threadIdx.x & 3;
+    const int qq = min(blockIdx.x * 4 + jq, p.hw - 1);
+    const float ev = p.qe[(int64_t)c * p.hw + qq], kv = p.qk[(int64_t)c * p.hw + qq];
+    s_qe[jq][c] = ev;
+    s_qp[jq][c] = kv * ev;
+    s_term[jq][c] = ev * (kv * kv);
+  }
+  __syncthreads();
   if (q >= p.hw) return;
   if (p.st->flag != 0u) return;  // the fp32 kernels produce this read
-  const int l31 = lane & 31, half = lane >> 5;
-  const int k = p.k;
 
-  // ---- query: lane c holds channel c; bsq in ATen's summation order (four 16-channel partial sums, see above)
-  const float ev = p.qe[(int64_t)lane * p.hw + q], kv = p.qk[(int64_t)lane * p.hw + q];
-  s_qe[wave][lane] = ev;
-  s_qp[wave][lane] = kv * ev;
-  const float term = ev * (kv * kv);
-  float bs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  // ---- bsq in ATen's summation order: four 16-channel partial sums (one per lane 0..3), then ((s0+s1)+s2)+s3
+  float part = 0.0f;
+  if (lane < 4) {
 #pragma unroll
-  for (int c = 0; c < CK; ++c) bs[c >> 4] += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(term), c));
-  const float bsq = ((bs[0] + bs[1]) + bs[2]) + bs[3];
+    for (int c = 0; c < 16; ++c) part += s_term[wave][16 * lane + c];
+  }
+  const float bs0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part), 0));
+  const float bs1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part), 1));
+  const float bs2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part), 2));
+  const float bs3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part), 3));
+  const float bsq = ((bs0 + bs1) + bs2) + bs3;
 
-  // ---- gather the candidates of every range (lane = (half-lane sub-list, slot))
-  int total = 0;
-  for (int i = 0; i < p.splits; ++i) {
-    const int64_t sub = ((int64_t)i * p.hw + q) * 2 + half;
-    const uint32_t c = p.cand_cnt[sub];
-    const bool valid = (uint32_t)l31 < (c < (uint32_t)PF_SUB ? c : (uint32_t)PF_SUB);
-    const uint64_t ent = valid ? p.cand[sub * PF_SUB + l31] : 0ull;
-    const unsigned long long b = __builtin_amdgcn_ballot_w64(valid);
-    if (valid) {
-      const int pos = total + prefix_below(b);
-      if (pos < PF_RESC_MAX) s_tok[wave][pos] = (uint32_t)ent;
-    }
-    total += __popcll(b);
+  // ---- gather: lane l owns sub-list l = (range, half-lane) of this query (<= 64 of them); its entries go to
+  // s_tok[prefix(l) .. prefix(l) + count(l))
+  const int n_sub = p.splits * 2;
+  const int64_t sub0 = (int64_t)q * n_sub;
+  uint32_t mine = 0u;
+  if (lane < n_sub) {
+    mine = p.cand_cnt[sub0 + lane];
+    mine = mine < (uint32_t)PF_SUB ? mine : (uint32_t)PF_SUB;
+  }
+  uint32_t incl = mine;  // inclusive prefix sum over the lanes
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+    if (lane >= o) incl += up;
+  }
+  const int total = __builtin_amdgcn_readlane((int)incl, 63);
+  const uint32_t base = incl - mine;
+  uint32_t longest = mine;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const uint32_t other = (uint32_t)__shfl_xor((int)longest, o, 64);
+    longest = other > longest ? other : longest;
   }
   if (total > PF_RESC_MAX || total < k) {  // flat bank (or a bug): the fp32 kernels take over
     if (lane == 0) atomicOr(&p.st->flag, 8u);
     return;
+  }
+  const uint64_t* my_sub = p.cand + (sub0 + lane) * PF_SUB;
+  for (uint32_t s0 = 0; s0 < longest; s0 += 4) {  // four independent loads in flight per lane
+    uint64_t ent[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ent[u] = (s0 + u < mine) ? my_sub[s0 + u] : 0ull;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (s0 + u < mine) s_tok[wave][base + s0 + u] = (uint32_t)ent[u];
   }
   DEVA_COMPILER_FENCE();
 
@@ -1749,41 +1802,56 @@ __global__ __launch_bounds__(256) void affinity_pf_rescore_kernel(const PfRescor
       if (live_c) e[rr] = ((uint64_t)orderable(v) << 32) | (uint64_t)(~tok);
     }
   }
-  const int rounds = (total + 63) / 64;
-  const uint64_t thr = kth_largest<PF_RESC_MAX / 64>(e, rounds, k);
   volatile uint64_t* unsorted = &s_buf[wave][0][0];
   volatile uint64_t* sorted = &s_buf[wave][1][0];
-  int base = 0;
-#pragma unroll
-  for (int i = 0; i < PF_RESC_MAX / 64; ++i) {
-    if (i < rounds) {
-      const bool keep = e[i] >= thr && e[i] != 0ull;
-      const unsigned long long b = __builtin_amdgcn_ballot_w64(keep);
-      if (keep) unsorted[base + prefix_below(b)] = e[i];
-      base += __popcll(b);
-    }
-  }
-  DEVA_COMPILER_FENCE();
-  // ---- from here on: affinity_finalize_kernel's tail
+  uint64_t best;  // lane r: the r-th best key
   const bool live = lane < k;
-  const uint64_t cand = live ? unsorted[lane] : 0ull;
-  int rank = 0;
-  for (int j = 0; j < k; ++j) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cand, j);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cand >> 32), j);
-    rank += ((((uint64_t)hi << 32) | lo) > cand) ? 1 : 0;
+  if (total <= 64) {
+    // one round (the usual case): rank counting over the <= 64 unique keys selects AND sorts
+    const uint64_t key = e[0];
+    int rank = 0;
+    for (int j = 0; j < total; ++j) {
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, j);
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), j);
+      rank += ((((uint64_t)hi << 32) | lo) > key) ? 1 : 0;
+    }
+    if (lane < total && rank < k) sorted[rank] = key;
+    DEVA_COMPILER_FENCE();
+    best = live ? sorted[lane] : 0ull;
+  } else {
+    const int rounds = (total + 63) / 64;
+    const uint64_t thr = kth_largest<PF_RESC_MAX / 64>(e, rounds, k);
+    int base_k = 0;
+#pragma unroll
+    for (int i = 0; i < PF_RESC_MAX / 64; ++i) {
+      if (i < rounds) {
+        const bool keep = e[i] >= thr && e[i] != 0ull;
+        const unsigned long long b = __builtin_amdgcn_ballot_w64(keep);
+        if (keep) unsorted[base_k + prefix_below(b)] = e[i];
+        base_k += __popcll(b);
+      }
+    }
+    DEVA_COMPILER_FENCE();
+    const uint64_t cand = live ? unsorted[lane] : 0ull;
+    int rank = 0;
+    for (int j = 0; j < k; ++j) {
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cand, j);
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cand >> 32), j);
+      rank += ((((uint64_t)hi << 32) | lo) > cand) ? 1 : 0;
+    }
+    DEVA_COMPILER_FENCE();
+    if (live) sorted[rank] = cand;
+    DEVA_COMPILER_FENCE();
+    best = live ? sorted[lane] : 0ull;
   }
-  DEVA_COMPILER_FENCE();
-  if (live) sorted[rank] = cand;
-  DEVA_COMPILER_FENCE();
-  const uint64_t mine = live ? sorted[lane] : 0ull;  // lane r holds the r-th best
+  // ---- from here on: affinity_finalize_kernel's tail
   if (p.out_keys) {
-    if (live) p.out_keys[(int64_t)q * CAP + lane] = (mine & 0xffffffff00000000ull) | (uint64_t)(~(~(uint32_t)mine + p.token_offset));
+    if (live) p.out_keys[(int64_t)q * CAP + lane] = (best & 0xffffffff00000000ull) | (uint64_t)(~(~(uint32_t)best + p.token_offset));
     if (lane == 0) p.out_cnt[q] = (uint32_t)k;
     return;
   }
-  const float score = from_orderable((uint32_t)(mine >> 32));
-  const uint32_t token = ~(uint32_t)mine;
+  const float score = from_orderable((uint32_t)(best >> 32));
+  const uint32_t token = ~(uint32_t)best;
   const float ex = live ? expf(score) : 0.0f;
   float sum = 0.0f;
   for (int r = 0; r < k; ++r) sum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ex), r));
@@ -2050,7 +2118,10 @@ extern "C" int deva_readout_sparse(const int32_t* idx, const float* weight, int 
 
 // ------------------------------------------------------------------ fp16 pre-filter + exact re-scoring (host side)
 static int g_prefilter = -1;  // -1: DEVA_AFFINITY_PREFILTER not read yet; 0 = never, 1 = automatic (default)
-constexpr int PF_MIN_TOKENS = 2048;  // below this the five launches cost more than the fp32 kernels need
+// below these the six launches cost more than the fp32 kernels need (profiles/r03_affinity_read.txt: 65 vs 40 us at
+// 2 048 x 1 620, 81 vs 89 us at 10 000 x 1 620 before the query operands were hoisted)
+constexpr int PF_MIN_TOKENS = 4096;
+constexpr int64_t PF_MIN_SCORES = 8000000;
 
 static int pf_qg(int hw) { return hw >= 4096 ? 2 : 1; }  // query groups per wave (large frames: half the operand traffic)
 
@@ -2067,7 +2138,7 @@ static int pf_splits(int n_total, int hw) {
 
 struct PfLayout {
   int splits, tiles, old_splits;
-  int64_t off_state, off_a16, off_gmax, off_thr, off_cand, off_cnt, off_part, bytes;
+  int64_t off_state, off_a16, off_bq16, off_gmax, off_thr, off_cand, off_cnt, off_part, bytes;
 };
 
 static PfLayout pf_layout(int n_total, int hw, int k) {
@@ -2081,6 +2152,8 @@ static PfLayout pf_layout(int n_total, int hw, int k) {
   o += 2048;  // PfState, then the stats kernel's [64][4] partial maxima
   L.off_a16 = o;
   o += align((int64_t)L.tiles * PF_TILE_BYTES);
+  L.off_bq16 = o;
+  o += align(ceil_div(hw, QT) * PF_TILE_BYTES);
   L.off_gmax = o;
   o += align((int64_t)L.splits * hw * PF_GROUPS * 4);
   L.off_thr = o;
@@ -2100,8 +2173,7 @@ extern "C" int deva_affinity_prefilter_enabled(int n_total, int hw, int k) {
     const char* e = getenv("DEVA_AFFINITY_PREFILTER");
     g_prefilter = (e && atoi(e) == 0) ? 0 : 1;
   }
-  (void)hw;
-  return g_prefilter && n_total >= PF_MIN_TOKENS && k >= 1 && k <= K_MAX;
+  return g_prefilter && n_total >= PF_MIN_TOKENS && (int64_t)n_total * hw >= PF_MIN_SCORES && k >= 1 && k <= K_MAX;
 }
 
 extern "C" int deva_affinity_force_prefilter(int mode) {
@@ -2149,7 +2221,10 @@ extern "C" int deva_affinity_read(const float* key_long, const float* shr_long, 
     const int n_pad = L.tiles * TOKT;
     hipLaunchKernelGGL(affinity_pf_prep_kernel, dim3((unsigned)ceil_div((int64_t)n_pad * 2, 256)), dim3(256), 0, st, b,
                        stat_part, state, n_pad, base + L.off_a16);
+    hipLaunchKernelGGL(affinity_pf_query_kernel, dim3((unsigned)ceil_div(hw, 4 * QT)), dim3(256), 0, st, qk, qe, hw, state,
+                       base + L.off_bq16);
     PfArgs a;
+    a.bq16 = base + L.off_bq16;
     a.a16 = base + L.off_a16;
     a.n_total = (int)n_total;
     a.total_tiles = L.tiles;
