@@ -132,14 +132,17 @@ def _assert_identical(tag, a, b):
     assert torch.equal(u0.view(torch.int32), u1.view(torch.int32)), f'{tag}: usage counters differ'
 
 
-@pytest.mark.parametrize('n,hw,scale,k,n_long', [(2048, 100, 1.0, 30, 0), (5000, 1620, 2.0, 30, 1200), (10001, 513, 1.0, 30, 7),
-                                                 (40000, 257, 0.3, 30, 39999), (3000, 33, 30.0, 30, 0),
-                                                 (8200, 1, 1.0, 5, 100), (4096, 128, 0.01, 32, 0)])
+@pytest.mark.parametrize('n,hw,scale,k,n_long', [(4096, 2000, 1.0, 30, 0), (5000, 1620, 2.0, 30, 1200), (10001, 801, 1.0, 30, 7),
+                                                 (40000, 257, 0.3, 30, 39999), (5000, 1700, 30.0, 30, 0),
+                                                 (8200, 4100, 1.0, 5, 100), (4096, 2048, 0.01, 32, 0),
+                                                 (6000, 4099, 1.0, 30, 0)])
 def test_fp16_prefilter_is_bit_identical_to_the_fp32_kernels(n, hw, scale, k, n_long):
     """deva_affinity_read: fp16 MFMA bounds -> group-maxima threshold -> candidates -> exact fp32 re-scoring must
     reproduce the fp32 kernels bit for bit (indices, order, weights, usage) WITHOUT falling back, on ragged sizes,
     a long + working bank, large / tiny key magnitudes (the operand scales are data-dependent powers of two)"""
     mk, ms, qk, qe = synth.affinity_inputs(n, hw, seed=n + hw, key_scale=scale)
+    from deva.hip import lib
+    assert lib().deva_affinity_prefilter_enabled(n, hw, k) == 1, 'shape below the library\'s pre-filter policy'
     fp32, pre, flag = _both_paths(mk, ms, qk, qe, k, n_long)
     _assert_identical(f'n{n}hw{hw}', fp32, pre)
     assert flag == 0, f'the pre-filter fell back (flag {flag})'
@@ -149,7 +152,7 @@ def test_fp16_prefilter_falls_back_where_its_bound_does_not_hold():
     """inputs outside the bound's premises must raise the device flag and still give the fp32 kernels' result:
     a negative selection value (the Cauchy-Schwarz step needs qe >= 0), a non-finite key, and a flat bank (every
     token identical: every score is a candidate, the sub-lists overflow)"""
-    n, hw, k = 4096, 96, 30
+    n, hw, k = 8192, 1024, 30  # (large enough for the library to choose the pre-filter)
     mk, ms, qk, qe = synth.affinity_inputs(n, hw, seed=5)
     qe_neg = qe.clone()
     qe_neg[3, 17] = -0.25
@@ -171,7 +174,7 @@ def test_fp16_prefilter_shard_keys_equal_the_fp32_select():
     """the hand-over format of a bank shard (affinity_candidates) through both paths"""
     if os.environ.get('DEVA_TEST_DRYRUN') == '1':
         pytest.skip('kernel-path property: nothing to compare on the emulated ops')
-    n, hw, k = 6000, 200, 30
+    n, hw, k = 6000, 1400, 30
     mk, ms, qk, qe = synth.affinity_inputs(n, hw, seed=9)
     rows, shr = to_dev(mk.t().contiguous()), to_dev(ms.reshape(-1).contiguous())
     new = ops.affinity_candidates(None, None, 0, rows, shr, n, to_dev(qk), to_dev(qe), k, token_offset=12345)

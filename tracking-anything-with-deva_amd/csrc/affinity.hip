@@ -1550,7 +1550,8 @@ __global__ __launch_bounds__(PF_QW * 64, 2) void affinity_pf_pass_kernel(const P
     const uint8_t* src = p.bq16 + (int64_t)group * PF_TILE_BYTES + lane * 16;
 #pragma unroll
     for (int kb = 0; kb < PF_KB; ++kb) bq[u][kb] = *reinterpret_cast<const h8*>(src + kb * 1024);
-    thr[u] = PASS ? p.thr[q[u]] : 0.0f;
+    // a lane without a query (ragged last group) must never file a candidate into the clamped query's sub-list
+    thr[u] = PASS ? (q_ok[u] ? p.thr[q[u]] : INFINITY) : 0.0f;
     ccnt[u] = 0u;
     my_list[u] = p.cand + (((int64_t)q[u] * p.splits + split) * 2 + half) * PF_SUB;
 #pragma unroll
