@@ -1617,6 +1617,8 @@ __global__ __launch_bounds__(PF_QW * 64, 2) void affinity_pf_pass_kernel(const P
   int t = t0;
   if (t < t1f) load(xa, t);
   while (t < t1f) {
+    // (a workgroup barrier here, to keep the four waves on the same tile so that the L1 could merge their operand
+    // loads, was measured: 130.9 vs 128.3 us at 10 000 x 8 160 -- the passes are not bound by L2 bandwidth)
     if (t + 1 < t1f) load(xb, t + 1);
     process(xa, t, std::true_type{});
     if (t + 1 >= t1f) break;
