@@ -23,6 +23,10 @@ MIN_OCCUPANCY = {
     'affinity_topk_wg_kernelILi704ELi1ELi8E': 2,
     'affinity_topk_kernelILi100ELi2ELb0ELb1E': 2,
     'conv_igemm_kernelILi128ELi128E': 4,
+    'affinity_pf_pass_kernelILi0ELi2E': 2,
+    'affinity_pf_pass_kernelILi1ELi2E': 2,
+    'affinity_pf_pass_kernelILi0ELi1E': 2,
+    'affinity_pf_pass_kernelILi1ELi1E': 2,
 }
 
 

@@ -51,3 +51,5 @@ for f in glob.glob('gpurun_out/readprof/**/read_kernel_stats.csv', recursive=Tru
         print(f"{r['Name'][:70]:70s} calls {r['Calls']:>5s} avg {float(r['AverageNs'])/1e3:9.1f} us total {float(r['TotalDurationNs'])/1e6:8.2f} ms")
 PY
 fi
+if has pmcread; then bash tools/pmc_read.sh read; fi
+if has pmcbench; then bash tools/pmc_bench.sh; fi

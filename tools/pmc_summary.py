@@ -126,5 +126,48 @@ def aff(prefix, out):
     print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != 'raw_per_dispatch'} for k, v in res.items()}, indent=1))
 
 
+def read(prefix, out):
+    """per-dispatch averages of every kernel of deva_affinity_read at N = 10 000 x HW = 8 160 (tools/pmc_read.sh)"""
+    counters, durations = load(prefix)
+    n, hw = 10000, 8160
+    res = {'shape': f'N={n} x HW={hw}, k=30', 'algorithmic_bytes': 4.0 * (64 * n + n + 2 * 64 * hw) + 8.0 * 30 * hw + 4.0 * n,
+           'kernels': {}}
+    for name in sorted(counters):
+        if not name.startswith('affinity_'):
+            continue
+        c = {k: v[0] / v[1] for k, v in counters[name].items()}
+        d_ns, d_n = durations[name]
+        entry = {'avg_duration_us_under_counters': d_ns / d_n / 1e3, 'dispatches': d_n}
+        if 'GRBM_GUI_ACTIVE' in c:
+            active = c['GRBM_GUI_ACTIVE'] / 8.0  # summed over the 8 XCDs
+            if 'SQ_VALU_MFMA_BUSY_CYCLES' in c and active > 0:
+                entry['mfma_util_frac'] = c['SQ_VALU_MFMA_BUSY_CYCLES'] / (active * 1024)
+        if 'SQ_WAVE_CYCLES' in c and c['SQ_WAVE_CYCLES'] > 0:
+            entry['wave_cycle_shares'] = {k: c[k] / c['SQ_WAVE_CYCLES'] for k in
+                                          ('SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_ACTIVE_INST_VALU')
+                                          if k in c}
+        if c.get('SQ_INSTS_MFMA', 0) > 0:
+            entry['instructions_per_mfma'] = {k: c[k] / c['SQ_INSTS_MFMA'] for k in
+                                              ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_VMEM') if k in c}
+        if 'FETCH_SIZE' in c:
+            entry['hbm_read_bytes (FETCH_SIZE KiB x 1024 x 2)'] = c['FETCH_SIZE'] * 2048
+        if 'WRITE_SIZE' in c:
+            entry['hbm_write_bytes (WRITE_SIZE KiB x 1024)'] = c['WRITE_SIZE'] * 1024
+        if 'TCC_HIT_sum' in c and 'TCC_MISS_sum' in c and c['TCC_HIT_sum'] + c['TCC_MISS_sum'] > 0:
+            entry['l2_hit_rate'] = c['TCC_HIT_sum'] / (c['TCC_HIT_sum'] + c['TCC_MISS_sum'])
+        entry['raw_per_dispatch'] = c
+        res['kernels'][name] = entry
+    pf = [k for k in res['kernels'] if k.startswith('affinity_pf_')]
+    tot = lambda key: sum(res['kernels'][k].get(key, 0.0) for k in pf)
+    res['prefilter_total'] = {'hbm_read_bytes': tot('hbm_read_bytes (FETCH_SIZE KiB x 1024 x 2)'),
+                              'hbm_write_bytes': tot('hbm_write_bytes (WRITE_SIZE KiB x 1024)')}
+    res['prefilter_total']['hbm_bytes'] = res['prefilter_total']['hbm_read_bytes'] + res['prefilter_total']['hbm_write_bytes']
+    res['prefilter_total']['traffic_over_algorithmic'] = res['prefilter_total']['hbm_bytes'] / res['algorithmic_bytes']
+    with open(out, 'w') as f:
+        json.dump(res, f, indent=1)
+    slim = {k: {kk: vv for kk, vv in v.items() if kk != 'raw_per_dispatch'} for k, v in res['kernels'].items()}
+    print(json.dumps({'prefilter_total': res['prefilter_total'], 'kernels': slim}, indent=1))
+
+
 if __name__ == '__main__':
-    {'conv': conv, 'aff': aff}[sys.argv[1]](sys.argv[2], sys.argv[3])
+    {'conv': conv, 'aff': aff, 'read': read}[sys.argv[1]](sys.argv[2], sys.argv[3])
