@@ -226,6 +226,9 @@ int64_t deva_affinity_read_scratch(int n_total, int hw, int k);
 int deva_affinity_prefilter_enabled(int n_total, int hw, int k);
 int deva_affinity_force_prefilter(int mode);
 int deva_affinity_read_flag(const uint64_t* scratch, void* stream);
+/* test / tuning hook (synchronises): out[5] = {fall-back flag, largest candidate sub-list, largest candidate count of a
+ * query, mean candidates per query x 1000, token ranges} of the last pre-filtered read on `scratch` */
+int deva_affinity_read_stats(const uint64_t* scratch, int n_total, int hw, int k, int64_t* out, void* stream);
 
 /* KeyValueMemoryStore.update_bucket_usage (kv_memory_store.py:118-125) for one segment:
  * use[i] += usage_fix[offset+i] * 2^-40 (if use != NULL), life[i] += 1 (if life != NULL), and
@@ -237,10 +240,13 @@ int deva_usage_update(uint64_t* usage_fix, int64_t offset, float* use, float* li
  * out[c][q] = sum_j weight[q][j] * value(idx[q][j])[c], value rows token-major [n][cv] in the
  * same long-then-work index space.  out is [cv][hw] (an NCHW plane stack).  Only tokens in
  * [tok_lo, tok_hi) contribute (pass 0, INT_MAX for the whole bank): a bank shard adds its own terms
- * and the partial read-outs are summed over the shards. */
+ * and the partial read-outs are summed over the shards.
+ * map_long / map_work (NULL = identity): value-sharded storage -- the value arenas hold only the rows this rank
+ * owns; map[token within the segment] = local row, < 0 = the row lives on another rank (its owner adds that term). */
 int deva_readout_sparse(const int32_t* idx, const float* weight, int hw, int k,
                         const float* val_long, int n_long, const float* val_work, int cv,
-                        float* out, int tok_lo, int tok_hi, void* stream);
+                        float* out, int tok_lo, int tok_hi, const int32_t* map_long,
+                        const int32_t* map_work, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Bank maintenance (KeyValueMemoryStore.add / sieve_by_range / remove_obsolete_features,

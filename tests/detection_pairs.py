@@ -84,7 +84,7 @@ def run(tag, hip, orc, H, W, frames, every, detection_of, make_info, noisy=None,
                 print(f'{tag} frame {t} (detection): merged masks differ from the clean reference at '
                       f'{int((a.argmax(0) != c.argmax(0)).sum())} pixels; forward-argmax pixels adopted so far {merged_px}')
         else:
-            drift.add(a, b, c, d if c is not None else None, frame=t, adopted_so_far=adopted + merged_px)
+            drift.add(a, b, c, d, frame=t, adopted_so_far=adopted + merged_px)
         hip_seg.clear()
         orc_seg.clear()
         assert hip.object_manager.num_obj == len(orc.table), t

@@ -150,13 +150,30 @@ def usage_update(usage_fix, offset, use, life, n):
     seg.zero_()
 
 
-def readout_sparse(idx, weight, val_long, n_long, val_work, out, tok_range=None):
+def readout_sparse(idx, weight, val_long, n_long, val_work, out, tok_range=None, row_map_long=None, row_map_work=None):
     hw, k = idx.shape
     cv = out.shape[0]
+    w = weight
+    if row_map_long is not None or row_map_work is not None:
+        # value-sharded storage: token -> local row of its segment's arena, < 0 = another rank's row (weight 0)
+        t = idx.long()
+        is_long = t < n_long
+        seg = torch.where(is_long, t, t - n_long)
+        loc = torch.full_like(seg, -1)
+        if n_long:
+            loc = torch.where(is_long, (row_map_long.long()[seg.clamp(max=row_map_long.numel() - 1)] if row_map_long is not None else seg), loc)
+        loc = torch.where(~is_long, (row_map_work.long()[seg.clamp(min=0, max=row_map_work.numel() - 1)] if row_map_work is not None else seg), loc)
+        w = torch.where(loc >= 0, w, torch.zeros_like(w))
+        rows_l = val_long if n_long else val_work
+        g = torch.where(is_long.reshape(-1, 1), rows_l[loc.clamp(min=0).clamp(max=rows_l.shape[0] - 1).reshape(-1)],
+                        val_work[loc.clamp(min=0).clamp(max=val_work.shape[0] - 1).reshape(-1)]).reshape(hw, k, cv)
+        if tok_range is not None:
+            w = torch.where((idx >= tok_range[0]) & (idx < tok_range[1]), w, torch.zeros_like(w))
+        out.copy_((g * w[:, :, None]).sum(1).t().reshape(out.shape))
+        return out
     n_work_needed = int(idx.max().item()) + 1 - n_long
     vals = _bank(val_long, n_long, val_work, max(n_work_needed, 0))
     g = vals[idx.long().reshape(-1)].reshape(hw, k, cv)
-    w = weight
     if tok_range is not None:
         w = torch.where((idx >= tok_range[0]) & (idx < tok_range[1]), weight, torch.zeros_like(weight))
     out.copy_((g * w[:, :, None]).sum(1).t().reshape(out.shape))

@@ -90,10 +90,13 @@ def test_1080p_detections_10k_bank_against_oracle(network, recipe_state_dict):
     (H, W), frames, every = FULL_HD, 12, 5
     cfg = synth.base_config(mem_every=3, max_missed_detection_count=5, max_num_objects=-1)
     hip = DEVAInferenceCore(network, cfg)
-    orc, clean, noisy = (O.OracleDetectionCore(P, cfg) for _ in range(3))
+    orc, noisy = (O.OracleDetectionCore(P, cfg) for _ in range(2))
+    # (a third, plain oracle as the "clean" reference costs another 30 s: profiles/r03a/test_gpu_g_fullsize.log holds
+    # that run -- HIP vs clean 1.14e-2 beside the reference's own drift 1.02e-2; the floor below is measured against
+    # the tie-following run, which is the clean one up to the adopted ties)
     report, _ = detection_pairs.run('1080p/detections/10k-bank', hip, orc, H, W, frames, every,
                                     lambda t: synth.detection_frame(H, W, t, segments=1), ObjectInfo, noisy=noisy,
-                                    clean=clean, prefill=detection_pairs.prefill_10k, same_ids=False)
+                                    prefill=detection_pairs.prefill_10k, same_ids=False)
     assert hip.memory.long_mem.size(0) == orc.memory.long.size(0) == 10000
     print('1080p detections clip:', json.dumps({k: float(f'{v:.3g}') for k, v in report.items()}))
 

@@ -112,6 +112,19 @@ def _run(rank, world, port, name, mode, out):
     _, rec = scenarios.run_scenario(Recording, sc)
     core = rec.core
     got = state(core)
+    if mode == 'bank':
+        # store-level ownership (VERDICT r2 missing 2): every rank holds ~1/world of the value rows of both stores
+        mem = core.memory
+        for store in (mem.work_mem, mem.long_mem) if mem.use_long_term else (mem.work_mem,):
+            for b in store.buckets:
+                n, mine = store.size(b), store.local_size(b)
+                lrow = store.row_map(b)[:n]
+                assert int((lrow >= 0).sum()) == mine and sorted(lrow[lrow >= 0].tolist()) == list(range(mine))
+                assert abs(mine - n / world) <= n / world * 0.35 + 2 * world, (rank, b, n, mine)
+                owned = torch.zeros(n)
+                owned[lrow >= 0] = 1
+                dist.all_reduce(owned)
+                assert bool((owned == 1).all()), 'every value row must live on exactly one rank'
     assert core.memory.comm_bytes > 0
     if mode == 'owner' and rank != 0:
         assert all(p is None for p in outs)

@@ -1206,7 +1206,9 @@ __global__ __launch_bounds__(256) void readout_sparse_kernel(const int32_t* __re
                                                              const float* __restrict__ weight, int hw, int k,
                                                              const float* __restrict__ val_long, int n_long,
                                                              const float* __restrict__ val_work, int cv,
-                                                             float* __restrict__ out, int tok_lo, int tok_hi) {
+                                                             float* __restrict__ out, int tok_lo, int tok_hi,
+                                                             const int32_t* __restrict__ map_long,
+                                                             const int32_t* __restrict__ map_work) {
   __shared__ float tile[RC][RQ + 1];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -1223,7 +1225,14 @@ __global__ __launch_bounds__(256) void readout_sparse_kernel(const int32_t* __re
         const int t = idx[(int64_t)q * k + j];
         if (t < tok_lo || t >= tok_hi) continue;  // token of another bank shard: its owner adds that term
         const float w = weight[(int64_t)q * k + j];
-        const float* row = (t < n_long) ? (val_long + (int64_t)t * cv) : (val_work + (int64_t)(t - n_long) * cv);
+        // value-sharded storage: the arenas hold this rank's rows only; map[token] = local row, < 0 = another rank's
+        int r = (t < n_long) ? t : t - n_long;
+        const int32_t* map = (t < n_long) ? map_long : map_work;
+        if (map) {
+          r = map[r];
+          if (r < 0) continue;
+        }
+        const float* row = ((t < n_long) ? val_long : val_work) + (int64_t)r * cv;
         const float4 v = *reinterpret_cast<const float4*>(row + c0 + cl);
         acc.x += w * v.x;
         acc.y += w * v.y;
@@ -1265,7 +1274,18 @@ __global__ __launch_bounds__(256) void readout_sparse_kernel(const int32_t* __re
 //   (S = power-of-two scale of the query, see pf_query_operand; the d margin of 33 % over 2^-10 absorbs the fp32
 //   round-off of the reference chain itself, ~70 * 2^-24 relative to P).
 //
-// Five kernels, no LDS lists, no prune rounds, no workgroup barriers:
+// Centering.  On real clips the keys share a large common component (the best-matching tokens have mk ~ qk), so
+// A, B and bsq are ~200x the score they cancel to and a 2^-10 relative bound on P would let thousands of tokens
+// through (measured on the 1080p clip: 480 - 6 200 candidates per query).  The distance is invariant under a
+// common shift, sum qe (mk - qk)^2 = sum qe ((mk - mu) - (qk - mu))^2, so both sides are centred on the bank's mean
+// key mu before they are rounded to fp16 (fp32 subtractions: relative error 2^-24 of the CENTRED value): P shrinks
+// 35x on that clip and the same bound admits ~37 candidates.  The fp32 round-off of the REFERENCE chain is relative
+// to its uncentred terms, P_unc <= 2 P + 4 m sum qe mu^2: the first part is inside d2, the second is the per-query
+// constant E_q = 4e-5 * max m * sum_c qe_c mu_c^2 (8e-6 relative round-off of the 64-step fp32 chains x 4, + margin)
+// subtracted from the filter threshold twice like ABS.
+//
+// Kernels (no LDS lists, no prune rounds, no workgroup barriers):
+//   pf_mean     per-block partial channel sums of the bank -> mu;
 //   pf_stats    max of mk^2 m, 2|mk| m, m over the bank -> power-of-two scales that put the largest operand
 //               just under 2^15 (fp16 max 65 504); non-finite input -> fall-back flag;
 //   pf_prep     the bank as fp16 MFMA A-operands, tile-major [tile][9 K-blocks][64 lanes][8 halfs]: every
@@ -1291,16 +1311,18 @@ constexpr int PF_QW = 4;                      // waves (32 queries each) per wor
 constexpr int PF_SUB = 32;                    // candidate slots per (range, query, half-lane)
 constexpr int PF_MAX_SPLITS = 32;
 constexpr int PF_GROUPS = 32;                 // group maxima per (range, query): one per token slot of the tiles
-constexpr int PF_RESC_MAX = 256;              // candidates re-scored per query (4 rounds of 64)
-constexpr float PF_D2 = 2.61e-3f;             // 2 d / (1 - d), d = 1.3e-3
+constexpr int PF_RESC_MAX = 512;              // candidates re-scored per query (8 rounds of 64)
+constexpr float PF_D2 = 2.63e-3f;             // 2 d / (1 - d), d = 1.3e-3, + 2e-5 for the reference's fp32 round-off on 2 P
 constexpr float PF_ABS = 600.0f;              // operands below 2^-14 (flushed or subnormal): 2 chains x 2^-14 x 2 x 65 x 2^15
 
-struct PfState {     // device block, zeroed before every read
+struct PfState {     // device block, written by the prep kernel of every read
   uint32_t flag;     // != 0: the fp32 kernels take over
-  uint32_t max_p;    // float bits: max mk^2 m
-  uint32_t max_q;    // max 2 |mk| m
+  uint32_t max_p;    // float bits: max (mk - mu)^2 m
+  uint32_t max_q;    // max 2 |mk - mu| m
   uint32_t max_m;    // max m
+  float mu[CK];      // mean key of the bank (the common shift of both operand sides)
 };
+constexpr float PF_EQ = 4e-5f;  // reference fp32 round-off carried by the shift: E_q = PF_EQ * max m * sum qe mu^2
 
 // power of two P with x * P in [2^14, 2^15)
 __device__ __forceinline__ float pf_scale(float x) {
@@ -1338,10 +1360,35 @@ __device__ __forceinline__ const float* pf_row(const PfBank& b, int n, float* ms
 
 constexpr int PF_STAT_BLOCKS = 64;
 
-// grid-stride over (token, 16 channels); every block leaves its partial maxima (and a bad-input mark) in
-// part[block][4] -- no atomics, nothing to zero beforehand
-__global__ __launch_bounds__(256) void affinity_pf_stats_kernel(const PfBank b, uint32_t* __restrict__ part) {
+// grid-stride over tokens: per-block partial channel sums of the keys -> sums[block][64] (thread = channel x 4 token lanes)
+__global__ __launch_bounds__(256) void affinity_pf_mean_kernel(const PfBank b, float* __restrict__ sums) {
+  __shared__ float s_part[4][CK];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  float acc = 0.0f;
+  for (int n = blockIdx.x * 4 + g; n < b.n_total; n += PF_STAT_BLOCKS * 4) {
+    float ms;
+    acc += pf_row(b, n, &ms)[c];
+  }
+  s_part[g][c] = acc;
+  __syncthreads();
+  if (g == 0) sums[blockIdx.x * CK + c] = (s_part[0][c] + s_part[1][c]) + (s_part[2][c] + s_part[3][c]);
+}
+
+// grid-stride over (token, 16 channels); every block first forms mu from the partial sums, then leaves its partial
+// maxima of the CENTRED operands (and a bad-input mark) in part[block][4] -- no atomics, nothing to zero beforehand
+__global__ __launch_bounds__(256) void affinity_pf_stats_kernel(const PfBank b, const float* __restrict__ sums,
+                                                                 uint32_t* __restrict__ part, float* __restrict__ mu_out) {
   __shared__ float s_red[4][4];
+  __shared__ float s_mu[CK];
+  if (threadIdx.x < CK) {
+    float t = 0.0f;
+    for (int i = 0; i < PF_STAT_BLOCKS; ++i) t += sums[i * CK + threadIdx.x];
+    t = t / (float)b.n_total;
+    t = (t == t && fabsf(t) < INFINITY) ? t : 0.0f;  // (non-finite banks fall back anyway)
+    s_mu[threadIdx.x] = t;
+    if (blockIdx.x == 0) mu_out[threadIdx.x] = t;
+  }
+  __syncthreads();
   float mp = 0.0f, mq = 0.0f, mm = 0.0f;
   bool bad = false;
   const int total = b.n_total * 4;
@@ -1357,8 +1404,8 @@ __global__ __launch_bounds__(256) void affinity_pf_stats_kernel(const PfBank b, 
       const f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * j);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const float a = fabsf(v[u]);
-        bad = bad || !(a < INFINITY);
+        bad = bad || !(fabsf(v[u]) < INFINITY);
+        const float a = fabsf(v[u] - s_mu[16 * (i & 3) + 4 * j + u]);
         mp = fmaxf(mp, a * a * m);
         mq = fmaxf(mq, 2.0f * a * m);
       }
@@ -1428,7 +1475,7 @@ __global__ __launch_bounds__(256) void affinity_pf_prep_kernel(const PfBank b, c
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(row + 16 * kb + 8 * half + 4);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float a = e < 4 ? v0[e] : v1[e - 4];
+        const float a = (e < 4 ? v0[e] : v1[e - 4]) - st->mu[16 * kb + 8 * half + e];  // centred on the bank's mean key
         out[kb][e] = (_Float16)(a * a * m * sp);
         out[5 + kb][e] = (_Float16)(2.0f * a * m * sq);
       }
@@ -1460,17 +1507,21 @@ struct PfArgs {
 // of (bank scale x largest query scale that keeps the group below 2^15).  Raises the fall-back flag for a
 // negative or non-finite selection / key.
 __device__ __forceinline__ void pf_query_operand(const float* __restrict__ qk, const float* __restrict__ qe, int hw, int q,
-                                                 int half, const PfState* st, h8 (&bq)[PF_KB], bool* bad_out) {
+                                                 int half, const PfState* st, h8 (&bq)[PF_KB], bool* bad_out,
+                                                 float* eq_out) {
   float e_[32], p_[32];
-  float bsq = 0.0f, e_max = 0.0f, p_max = 0.0f;
+  float bsq = 0.0f, e_max = 0.0f, p_max = 0.0f, mq2 = 0.0f;
   bool bad = false;
 #pragma unroll
   for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int c = 16 * kb + 8 * half + e;
-      const float ev = qe[(int64_t)c * hw + q], kv = qk[(int64_t)c * hw + q];
-      bad = bad || !(ev >= 0.0f && ev < INFINITY) || !(fabsf(kv) < INFINITY);
+      const float ev = qe[(int64_t)c * hw + q], kraw = qk[(int64_t)c * hw + q];
+      const float mu_c = st->mu[c];
+      const float kv = kraw - mu_c;  // centred like the bank
+      mq2 += ev * (mu_c * mu_c);
+      bad = bad || !(ev >= 0.0f && ev < INFINITY) || !(fabsf(kraw) < INFINITY);
       e_[8 * kb + e] = ev;
       p_[8 * kb + e] = kv * ev;
       bsq += ev * (kv * kv);
@@ -1479,6 +1530,7 @@ __device__ __forceinline__ void pf_query_operand(const float* __restrict__ qk, c
     }
   // both half-lanes of a query end up with the same values
   const float bsq_o = __shfl_xor(bsq, 32, 64), e_o = __shfl_xor(e_max, 32, 64), p_o = __shfl_xor(p_max, 32, 64);
+  mq2 += __shfl_xor(mq2, 32, 64);
   bsq = half ? (bsq_o + bsq) : (bsq + bsq_o);
   e_max = fmaxf(e_max, e_o);
   p_max = fmaxf(p_max, p_o);
@@ -1498,14 +1550,16 @@ __device__ __forceinline__ void pf_query_operand(const float* __restrict__ qk, c
 #pragma unroll
   for (int e = 0; e < 8; ++e) bq[4][e] = (_Float16)0.0f;
   if (half == 0) bq[4][0] = (_Float16)(bsq * tb);
-  *bad_out = bad;
+  *bad_out = bad || !(mq2 < INFINITY);
+  *eq_out = PF_EQ * __uint_as_float(st->max_m) * mq2 * S;  // in the query's scaled units, like ABS
 }
 
 // one wave per 32 queries: the fp16 query operands of both passes, computed ONCE per read (every (range, pass) wave
 // used to rebuild them: 64 strided loads and the scale logic per query group, which at ~20 tiles per wave cost as
 // much as the tiles).  Layout like the bank operand: [query group][9 K-blocks][64 lanes][8 halfs].
 __global__ __launch_bounds__(256) void affinity_pf_query_kernel(const float* __restrict__ qk, const float* __restrict__ qe,
-                                                                 int hw, PfState* st, uint8_t* __restrict__ bq16) {
+                                                                 int hw, PfState* st, uint8_t* __restrict__ bq16,
+                                                                 float* __restrict__ eq) {
   const int lane = threadIdx.x & 63;
   const int group = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int q0 = group * QT;
@@ -1513,8 +1567,10 @@ __global__ __launch_bounds__(256) void affinity_pf_query_kernel(const float* __r
   const int l31 = lane & 31, half = lane >> 5;
   h8 bq[PF_KB];
   bool bad;
-  pf_query_operand(qk, qe, hw, min(q0 + l31, hw - 1), half, st, bq, &bad);
+  float e_q;
+  pf_query_operand(qk, qe, hw, min(q0 + l31, hw - 1), half, st, bq, &bad, &e_q);
   if (__builtin_amdgcn_ballot_w64(bad && q0 + l31 < hw) && lane == 0) atomicOr(&st->flag, 2u);
+  if (half == 0 && q0 + l31 < hw) eq[q0 + l31] = e_q;
   uint8_t* dst = bq16 + (int64_t)group * PF_TILE_BYTES + lane * 16;
 #pragma unroll
   for (int kb = 0; kb < PF_KB; ++kb) *reinterpret_cast<h8*>(dst + kb * 1024) = bq[kb];
@@ -1558,19 +1614,23 @@ __global__ __launch_bounds__(PF_QW * 64, 2) void affinity_pf_pass_kernel(const P
     for (int r = 0; r < 16; ++r) g[u][r] = -INFINITY;
   }
 
-  const int t0 = (int)(((int64_t)p.total_tiles * split) / p.splits);
-  const int t1 = (int)(((int64_t)p.total_tiles * (split + 1)) / p.splits);
+  // token ranges are TILE-CYCLIC (range s owns tiles s, s + S, ...): a video memory holds the same location once per
+  // memory frame, hw tokens apart -- with contiguous ranges those near-duplicates (the best matches of a query) share
+  // one (range, slot) group, whose single maximum then says little about the k-th best, and one half-lane sub-list
+  const int n_my = (p.total_tiles - split + p.splits - 1) / p.splits;
+  const int t0 = 0, t1 = n_my;  // visit index; tile = split + visit * splits
   const uint8_t* mine = p.a16 + lane * 16;
-  auto load = [&](h8 (&x)[PF_KB], int tile) __attribute__((always_inline)) {
-    const uint8_t* base = mine + (int64_t)tile * PF_TILE_BYTES;
+  auto load = [&](h8 (&x)[PF_KB], int visit) __attribute__((always_inline)) {
+    const uint8_t* base = mine + (int64_t)(split + visit * p.splits) * PF_TILE_BYTES;
 #pragma unroll
     for (int kb = 0; kb < PF_KB; ++kb) x[kb] = *reinterpret_cast<const h8*>(base + kb * 1024);
   };
   const float c_lo = -(1.0f + PF_D2), c_hi = -(1.0f - PF_D2);
 
   // full: every token slot of the tile is inside the bank (all tiles but possibly the last one of the bank)
-  auto process = [&](const h8 (&x)[PF_KB], int tile, auto full) __attribute__((always_inline)) {
+  auto process = [&](const h8 (&x)[PF_KB], int visit, auto full) __attribute__((always_inline)) {
     constexpr bool full_tile = decltype(full)::value;
+    const int tile = split + visit * p.splits;
     const int rows_left = p.n_total - tile * TOKT;
     const uint32_t tok0 = (uint32_t)(tile * TOKT + 4 * half);
 #pragma unroll
@@ -1611,7 +1671,7 @@ __global__ __launch_bounds__(PF_QW * 64, 2) void affinity_pf_pass_kernel(const P
   };
 
   // the bank's ragged last tile (if this range holds it) is peeled off the loop
-  const bool ragged = (t1 == p.total_tiles) && (p.n_total % TOKT != 0) && (t1 > t0);
+  const bool ragged = (n_my > 0) && (split + (n_my - 1) * p.splits == p.total_tiles - 1) && (p.n_total % TOKT != 0);
   const int t1f = ragged ? t1 - 1 : t1;
   h8 xa[PF_KB], xb[PF_KB];
   int t = t0;
@@ -1649,8 +1709,8 @@ __global__ __launch_bounds__(PF_QW * 64, 2) void affinity_pf_pass_kernel(const P
 // the order-preserving score bits (rounded DOWN: still a valid lower bound, at most 2^-9 relative below the exact
 // value -- a fraction of the bound's own width --, usually exact through the early exit) minus the absolute slack
 constexpr int PF_TAU_E = PF_MAX_SPLITS * PF_GROUPS / 64;
-__global__ __launch_bounds__(256) void affinity_pf_tau_kernel(const float* __restrict__ gmax, int hw, int k, int splits,
-                                                              float* __restrict__ thr) {
+__global__ __launch_bounds__(256) void affinity_pf_tau_kernel(const float* __restrict__ gmax, const float* __restrict__ eq,
+                                                              int hw, int k, int splits, float* __restrict__ thr) {
   const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= hw) return;
@@ -1681,7 +1741,7 @@ __global__ __launch_bounds__(256) void affinity_pf_tau_kernel(const float* __res
     }
   }
   // T == 0 (fewer than k groups hold tokens): -inf, every score becomes a candidate and the sub-lists overflow
-  if (lane == 0) thr[q] = (T == 0u ? -INFINITY : from_orderable(T)) - 2.0f * PF_ABS;
+  if (lane == 0) thr[q] = (T == 0u ? -INFINITY : from_orderable(T)) - 2.0f * (PF_ABS + eq[q]);
 }
 
 struct PfRescoreArgs {
@@ -2106,7 +2166,7 @@ extern "C" int deva_usage_update(uint64_t* usage_fix, int64_t offset, float* use
 
 extern "C" int deva_readout_sparse(const int32_t* idx, const float* weight, int hw, int k, const float* val_long,
                                    int n_long, const float* val_work, int cv, float* out, int tok_lo, int tok_hi,
-                                   void* stream) {
+                                   const int32_t* map_long, const int32_t* map_work, void* stream) {
   DEVA_REQUIRE(idx && weight && out && hw > 0 && k > 0 && cv > 0, "deva_readout_sparse: bad args");
   DEVA_REQUIRE(cv % 4 == 0, "deva_readout_sparse: value dim must be a multiple of 4");
   DEVA_REQUIRE(n_long == 0 || val_long, "deva_readout_sparse: null long-term values");
@@ -2115,7 +2175,7 @@ extern "C" int deva_readout_sparse(const int32_t* idx, const float* weight, int 
   DEVA_REQUIRE(vl && vw, "deva_readout_sparse: no value segment");
   dim3 grid((unsigned)ceil_div(hw, RQ), (unsigned)ceil_div(cv, RC));
   hipLaunchKernelGGL(readout_sparse_kernel, grid, dim3(256), 0, (hipStream_t)stream, idx, weight, hw, k, vl, n_long,
-                     vw, cv, out, tok_lo, tok_hi);
+                     vw, cv, out, tok_lo, tok_hi, map_long, map_work);
   return check_launch("deva_readout_sparse");
 }
 
@@ -2132,7 +2192,9 @@ static int pf_splits(int n_total, int hw) {
   const int tiles = (int)ceil_div(n_total, TOKT);
   const int qblocks = (int)ceil_div(hw, PF_QW * QT * pf_qg(hw));
   int s = (int)ceil_div(512, qblocks);  // two 4-wave workgroups per CU
-  if (s < 4) s = 4;                     // >= 128 groups per query: the k-th largest group maximum stays a tight bound
+  // >= 16 tile-cyclic ranges: 512 groups per query keep the k-th largest group maximum tight, and the near-duplicate
+  // tokens of consecutive memory frames spread over the ranges (measured on the 4K clip: 5 ranges -> sub-lists of 185)
+  if (s < 16) s = 16;
   if (s > tiles / 2) s = tiles / 2;     // >= 2 tiles per range
   if (s > PF_MAX_SPLITS) s = PF_MAX_SPLITS;
   if (s < 1) s = 1;
@@ -2141,7 +2203,7 @@ static int pf_splits(int n_total, int hw) {
 
 struct PfLayout {
   int splits, tiles, old_splits;
-  int64_t off_state, off_a16, off_bq16, off_gmax, off_thr, off_cand, off_cnt, off_part, bytes;
+  int64_t off_state, off_a16, off_bq16, off_gmax, off_thr, off_eq, off_cand, off_cnt, off_part, bytes;
 };
 
 static PfLayout pf_layout(int n_total, int hw, int k) {
@@ -2152,7 +2214,7 @@ static PfLayout pf_layout(int n_total, int hw, int k) {
   auto align = [](int64_t b) { return (b + 255) / 256 * 256; };
   int64_t o = 0;
   L.off_state = o;
-  o += 2048;  // PfState, then the stats kernel's [64][4] partial maxima
+  o += 512 + 1024 + PF_STAT_BLOCKS * CK * 4;  // PfState | [64][4] partial maxima | [64][64] partial channel sums
   L.off_a16 = o;
   o += align((int64_t)L.tiles * PF_TILE_BYTES);
   L.off_bq16 = o;
@@ -2160,6 +2222,8 @@ static PfLayout pf_layout(int n_total, int hw, int k) {
   L.off_gmax = o;
   o += align((int64_t)L.splits * hw * PF_GROUPS * 4);
   L.off_thr = o;
+  o += align((int64_t)hw * 4);
+  L.off_eq = o;
   o += align((int64_t)hw * 4);
   L.off_cand = o;
   o += align((int64_t)L.splits * hw * 2 * PF_SUB * 8);
@@ -2219,13 +2283,15 @@ extern "C" int deva_affinity_read(const float* key_long, const float* shr_long, 
     b.key_work = key_work ? key_work : key_long;
     b.shr_work = shr_work ? shr_work : shr_long;
     b.n_total = (int)n_total;
-    uint32_t* stat_part = reinterpret_cast<uint32_t*>(base + L.off_state + 64);  // [PF_STAT_BLOCKS][4], after the state
-    hipLaunchKernelGGL(affinity_pf_stats_kernel, dim3(PF_STAT_BLOCKS), dim3(256), 0, st, b, stat_part);
+    uint32_t* stat_part = reinterpret_cast<uint32_t*>(base + L.off_state + 512);  // [PF_STAT_BLOCKS][4], after the state
+    float* sums = reinterpret_cast<float*>(base + L.off_state + 512 + 1024);     // [PF_STAT_BLOCKS][64]
+    hipLaunchKernelGGL(affinity_pf_mean_kernel, dim3(PF_STAT_BLOCKS), dim3(256), 0, st, b, sums);
+    hipLaunchKernelGGL(affinity_pf_stats_kernel, dim3(PF_STAT_BLOCKS), dim3(256), 0, st, b, sums, stat_part, state->mu);
     const int n_pad = L.tiles * TOKT;
     hipLaunchKernelGGL(affinity_pf_prep_kernel, dim3((unsigned)ceil_div((int64_t)n_pad * 2, 256)), dim3(256), 0, st, b,
                        stat_part, state, n_pad, base + L.off_a16);
     hipLaunchKernelGGL(affinity_pf_query_kernel, dim3((unsigned)ceil_div(hw, 4 * QT)), dim3(256), 0, st, qk, qe, hw, state,
-                       base + L.off_bq16);
+                       base + L.off_bq16, reinterpret_cast<float*>(base + L.off_eq));
     PfArgs a;
     a.bq16 = base + L.off_bq16;
     a.a16 = base + L.off_a16;
@@ -2247,7 +2313,8 @@ extern "C" int deva_affinity_read(const float* key_long, const float* shr_long, 
     } else {
       hipLaunchKernelGGL((affinity_pf_pass_kernel<0, 1>), grid, dim3(PF_QW * 64), 0, st, a);
     }
-    hipLaunchKernelGGL(affinity_pf_tau_kernel, dim3((unsigned)ceil_div(hw, 4)), dim3(256), 0, st, a.gmax, hw, k, L.splits,
+    hipLaunchKernelGGL(affinity_pf_tau_kernel, dim3((unsigned)ceil_div(hw, 4)), dim3(256), 0, st, a.gmax,
+                       reinterpret_cast<const float*>(base + L.off_eq), hw, k, L.splits,
                        reinterpret_cast<float*>(base + L.off_thr));
     if (qg == 2) {
       hipLaunchKernelGGL((affinity_pf_pass_kernel<1, 2>), grid, dim3(PF_QW * 64), 0, st, a);
@@ -2294,4 +2361,42 @@ extern "C" int deva_affinity_read_flag(const uint64_t* scratch, void* stream) {
   if (hipMemcpyAsync(&flag, scratch, sizeof(flag), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return -1;
   if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
   return (int)flag;
+}
+
+// test / tuning hook: candidate statistics of the last pre-filtered read on `scratch` (synchronises the stream):
+// out[0] = fall-back flag, out[1] = largest sub-list count (capacity 32 per (range, query, half-lane)), out[2] = largest
+// number of candidates of one query, out[3] = mean candidates per query x 1000, out[4] = ranges (splits)
+extern "C" int deva_affinity_read_stats(const uint64_t* scratch, int n_total, int hw, int k, int64_t* out, void* stream) {
+  DEVA_REQUIRE(scratch && out && hw > 0, "deva_affinity_read_stats: bad args");
+  const PfLayout L = pf_layout(n_total, hw, k);
+  const uint8_t* base = reinterpret_cast<const uint8_t*>(scratch);
+  const size_t n_cnt = (size_t)L.splits * hw * 2;
+  uint32_t* host = (uint32_t*)malloc(n_cnt * sizeof(uint32_t));
+  uint32_t flag = 0;
+  if (!host) return 1;
+  hipStream_t st = (hipStream_t)stream;
+  bool ok = hipMemcpyAsync(&flag, base + L.off_state, 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+            hipMemcpyAsync(host, base + L.off_cnt, n_cnt * 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+            hipStreamSynchronize(st) == hipSuccess;
+  if (ok) {
+    uint32_t max_sub = 0, max_q = 0;
+    uint64_t total = 0;
+    for (int q = 0; q < hw; ++q) {
+      uint32_t sum = 0;
+      for (int s = 0; s < L.splits * 2; ++s) {
+        const uint32_t c = host[(size_t)q * L.splits * 2 + s];
+        max_sub = c > max_sub ? c : max_sub;
+        sum += c;
+      }
+      max_q = sum > max_q ? sum : max_q;
+      total += sum;
+    }
+    out[0] = flag;
+    out[1] = max_sub;
+    out[2] = max_q;
+    out[3] = (int64_t)(total * 1000 / (uint64_t)hw);
+    out[4] = L.splits;
+  }
+  free(host);
+  return ok ? 0 : 1;
 }

@@ -60,7 +60,7 @@ SIGNATURES = {
     'deva_affinity_default_splits': (c_int, [c_int, c_int]),
     'deva_usage_update': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p]),
     'deva_readout_sparse': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
-                                    c_void_p, c_int, c_int, c_void_p]),
+                                    c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'deva_affinity_select': (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
     'deva_affinity_read': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
@@ -68,6 +68,7 @@ SIGNATURES = {
     'deva_affinity_prefilter_enabled': (c_int, [c_int, c_int, c_int]),
     'deva_affinity_force_prefilter': (c_int, [c_int]),
     'deva_affinity_read_flag': (c_int, [c_void_p, c_void_p]),
+    'deva_affinity_read_stats': (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_int64), c_void_p]),
     'deva_affinity_merge': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'deva_bank_append': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     'deva_bank_gather_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),

@@ -344,16 +344,20 @@ def usage_update(usage_fix: torch.Tensor, offset: int, use: Optional[torch.Tenso
 
 
 def readout_sparse(idx: torch.Tensor, weight: torch.Tensor, val_long, n_long: int, val_work,
-                   out: torch.Tensor, tok_range: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+                   out: torch.Tensor, tok_range: Optional[Tuple[int, int]] = None,
+                   row_map_long: Optional[torch.Tensor] = None, row_map_work: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out [cv, hw(...)] = sparse readout of token-major values ([>=n, cv] arenas); with tok_range =
-    (lo, hi) only the tokens lo <= t < hi contribute (partial read-out of one bank shard)"""
+    (lo, hi) only the tokens lo <= t < hi contribute (partial read-out of one bank shard); with row maps
+    (int32 [>= n], value-sharded storage) token t of a segment is row map[t] of its arena, < 0 = not on this rank"""
     hw, k = idx.shape
     cv = out.shape[0]
     if out.numel() != cv * hw:
         raise DevaHipError('readout_sparse: bad output shape')
     lo, hi = (0, (1 << 31) - 1) if tok_range is None else (int(tok_range[0]), int(tok_range[1]))
     check(lib().deva_readout_sparse(_p(idx, torch.int32), _p(weight), hw, k, _p(val_long) if n_long else None,
-                                    n_long, _p(val_work), cv, _p(out), lo, hi, _stream()), 'deva_readout_sparse')
+                                    n_long, _p(val_work), cv, _p(out), lo, hi,
+                                    _p(row_map_long, torch.int32) if n_long else None, _p(row_map_work, torch.int32),
+                                    _stream()), 'deva_readout_sparse')
     return out
 
 

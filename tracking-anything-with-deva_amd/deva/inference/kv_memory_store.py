@@ -40,6 +40,10 @@ class _Arena:
 class _Bucket:
     def __init__(self, ck: int, device, with_selection: bool, with_usage: bool):
         self.n = 0
+        # value-sharded storage (shard_values): local row of every token in this rank's value arenas (-1 = the
+        # row lives on another rank) and the number of rows this rank holds
+        self.lrow: Optional[torch.Tensor] = None
+        self.n_local = 0
         self.k = _Arena(ck, device)
         self.s = _Arena(1, device)
         self.e = _Arena(ck, device) if with_selection else None
@@ -62,6 +66,37 @@ class KeyValueMemoryStore:
         self._b: Dict[int, _Bucket] = {}
         self._v: Dict[int, _Arena] = {}
         self._obj_bucket: Dict[int, int] = {}
+        self._vshard: Optional[Tuple[int, int]] = None  # (rank, world) once shard_values() was called
+
+    # ------------------------------------------------------------------ value-sharded storage (several GPUs, one clip)
+    def shard_values(self, rank: int, world: int) -> None:
+        """From now on this store keeps only ITS share of the VALUE rows (the bulk of a memory token: CV = 512 floats
+        per object against 64 + 64 + 3 for key / selection / shrinkage / usage, which stay replicated because every
+        rank scores and ranks them).  Of every batch of tokens appended together (a memory frame, a set of
+        prototypes) rank r owns the contiguous block [n*r/world, n*(r+1)/world); ownership travels with the token
+        through sieves and evictions (`row_map`).  Must be called on an empty store."""
+        assert not self._b and not self._v, 'shard_values: the store already holds memory'
+        assert 0 <= rank < world
+        self._vshard = (rank, world)
+
+    def row_map(self, bucket_id: int) -> Optional[torch.Tensor]:
+        """int32 [>= size]: local value row of every token of the bucket, -1 = another rank's; None if not sharded"""
+        return self._b[bucket_id].lrow if self._vshard is not None else None
+
+    def local_size(self, bucket_id: int) -> int:
+        bk = self._b[bucket_id]
+        return bk.n_local if self._vshard is not None else bk.n
+
+    def local_rows(self, bucket_id: int, lo: int, hi: int) -> Tuple[int, int, Optional[torch.Tensor]]:
+        """tokens [lo, hi) of a bucket -> (first local row, one past the last local row, int64 offsets within
+        [lo, hi) of the tokens this rank owns); local rows keep the global order, so the range is contiguous.
+        Unsharded: (lo, hi, None).  One host synchronisation (memory events only)."""
+        if self._vshard is None:
+            return lo, hi, None
+        lrow = self._b[bucket_id].lrow
+        own = torch.nonzero(lrow[lo:hi] >= 0).flatten()
+        first = int((lrow[:lo] >= 0).sum().item())
+        return first, first + own.numel(), own
 
     # ------------------------------------------------------------------ internal accessors
     def bucket_of(self, obj: int) -> int:
@@ -128,6 +163,9 @@ class KeyValueMemoryStore:
             else:
                 ops.bank_append(src.contiguous(), dst, n_old)
 
+        if self._vshard is not None:
+            rank, world = self._vshard
+            i0, i1 = n_new * rank // world, n_new * (rank + 1) // world  # this rank's block of the batch
         for obj, val in values.items():
             if supposed_bucket_id >= 0:
                 b = supposed_bucket_id
@@ -138,7 +176,18 @@ class KeyValueMemoryStore:
             if obj not in self._v:
                 self._v[obj] = _Arena(val.shape[1] if token_major else val.shape[0], device)
                 self._obj_bucket[obj] = b
-            put(self._v[obj], val, self._b[b].n if b in self._b else 0)
+            if self._vshard is None:
+                put(self._v[obj], val, self._b[b].n if b in self._b else 0)
+            elif i1 > i0:
+                n_loc = self._b[b].n_local if b in self._b else 0
+                part = val[i0:i1] if token_major else val[:, i0:i1]
+                dst = self._v[obj].ensure(n_loc + (i1 - i0), n_loc)
+                if token_major:
+                    ops.bank_gather_rows(part.contiguous(), None, dst[n_loc:n_loc + (i1 - i0)], i1 - i0)
+                else:
+                    ops.bank_append(part.contiguous(), dst, n_loc)
+            else:
+                self._v[obj].ensure(1, 0)
 
         ck = key.shape[1] if token_major else key.shape[0]
         for b in touched:
@@ -154,6 +203,17 @@ class KeyValueMemoryStore:
                 life = bk.life.ensure(bk.n + n_new, bk.n)
                 use[bk.n:bk.n + n_new].zero_()
                 life[bk.n:bk.n + n_new].fill_(1e-7)  # kv_memory_store.py:93-95
+            if self._vshard is not None:
+                if bk.lrow is None or bk.lrow.numel() < bk.n + n_new:
+                    grown = torch.full((max(_MIN_ROWS, 2 * (bk.n + n_new)),), -1, dtype=torch.int32, device=device)
+                    if bk.lrow is not None:
+                        grown[:bk.n] = bk.lrow[:bk.n]
+                    bk.lrow = grown
+                bk.lrow[bk.n:bk.n + n_new] = -1
+                if i1 > i0:
+                    bk.lrow[bk.n + i0:bk.n + i1] = torch.arange(bk.n_local, bk.n_local + (i1 - i0), dtype=torch.int32,
+                                                                device=device)
+                bk.n_local += i1 - i0
             bk.n += n_new
 
     # ------------------------------------------------------------------ usage
@@ -187,7 +247,27 @@ class KeyValueMemoryStore:
         bk = self._b[bucket_id]
         total = sum((p[1] - p[0]) if isinstance(p[0], int) else p[1] for p in parts)
         arenas = [bk.k, bk.s] + ([bk.e] if bk.e else []) + ([bk.use, bk.life] if bk.use else [])
-        arenas += [self._v[o] for o in self.buckets[bucket_id]]
+        if self._vshard is None:
+            arenas += [self._v[o] for o in self.buckets[bucket_id]]
+        else:
+            # the kept tokens' local rows, in order; the survivors are renumbered 0 .. n_local-1
+            dev = bk.lrow.device
+            keep = torch.cat([torch.arange(p[0], p[1], device=dev) if isinstance(p[0], int) else p[0][:p[1]].long()
+                              for p in parts]) if parts else torch.zeros(0, dtype=torch.long, device=dev)
+            old_l = bk.lrow[keep]
+            mine = old_l >= 0
+            local_idx = old_l[mine].contiguous()
+            n_local = int(local_idx.numel())
+            new_lrow = torch.full_like(bk.lrow, -1)
+            new_lrow[:total] = torch.where(mine, (torch.cumsum(mine, 0) - 1).int(), torch.full_like(old_l, -1))
+            for o in self.buckets[bucket_id]:
+                a = self._v[o]
+                old = a.buf
+                a.buf = None
+                new = a.ensure(max(n_local, old.shape[0]), 0)
+                if n_local:
+                    ops.bank_gather_rows(old, local_idx, new[:n_local], n_local)
+            bk.lrow, bk.n_local = new_lrow, n_local
         for a in arenas:
             old = a.buf
             a.buf = None
@@ -241,6 +321,8 @@ class KeyValueMemoryStore:
         stop = n if end == 0 else (n + end if end < 0 else end)
         cnt = stop - start
         bk = self._b[bucket_id]
+        if self._vshard is not None:
+            raise NotImplementedError('get_all_sliced: the value rows of a sharded store live on several ranks')
         k = ops.bank_export(bk.k.buf[start:stop], cnt)
         sk = bk.s.buf[start:stop].clone().unsqueeze(0)
         ek = ops.bank_export(bk.e.buf[start:stop], cnt) if self.save_selection else None
@@ -278,7 +360,8 @@ class KeyValueMemoryStore:
 
     @property
     def value(self) -> Dict[int, torch.Tensor]:
-        return {o: ops.bank_export(a.buf, self.get_v_size(o)) for o, a in self._v.items()}
+        """reference layout {obj: CV x N}; a value-sharded store returns THIS RANK'S rows (CV x local_size)"""
+        return {o: ops.bank_export(a.buf, self.local_size(self._obj_bucket[o])) for o, a in self._v.items()}
 
     @property
     def shrinkage(self) -> Dict[int, torch.Tensor]:

@@ -78,6 +78,7 @@ class MemoryManager:
 
         self._usage_fix: Optional[torch.Tensor] = None  # int64 fixed-point usage scratch, kept zeroed
         self._shard_group = None  # torch.distributed group the memory read is sharded over
+        self._values_sharded = False  # shard_bank(shard_values=True): each rank stores 1/world of the value rows
         self._shard_mode: Optional[str] = None  # 'queries' | 'bank'
         self._shard_owner: Optional[int] = None  # group rank that owns the encoder / decoder (frame-owner mode)
         self.comm_bytes = 0  # bytes this rank sent + received in collectives since sharding was enabled
@@ -125,15 +126,20 @@ class MemoryManager:
         self._shard_owner = owner
         self.comm_bytes = 0
 
-    def shard_bank(self, group=None) -> None:
+    def shard_bank(self, group=None, shard_values: bool = True) -> None:
         """Partition every following `match_memory` by MEMORY TOKEN RANGE over `group` (SURVEY.md 8e
         "shard the bank"): rank r matches the queries against rows [r*per, (r+1)*per) of the virtual
         long-then-work bank only, the per-shard top-k candidates (64-bit score|token keys, hw*k*8 B per
         rank) are all-gathered and merged to the exact global top-k on every rank, each rank reads out
-        the value rows of its own range and the partial read-outs are summed (all-reduce).  The merged
-        selection, weights and usage counters are bit-identical to the unsharded read.  Storage is still
-        replicated (every rank appends every memory frame); dropping the rows a rank does not own is a
-        store-level follow-up that needs no further collective."""
+        the value rows it holds and the partial read-outs are summed (all-reduce).  The merged selection,
+        weights and usage counters are bit-identical to the unsharded read.
+
+        shard_values=True (default; call before the first memory frame): the STORAGE is partitioned too --
+        each rank keeps 1/world of the value rows of both stores (`KeyValueMemoryStore.shard_values`: of every
+        memory frame / prototype batch rank r appends only its block; sieves and evictions drop only local rows;
+        a consolidation forms the prototype values from the local candidate rows and all-reduces the P x CV
+        partial sums).  Keys, shrinkage, selection and usage counters (131 of the 131 + 512 x objects floats of a
+        token) stay replicated: every rank scores and ranks them, which is what keeps the decisions identical."""
         import torch.distributed as dist
         if not dist.is_initialized():
             raise RuntimeError('shard_bank: torch.distributed is not initialised')
@@ -144,6 +150,12 @@ class MemoryManager:
         self._shard_mode = 'bank'
         self._shard_owner = None
         self.comm_bytes = 0
+        self._values_sharded = bool(shard_values)
+        if shard_values:
+            rank, world = dist.get_rank(self._shard_group), dist.get_world_size(self._shard_group)
+            self.work_mem.shard_values(rank, world)
+            if self.use_long_term:
+                self.long_mem.shard_values(rank, world)
 
     @property
     def is_frame_owner(self) -> bool:
@@ -168,6 +180,13 @@ class MemoryManager:
     def _readout_into(self, out: torch.Tensor, idx, weight, bucket_id: int, obj: int, with_long: bool, n_long: int,
                       tok_range=None) -> None:
         obj_long = with_long and obj in self.long_mem
+        if getattr(self, '_values_sharded', False):
+            # value-sharded storage: this rank adds the terms of the rows it holds (tok_range does not apply)
+            ops.readout_sparse(idx, weight, self.long_mem.value_arena(obj) if obj_long else None,
+                               n_long if obj_long else 0, self.work_mem.value_arena(obj), out,
+                               row_map_long=self.long_mem.row_map(bucket_id) if obj_long else None,
+                               row_map_work=self.work_mem.row_map(bucket_id))
+            return
         ops.readout_sparse(idx, weight, self.long_mem.value_arena(obj) if obj_long else None,
                            n_long if obj_long else 0, self.work_mem.value_arena(obj), out, tok_range=tok_range)
 
@@ -288,7 +307,11 @@ class MemoryManager:
         n = n_long + n_work
         rank, world, per, lo = self._shard_range(n)
         if n < max(128, self.top_k + world) * world:  # first frames of a clip: every shard must hold >= top_k tokens
-            return self._read_bucket(bucket_id, bucket, qk, qe, rows)
+            self._read_bucket(bucket_id, bucket, qk, qe, rows)  # (every rank scores the whole replicated key bank)
+            if getattr(self, '_values_sharded', False):  # ... but holds only its share of the value rows
+                dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=self._shard_group)
+                self.comm_bytes += 2 * rows.numel() * 4 * (world - 1) // world
+            return
         hi = min(n, lo + per)
         hw = qk.shape[1]
         # this rank's rows of the virtual bank [long | work]
@@ -391,10 +414,12 @@ class MemoryManager:
         lo, hi = HW, n - (self.min_work_tokens - HW)
         objs = self.work_mem.buckets[bucket_id]
         use, life = self.work_mem.usage_arenas(bucket_id)
+        # value-sharded storage: this rank holds rows [v_lo, v_hi) of the candidates, `owned` = their offsets in [lo, hi)
+        v_lo, v_hi, owned = self.work_mem.local_rows(bucket_id, lo, hi)
         proto_key, proto_val, proto_shr = self.consolidation(
             self.work_mem.key_arena(bucket_id)[lo:hi], self.work_mem.shrinkage_arena(bucket_id)[lo:hi],
             self.work_mem.selection_arena(bucket_id)[lo:hi],
-            {o: self.work_mem.value_arena(o)[lo:hi] for o in objs}, (use[lo:hi], life[lo:hi]))
+            {o: self.work_mem.value_arena(o)[v_lo:v_hi] for o in objs}, (use[lo:hi], life[lo:hi]), owned_rows=owned)
         self.work_mem.sieve_by_range(bucket_id, HW, -self.min_work_tokens + HW,
                                      min_size=self.min_work_tokens + HW)
         self.long_mem.add(proto_key, proto_val, proto_shr, selection=None, supposed_bucket_id=bucket_id,
@@ -402,10 +427,12 @@ class MemoryManager:
 
     def consolidation(self, candidate_key: torch.Tensor, candidate_shrinkage: torch.Tensor,
                       candidate_selection: torch.Tensor, candidate_value: Dict[int, torch.Tensor],
-                      usage: Tuple[torch.Tensor, torch.Tensor]):
+                      usage: Tuple[torch.Tensor, torch.Tensor], owned_rows: Optional[torch.Tensor] = None):
         """memory_manager.py:251-276 on TOKEN-MAJOR candidates: key/selection [Nc,CK], shrinkage
         [Nc], values {obj: [Nc,CV]}, usage = (use_cnt, life_cnt) rows.  Returns token-major
-        prototype key [P,CK], values {obj: [P,CV]}, shrinkage [P]."""
+        prototype key [P,CK], values {obj: [P,CV]}, shrinkage [P].
+        owned_rows (value-sharded storage): `candidate_value` holds only the candidates this rank owns (their
+        offsets among the Nc candidates); the P x CV partial sums are all-reduced over the shard group."""
         n_cand = candidate_key.shape[0]
         P = self.num_prototypes
         # prototypes = the P candidates with the highest normalised usage (torch.topk, sorted)
@@ -418,7 +445,18 @@ class MemoryManager:
         proto_key = torch.empty((P, candidate_key.shape[1]), dtype=torch.float32, device=aff.device)
         ops.bank_gather_rows(candidate_key, proto_idx, proto_key, P)
         proto_val = {}
-        for obj, v in candidate_value.items():
+        if owned_rows is not None:
+            import torch.distributed as dist
+            n_own = int(owned_rows.numel())
+            gemm_own = ops.PackedConv(aff.index_select(0, owned_rows).contiguous(), None, n_own, P, aff.shape[1], 1, 1) if n_own else None
+            for obj, v in candidate_value.items():
+                cv = v.shape[1]
+                part = (ops.conv2d(gemm_own, v.contiguous().reshape(1, n_own, 1, cv)).view(P, cv) if n_own
+                        else torch.zeros((P, cv), dtype=torch.float32, device=aff.device))
+                dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self._shard_group)
+                self.comm_bytes += 2 * part.numel() * 4
+                proto_val[obj] = part
+        for obj, v in ([] if owned_rows is not None else candidate_value.items()):
             cv = v.shape[1]
             proto_val[obj] = ops.conv2d(gemm, v.reshape(1, n_cand, 1, cv)).view(P, cv)
         proto_shr = ops.conv2d(gemm, candidate_shrinkage.reshape(1, n_cand, 1, 1)).view(P)
