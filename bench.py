@@ -336,6 +336,41 @@ def run_long4k(net, device, steps, warmup, seed, shard, dist, size=(2160, 3840),
     return steps / elapsed, bank, (mem.comm_bytes - comm0) / steps
 
 
+def run_prefetched(net, device, cfg, height, width, num_objects, steps, warmup, seed):
+    """the headline loop with ONE addition: before frame t is stepped, the key encoder of frame t+1 is started on a
+    side stream (`ImageFeatureStore.prefetch`, an extension of this package -- the reference's drivers do not call
+    it).  Same kernels, same results; the encoder's latency-bound batch-1 launches overlap the decoder of frame t."""
+    from deva.utils.tensor_utils import pad_divide_by
+    n_frames = 1 + warmup + steps
+    frames = make_clip(height, width, n_frames + 1, seed=seed, device=device)
+    padded = [pad_divide_by(f, 16)[0].unsqueeze(0) for f in frames]
+    core = start_clip(net, cfg, frames, num_objects, device)
+
+    def step(t):
+        core.image_feature_store.prefetch(core.curr_ti + 2, padded[t + 1])
+        core.step(frames[t])
+
+    for t in range(1, 1 + warmup):
+        step(t)
+    elapsed = timed_region(lambda: [step(t) for t in range(1 + warmup, n_frames)], None, device)
+    core.image_feature_store.delete(core.curr_ti + 1)
+    return steps / elapsed
+
+
+def run_480p_single(net, device, steps, warmup, seed=100):
+    """BASELINE configs[0] shape on the GPU: 854x480, ONE object, default flags (long-term memory on) -- the regime
+    where the frame is short enough for launch gaps to show"""
+    from workload import synth
+    cfg = synth.base_config()
+    n_frames = 1 + warmup + steps
+    frames = make_clip(480, 854, n_frames, seed=seed, device=device)
+    core = start_clip(net, cfg, frames, 1, device)
+    for t in range(1, 1 + warmup):
+        core.step(frames[t])
+    elapsed = timed_region(lambda: [core.step(frames[t]) for t in range(1 + warmup, n_frames)], None, device)
+    return steps / elapsed
+
+
 def run_1080p(net, device, steps, warmup, detections, seed=7):
     """The 1080p lines (1920x1080, padded 1088x1920, ONE object, long-term memory pre-filled to 10 000 tokens):
     detections=False -- pure propagation (the north-star target line: >= 30 FPS with a 10k-element bank);
@@ -630,12 +665,25 @@ def main():
         result['affinity'] = affinity_microbench(device)
         if not args.no_extra:
             del core
+            fps480s = run_480p_single(net, device, steps=60, warmup=10)
+            fps_pref = run_prefetched(net, device, cfg, args.height, args.width, args.objects, args.steps, args.warmup,
+                                      seed=100)
             fps1080, state1080 = run_1080p(net, device, steps=25, warmup=6, detections=False)
             fps1080d, state1080d = run_1080p(net, device, steps=25, warmup=6, detections=True)
             fps1080s, state1080s = run_1080p_segments(net, device, steps=25, warmup=6, segments=8)
             fps4k, bank4k, _ = run_long4k(net, device, steps=20, warmup=5, seed=11, shard=None, dist=None)
             gate1080 = 'tests/test_gpu_g_fullsize.py::test_1080p_detections_10k_bank_against_oracle'
             result['also'] = [
+                {'metric': 'propagation FPS @480p (5 objects, working memory only) WITH next-frame key-encoder prefetch',
+                 'value': fps_pref, 'unit': 'frames/s', 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 / fps_pref,
+                 'config': {'workload': 'the headline clip and loop, plus ImageFeatureStore.prefetch(t+1) on a side stream before '
+                                        'every step (an extension: the unchanged drivers do not call it; identical results)'},
+                 'parity_gate': 'tests/test_gpu_e_network.py::test_prefetched_key_encoder_is_bit_identical'},
+                {'metric': 'propagation FPS @480p (1 object, default flags)', 'value': fps480s, 'unit': 'frames/s', 'steps': 60,
+                 'warmup': 10, 'ms_per_step': 1e3 / fps480s,
+                 'config': {'workload': 'BASELINE configs[0] shape on the GPU: synthetic 854x480 clip, one object, long-term '
+                                        'memory on (the launch-gap-sensitive regime)'},
+                 'parity_gate': 'tests/test_gpu_e_network.py::test_vos_example_against_reference_golden'},
                 {'metric': 'propagation FPS @1080p (1 object, 10k-token long-term bank)',
                  'value': fps1080, 'unit': 'frames/s', 'steps': 25, 'warmup': 6, 'ms_per_step': 1e3 / fps1080,
                  'config': {'workload': 'north-star target line: synthetic 1920x1080 clip (padded 1088x1920), one object '

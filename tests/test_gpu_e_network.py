@@ -198,6 +198,30 @@ def test_480p_five_objects_against_oracle(network, recipe_state_dict):
     _five_objects_480p('480p/5obj', network, recipe_state_dict[0], with_clean=False)
 
 
+def test_prefetched_key_encoder_is_bit_identical(network):
+    """ImageFeatureStore.prefetch (side-stream key encoder of the NEXT frame, an extension used by one bench line):
+    same outputs, bit for bit, as the plain loop"""
+    from deva.inference.inference_core import DEVAInferenceCore
+    from deva.utils.tensor_utils import pad_divide_by
+    H, W, no, frames = 96, 128, 2, 9
+    cfg = synth.base_config(mem_every=3)
+    stream = synth.FrameStream(H, W, seed=4)
+    imgs = [stream.next().to(dev()) for _ in range(frames + 1)]
+    mask0 = synth.box_mask(H, W, no).to(dev())
+    outs = {}
+    for mode in ('plain', 'prefetch'):
+        core = DEVAInferenceCore(network, cfg)
+        res = [core.step(imgs[0], mask0, [1, 2])]
+        for t in range(1, frames):
+            if mode == 'prefetch':
+                core.image_feature_store.prefetch(core.curr_ti + 2, pad_divide_by(imgs[t + 1], 16)[0].unsqueeze(0))
+            res.append(core.step(imgs[t]))
+        torch.cuda.synchronize()
+        core.image_feature_store.delete(core.curr_ti + 1)
+        outs[mode] = [r.cpu() for r in res]
+    assert all(torch.equal(a, b) for a, b in zip(outs['plain'], outs['prefetch']))
+
+
 def test_480p_lockstep_teacher_forced(network, recipe_state_dict):
     """Every stage of every frame at full 480x864 size on IDENTICAL inputs (tests/lockstep.py)."""
     import lockstep

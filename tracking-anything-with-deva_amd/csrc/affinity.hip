@@ -1151,8 +1151,11 @@ __global__ __launch_bounds__(256) void affinity_finalize_kernel(const uint64_t* 
     }
   }
   DEVA_COMPILER_FENCE();
+  // (fewer than k survivors only if scores are NaN -- a NaN fails every comparison of the selection; the reference's
+  // topk propagates NaN there: the missing slots get weight NaN / token 0 instead of uninitialised LDS contents)
   const bool live = lane < k;
-  const uint64_t cand = live ? unsorted[lane] : 0ull;
+  // placeholder of a missing slot: unique, below every real key, score bits of a NaN, token = lane (in range)
+  const uint64_t cand = (live && lane < base) ? unsorted[lane] : (uint64_t)(0xffffffffu - (uint32_t)lane);
   int rank = 0;
   for (int j = 0; j < k; ++j) {  // lane j's key, broadcast through SGPRs (j is wave-uniform)
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cand, j);
@@ -1308,10 +1311,10 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 constexpr int PF_KB = 9;                      // K-blocks of 16 halfs per token: 4 (P: mk^2 m) + 1 (P: m x bsq) + 4 (Q)
 constexpr int PF_TILE_BYTES = PF_KB * 64 * 16;  // [kb][lane][8 halfs]
 constexpr int PF_QW = 4;                      // waves (32 queries each) per workgroup, all on the same token range
-constexpr int PF_SUB = 32;                    // candidate slots per (range, query, half-lane)
+constexpr int PF_SUB = 64;                    // candidate slots per (range, query, half-lane)
 constexpr int PF_MAX_SPLITS = 32;
 constexpr int PF_GROUPS = 32;                 // group maxima per (range, query): one per token slot of the tiles
-constexpr int PF_RESC_MAX = 512;              // candidates re-scored per query (8 rounds of 64)
+constexpr int PF_RESC_MAX = 2048;             // candidates re-scored per query (up to 32 rounds of 64)
 constexpr float PF_D2 = 2.63e-3f;             // 2 d / (1 - d), d = 1.3e-3, + 2e-5 for the reference's fp32 round-off on 2 P
 constexpr float PF_ABS = 600.0f;              // operands below 2^-14 (flushed or subnormal): 2 chains x 2^-14 x 2 x 65 x 2^15
 
@@ -1358,7 +1361,7 @@ __device__ __forceinline__ const float* pf_row(const PfBank& b, int n, float* ms
   return b.key_work + (int64_t)(n - b.n_long) * CK;
 }
 
-constexpr int PF_STAT_BLOCKS = 64;
+constexpr int PF_STAT_BLOCKS = 256;
 
 // grid-stride over tokens: per-block partial channel sums of the keys -> sums[block][64] (thread = channel x 4 token lanes)
 __global__ __launch_bounds__(256) void affinity_pf_mean_kernel(const PfBank b, float* __restrict__ sums) {
@@ -1433,14 +1436,18 @@ __global__ __launch_bounds__(256) void affinity_pf_stats_kernel(const PfBank b, 
 // one thread per (token slot of the padded bank, half-lane): writes the 9 x 16 B this MFMA lane will load
 __global__ __launch_bounds__(256) void affinity_pf_prep_kernel(const PfBank b, const uint32_t* __restrict__ part,
                                                                 PfState* st, int n_pad, uint8_t* __restrict__ a16) {
-  // every block reduces the 64 partial maxima of the stats kernel itself (one wave, 256 B); block 0 publishes
+  // every block reduces the partial maxima of the stats kernel itself (one wave); block 0 publishes
   // them together with the cleared fall-back flag for the kernels that follow in the stream
   __shared__ float s_max[4];
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     float v[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) v[c] = wave_max_f(__uint_as_float(part[lane * 4 + c]));
+    for (int c = 0; c < 4; ++c) {
+      float m = 0.0f;
+      for (int i = lane; i < PF_STAT_BLOCKS; i += 64) m = fmaxf(m, __uint_as_float(part[i * 4 + c]));
+      v[c] = wave_max_f(m);
+    }
     if (lane == 0) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) s_max[c] = v[c];
@@ -1766,7 +1773,7 @@ struct PfRescoreArgs {
 // v_mfma_f32_32x32x2_f32: channels in natural order, mk^2 rounded before it enters the chain, qk*qe rounded
 // likewise), exact top-k, softmax / usage
 __global__ __launch_bounds__(256) void affinity_pf_rescore_kernel(const PfRescoreArgs p) {
-  __shared__ uint32_t s_tok[4][PF_RESC_MAX];
+  __shared__ uint64_t s_key[4][PF_RESC_MAX];  // candidate tokens, overwritten in place by their exact (score, token) keys
   __shared__ __attribute__((aligned(16))) float s_qe[4][CK];
   __shared__ __attribute__((aligned(16))) float s_qp[4][CK];
   __shared__ float s_term[4][CK];
@@ -1833,38 +1840,38 @@ __global__ __launch_bounds__(256) void affinity_pf_rescore_kernel(const PfRescor
     for (int u = 0; u < 4; ++u) ent[u] = (s0 + u < mine) ? my_sub[s0 + u] : 0ull;
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (s0 + u < mine) s_tok[wave][base + s0 + u] = (uint32_t)ent[u];
+      if (s0 + u < mine) s_key[wave][base + s0 + u] = ent[u] & 0xffffffffull;
   }
   DEVA_COMPILER_FENCE();
 
-  // ---- exact scores, 64 candidates per round
+  // ---- exact scores, 64 candidates per round (a real loop: the keys go to LDS, the registers of a round are reused)
+  for (int r0 = 0; r0 < total; r0 += 64) {
+    const int c = r0 + lane;
+    const bool live_c = c < total;
+    const uint32_t tok = live_c ? (uint32_t)s_key[wave][c] : 0u;
+    float ms;
+    const float* row = pf_row(p.bank, (int)tok, &ms);
+    float accA = 0.0f, accB = 0.0f;
+#pragma unroll
+    for (int j = 0; j < CK / 4; ++j) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(row + 4 * j);
+      const f32x4 qe4 = *reinterpret_cast<const f32x4*>(&s_qe[wave][4 * j]);
+      const f32x4 qp4 = *reinterpret_cast<const f32x4*>(&s_qp[wave][4 * j]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float a = x[u];
+        accA = __builtin_fmaf(a * a, qe4[u], accA);
+        accB = __builtin_fmaf(a, qp4[u], accB);
+      }
+    }
+    const float v = (((accB + accB) - accA) - bsq) * (ms * 0.125f);
+    s_key[wave][c] = live_c ? (((uint64_t)orderable(v) << 32) | (uint64_t)(~tok)) : 0ull;
+  }
+  DEVA_COMPILER_FENCE();
+  const int rounds = (total + 63) / 64;
   uint64_t e[PF_RESC_MAX / 64];
 #pragma unroll
-  for (int rr = 0; rr < PF_RESC_MAX / 64; ++rr) {
-    e[rr] = 0ull;
-    if (rr * 64 < total) {
-      const int c = rr * 64 + lane;
-      const bool live_c = c < total;
-      const uint32_t tok = live_c ? s_tok[wave][c] : 0u;
-      float ms;
-      const float* row = pf_row(p.bank, (int)tok, &ms);
-      float accA = 0.0f, accB = 0.0f;
-#pragma unroll
-      for (int j = 0; j < CK / 4; ++j) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(row + 4 * j);
-        const f32x4 qe4 = *reinterpret_cast<const f32x4*>(&s_qe[wave][4 * j]);
-        const f32x4 qp4 = *reinterpret_cast<const f32x4*>(&s_qp[wave][4 * j]);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float a = x[u];
-          accA = __builtin_fmaf(a * a, qe4[u], accA);
-          accB = __builtin_fmaf(a, qp4[u], accB);
-        }
-      }
-      const float v = (((accB + accB) - accA) - bsq) * (ms * 0.125f);
-      if (live_c) e[rr] = ((uint64_t)orderable(v) << 32) | (uint64_t)(~tok);
-    }
-  }
+  for (int rr = 0; rr < PF_RESC_MAX / 64; ++rr) e[rr] = (rr < rounds) ? s_key[wave][rr * 64 + lane] : 0ull;
   volatile uint64_t* unsorted = &s_buf[wave][0][0];
   volatile uint64_t* sorted = &s_buf[wave][1][0];
   uint64_t best;  // lane r: the r-th best key
@@ -1882,7 +1889,6 @@ __global__ __launch_bounds__(256) void affinity_pf_rescore_kernel(const PfRescor
     DEVA_COMPILER_FENCE();
     best = live ? sorted[lane] : 0ull;
   } else {
-    const int rounds = (total + 63) / 64;
     const uint64_t thr = kth_largest<PF_RESC_MAX / 64>(e, rounds, k);
     int base_k = 0;
 #pragma unroll
@@ -2214,7 +2220,7 @@ static PfLayout pf_layout(int n_total, int hw, int k) {
   auto align = [](int64_t b) { return (b + 255) / 256 * 256; };
   int64_t o = 0;
   L.off_state = o;
-  o += 512 + 1024 + PF_STAT_BLOCKS * CK * 4;  // PfState | [64][4] partial maxima | [64][64] partial channel sums
+  o += 512 + PF_STAT_BLOCKS * 16 + PF_STAT_BLOCKS * CK * 4;  // PfState | [blocks][4] partial maxima | [blocks][64] channel sums
   L.off_a16 = o;
   o += align((int64_t)L.tiles * PF_TILE_BYTES);
   L.off_bq16 = o;
@@ -2284,7 +2290,7 @@ extern "C" int deva_affinity_read(const float* key_long, const float* shr_long, 
     b.shr_work = shr_work ? shr_work : shr_long;
     b.n_total = (int)n_total;
     uint32_t* stat_part = reinterpret_cast<uint32_t*>(base + L.off_state + 512);  // [PF_STAT_BLOCKS][4], after the state
-    float* sums = reinterpret_cast<float*>(base + L.off_state + 512 + 1024);     // [PF_STAT_BLOCKS][64]
+    float* sums = reinterpret_cast<float*>(base + L.off_state + 512 + PF_STAT_BLOCKS * 16);  // [PF_STAT_BLOCKS][64]
     hipLaunchKernelGGL(affinity_pf_mean_kernel, dim3(PF_STAT_BLOCKS), dim3(256), 0, st, b, sums);
     hipLaunchKernelGGL(affinity_pf_stats_kernel, dim3(PF_STAT_BLOCKS), dim3(256), 0, st, b, sums, stat_part, state->mu);
     const int n_pad = L.tiles * TOKT;

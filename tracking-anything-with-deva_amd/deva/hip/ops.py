@@ -122,6 +122,15 @@ def _guard_elems(t: Optional[torch.Tensor]) -> int:
 
 _WORKSPACE = {}
 _WORKSPACE_ELEMS = 16 * 1024 * 1024  # 64 MB of split-K scratch per device
+_MAX_STREAM_CACHES = 8  # per-(device, stream) scratch caches are bounded: transient side streams must not pin HBM forever
+
+
+def _make_room(cache: dict) -> None:
+    """called before a NEW (device, stream) entry is inserted: drop the oldest entries beyond the bound (the caching
+    allocator keeps a dropped buffer alive until the kernels already queued on its stream have run)"""
+    while len(cache) >= _MAX_STREAM_CACHES:
+        cache.pop(next(iter(cache)))
+
 
 
 def _workspace(device) -> torch.Tensor:
@@ -129,6 +138,7 @@ def _workspace(device) -> torch.Tensor:
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _WORKSPACE.get(key)
     if ws is None:
+        _make_room(_WORKSPACE)
         ws = _WORKSPACE[key] = torch.empty(_WORKSPACE_ELEMS, dtype=torch.float32, device=device)
     return ws
 
@@ -291,6 +301,8 @@ def _affinity_workspace(elems: int, device) -> torch.Tensor:
     deva_affinity_finalize reads them"""
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _AFF_WS.get(key)
+    if ws is None:
+        _make_room(_AFF_WS)
     if ws is None or ws.numel() < elems:
         ws = _AFF_WS[key] = torch.empty((max(elems, 1 << 20),), dtype=torch.int64, device=device)
     return ws

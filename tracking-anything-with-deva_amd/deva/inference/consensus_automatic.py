@@ -19,6 +19,8 @@ programme is solved exactly by enumeration over its connected components (`solve
 from collections import defaultdict
 from typing import Dict, List, Literal, Tuple
 
+import warnings
+
 import numpy as np
 import torch
 
@@ -26,6 +28,10 @@ from deva.hip import ops
 from deva.inference.consensus_associated import spatial_alignment
 from deva.inference.object_info import ObjectInfo
 from deva.utils.tensor_utils import pad_divide_by, unpad
+
+
+_EXACT_COMPONENT_LIMIT = 22  # 4 M subsets at most
+_warned_large_component = False
 
 
 def solve_exact(pairwise_iou: np.ndarray, pairwise_iou_indicator: np.ndarray, total_segments: int) -> List[bool]:
@@ -51,6 +57,18 @@ def solve_exact(pairwise_iou: np.ndarray, pairwise_iou_indicator: np.ndarray, to
                     stack.append(v)
         comp.sort()
         best_val, best_set = 0.0, ()
+        if len(comp) > _EXACT_COMPONENT_LIMIT:
+            # matches are not transitive across frame pairs: a long voting window can chain many segments into one
+            # conflict component, and 2^|component| subsets would stall the host.  Greedy by weight instead (said once).
+            global _warned_large_component
+            if not _warned_large_component:
+                warnings.warn(f'consensus: a conflict component of {len(comp)} segments exceeds the exact solver\'s limit '
+                              f'({_EXACT_COMPONENT_LIMIT}); falling back to a greedy selection for it', RuntimeWarning)
+                _warned_large_component = True
+            for u in sorted(comp, key=lambda v: (-float(weight[v]), v)):
+                if weight[u] > 0 and not any(chosen[v] for v in conflict[u]):
+                    chosen[u] = True
+            continue
 
         def search(pos: int, picked: Tuple[int, ...], value: float, best):
             if pos == len(comp):

@@ -24,12 +24,41 @@ class ImageFeatureStore:
         self.network = network
         self.no_warning = no_warning
         self._store: Dict[int, _FrameFeatures] = {}
+        self._pending: Dict[int, 'torch.cuda.Event'] = {}  # prefetch(): entries still being computed on the side stream
+        self._side = None
 
     def _encode_feature(self, index: int, image: torch.Tensor) -> None:
         multi_scale, pix_feat = self.network.encode_image(image)
         self._store[index] = _FrameFeatures(multi_scale, pix_feat, *self.network.transform_key(pix_feat))
 
+    def prefetch(self, index: int, image: torch.Tensor) -> None:
+        """Extension (not in the reference): start the key encoder of frame `index` (1*3*H*W, padded like
+        `DEVAInferenceCore` pads it) on a SIDE stream, so that it overlaps with the decoder / memory work of the frame
+        the caller is about to step.  The key encoder depends on the image only; its batch-1 layers are launch-latency
+        bound and leave most of the GPU idle, which the large decoder kernels of the previous frame fill.  The first
+        `get_*` of that index waits for it.  Results are bit-identical to the unprefetched call (same kernels)."""
+        if index in self._store or not image.is_cuda:
+            return
+        main = torch.cuda.current_stream(image.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=image.device)
+        self._side.wait_stream(main)  # the image (and the weights) are ready
+        with torch.cuda.stream(self._side):
+            self._encode_feature(index, image)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        for t in (image, *self._tensors(self._store[index])):
+            t.record_stream(self._side if t is image else main)  # allocator: produced on one stream, consumed on the other
+        self._pending[index] = done
+
+    @staticmethod
+    def _tensors(entry: _FrameFeatures):
+        return (*entry.ms_features, entry.pix_feat, entry.key, entry.shrinkage, entry.selection)
+
     def _entry(self, index: int, image: torch.Tensor) -> _FrameFeatures:
+        done = self._pending.pop(index, None)
+        if done is not None:
+            torch.cuda.current_stream().wait_event(done)
         try:
             return self._store[index]
         except KeyError:
@@ -44,6 +73,7 @@ class ImageFeatureStore:
         return e.key, e.shrinkage, e.selection
 
     def delete(self, index) -> None:
+        self._pending.pop(index, None)
         self._store.pop(index, None)
 
     def __len__(self):

@@ -427,7 +427,7 @@ class MemoryManager:
 
     def consolidation(self, candidate_key: torch.Tensor, candidate_shrinkage: torch.Tensor,
                       candidate_selection: torch.Tensor, candidate_value: Dict[int, torch.Tensor],
-                      usage: Tuple[torch.Tensor, torch.Tensor], owned_rows: Optional[torch.Tensor] = None):
+                      usage: Tuple[torch.Tensor, torch.Tensor], *, owned_rows: Optional[torch.Tensor] = None):
         """memory_manager.py:251-276 on TOKEN-MAJOR candidates: key/selection [Nc,CK], shrinkage
         [Nc], values {obj: [Nc,CV]}, usage = (use_cnt, life_cnt) rows.  Returns token-major
         prototype key [P,CK], values {obj: [P,CV]}, shrinkage [P].
