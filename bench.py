@@ -22,7 +22,7 @@ Extra objects on the JSON line:
                 stays busy back to back, so an event pair brackets exactly the kernel(s) of its launch
                 at the clocks of the real frame loop.  peak = 157.3 TFLOP/s fp32 matrix.  `traffic` =
                 HBM bytes per frame of those kernels from the committed rocprofv3 --pmc passes over
-                this same command (profiles/pmc_r02/conv_traffic.json; bench.py cannot collect PMC
+                this same command (profiles/pmc_r03/conv_traffic.json; bench.py cannot collect PMC
                 counters itself), next to the algorithmic bytes per frame computed here.
   affinity      the north-star read (similarity -> exact top-k -> softmax -> usage): event-timed at the
                 BASELINE shape (N=10 000 bank, 1080p queries) through deva_affinity_read (fp16 MFMA
@@ -655,12 +655,12 @@ def main():
         }
         # HBM traffic of these kernels per frame, from the committed rocprofv3 --pmc passes over this same
         # command (tools/pmc_bench.sh; FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes)
-        pmc = os.path.join(ROOT, 'profiles', 'pmc_r02', 'conv_traffic.json')
+        pmc = os.path.join(ROOT, 'profiles', 'pmc_r03', 'conv_traffic.json')
         if os.path.exists(pmc):
             with open(pmc) as f:
                 d = json.load(f)
             result['roofline']['traffic'] = d['hbm_bytes_per_frame']
-            result['roofline']['traffic_source'] = 'profiles/pmc_r02/conv_traffic.json'
+            result['roofline']['traffic_source'] = 'profiles/pmc_r03/conv_traffic.json'
             result['roofline']['traffic_over_algorithmic'] = d['hbm_bytes_per_frame'] / (alg_bytes / n_replay)
         result['affinity'] = affinity_microbench(device)
         if not args.no_extra:
