@@ -194,7 +194,9 @@ int deva_affinity_merge(const uint64_t* keys, const uint32_t* counts, int hw, in
  * workgroups per CU with early key prefetch; 2: two per CU, late prefetch; 3: key tiles shared through LDS; 4, 5:
  * workgroup-shared lists, two / one 4-wave workgroup per CU; 7: ping-pong phases; 8: workgroup-shared lists, one 8-wave
  * workgroup per CU); 0 = automatic choice by frame and bank size (the default; the environment
- * variable DEVA_AFFINITY_SHAPE sets the initial value).  All shapes give bit-identical results.  Call between
+ * variable DEVA_AFFINITY_SHAPE sets the initial value).  All shapes give bit-identical results.  The product library
+ * carries shapes 2, 4 and 8 (the ones the automatic choice uses); 1, 3, 5, 6, 7 are A/B variants of `make PROBES=1`
+ * builds and are refused otherwise.  Call between
  * deva_affinity_default_splits / deva_affinity_workspace / deva_affinity_topk sequences, not inside one. */
 int deva_affinity_force_shape(int shape);
 /* workspace query: number of uint64 elements part_keys must hold */

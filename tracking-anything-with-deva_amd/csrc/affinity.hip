@@ -71,7 +71,7 @@ constexpr int QT = 32;            // queries per wave
 constexpr int CAP = 64;           // candidate slots per (range, query) handed to the merge kernel (one per lane)
 // in-kernel candidate lists: LCAP slots of 6 bytes (order-preserving score bits + 16-bit token offset
 // inside the range); row stride LCAP + 1 (odd: spreads the LDS banks).
-constexpr int LCAP_WIDE = 176;    // one workgroup per CU (136 KiB of lists)
+[[maybe_unused]] constexpr int LCAP_WIDE = 176;    // one workgroup per CU (136 KiB of lists; probe-build shapes 1 and 3)
 constexpr int LCAP_DUAL = 100;    // two workgroups per CU (2 x 76 KiB)
 constexpr int K_MAX = 32;          // top-k supported by the list / hand-over sizing below
 constexpr int MAX_SPLITS = 32;    // one 64-bit key per lane and range in the merge kernel
@@ -1957,7 +1957,11 @@ static int affinity_shape(int n_total, int hw) {
   if (g_forced_shape < 0) {
     const char* e = getenv("DEVA_AFFINITY_SHAPE");
     const int v = e ? atoi(e) : 0;
+#ifdef DEVA_AFFINITY_PROBES
     g_forced_shape = (v >= 1 && v <= 8) ? v : 0;
+#else
+    g_forced_shape = (v == 2 || v == 4 || v == 8) ? v : 0;
+#endif
   }
   if (g_forced_shape) return g_forced_shape;
   // measured (profiles/r02e_affinity_shapes.txt, total us of filter + finalize):
@@ -1974,6 +1978,12 @@ static int affinity_shape(int n_total, int hw) {
 
 extern "C" int deva_affinity_force_shape(int shape) {
   DEVA_REQUIRE(shape >= 0 && shape <= 8, "deva_affinity_force_shape: shape must be 0 (automatic) .. 8");
+#ifndef DEVA_AFFINITY_PROBES
+  // the product library carries the three shapes the automatic choice uses; 1, 3, 5, 6, 7 are A/B variants
+  // (bit-identical, slower: profiles/r02e_affinity_shapes.txt) of `make PROBES=1` builds
+  DEVA_REQUIRE(shape == 0 || shape == 2 || shape == 4 || shape == 8,
+               "deva_affinity_force_shape: shape %d is an A/B variant of probe builds (make PROBES=1)", shape);
+#endif
   g_forced_shape = shape;
   return 0;
 }
@@ -2076,18 +2086,13 @@ static int topk_fp32(const float* key_long, const float* shr_long, int n_long, c
   int shape = affinity_shape((int)n_total, hw);
   if (shape == 7 && (splits % 2 != 0 || ceil_div(a.total_tiles, splits / 2) > 2047)) shape = 4;  // needs list pairs
   switch (shape) {
+#ifdef DEVA_AFFINITY_PROBES  // A/B variants: bit-identical, slower (profiles/r02e_affinity_shapes.txt)
     case 7:
       hipLaunchKernelGGL((affinity_topk_pp_kernel<352>), dim3((unsigned)ceil_div(hw, QT), (unsigned)(splits / 2)),
                          dim3(PP_WAVES * 64), 0, (hipStream_t)stream, a);
       break;
-    case 8:
-      hipLaunchKernelGGL((affinity_topk_wg_kernel<704, 1, 8>), grid_wg, dim3(8 * 64), 0, (hipStream_t)stream, a);
-      break;
-    case 6:  // shape 2 with the early prefetch (operands copied out, next loads issued before the MFMAs) -- A/B probe
+    case 6:  // shape 2 with the early prefetch (operands copied out, next loads issued before the MFMAs)
       hipLaunchKernelGGL((affinity_topk_kernel<LCAP_DUAL, 2, false, false>), grid, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
-      break;
-    case 4:
-      hipLaunchKernelGGL((affinity_topk_wg_kernel<352, 2, WAVES>), grid_wg, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
       break;
     case 5:
       hipLaunchKernelGGL((affinity_topk_wg_kernel<704, 1, WAVES>), grid_wg, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
@@ -2095,11 +2100,18 @@ static int topk_fp32(const float* key_long, const float* shr_long, int n_long, c
     case 1:
       hipLaunchKernelGGL((affinity_topk_kernel<LCAP_WIDE, 1, false>), grid, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
       break;
-    case 2:  // key rows prefetched after the MFMAs, read in place (2-6 % faster than the early prefetch + copies)
-      hipLaunchKernelGGL((affinity_topk_kernel<LCAP_DUAL, 2, false, true>), grid, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
-      break;
-    default:
+    case 3:
       hipLaunchKernelGGL((affinity_topk_kernel<LCAP_WIDE, 1, true>), grid, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
+      break;
+#endif
+    case 8:
+      hipLaunchKernelGGL((affinity_topk_wg_kernel<704, 1, 8>), grid_wg, dim3(8 * 64), 0, (hipStream_t)stream, a);
+      break;
+    case 4:
+      hipLaunchKernelGGL((affinity_topk_wg_kernel<352, 2, WAVES>), grid_wg, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
+      break;
+    default:  // 2: key rows prefetched after the MFMAs, read in place (2-6 % faster than the early prefetch + copies)
+      hipLaunchKernelGGL((affinity_topk_kernel<LCAP_DUAL, 2, false, true>), grid, dim3(WAVES * 64), 0, (hipStream_t)stream, a);
   }
   return check_launch("deva_affinity_topk");
 }
