@@ -19,6 +19,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.environ.get('DEVA_REFERENCE_ROOT', '/root/reference')
 LAUNCH = os.path.join(ROOT, 'tests', 'run_reference_driver.py')
+# measured in the build container (emulated ops vs the reference): eval_vos <= 12 of 25 680 sampled pixels (0.05 %), all
+# at margins below 1e-2; eval_with_detections (semi-online voting on near-flat recipe probabilities) <= 0.64 % of the pixels
+MAX_FLIPPED_VOS, MAX_FLIPPED_DET = 0.002, 0.015
 
 pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, 'evaluation')),
                                 reason='needs the reference checkout (build container only)')
@@ -59,7 +62,8 @@ def test_eval_vos_unchanged_on_the_vos_example(tmp_path, checkpoint, golden_dir)
         got = png[::4, ::4]
         assert got.shape == want.shape
         assert int(((got != want) & decisive).sum()) == 0, f'frame {t}'
-        assert (got != want).mean() <= 0.02
+        print(f'eval_vos frame {t}: {int((got != want).sum())} of {got.size} sampled pixels differ from the reference argmax')
+        assert (got != want).mean() <= MAX_FLIPPED_VOS
 
 
 def test_eval_with_detections_unchanged_on_the_vipseg_example(tmp_path, checkpoint):
@@ -78,7 +82,8 @@ def test_eval_with_detections_unchanged_on_the_vipseg_example(tmp_path, checkpoi
         a = np.array(Image.open(os.path.join(ours, 'Annotations', vid, n)))
         b = np.array(Image.open(os.path.join(theirs, 'Annotations', vid, n)))
         assert a.shape == b.shape
-        assert (a != b).mean() <= 0.02, n       # hard masks: last-bit differences flip a few tied pixels
+        print(f'eval_with_detections {n}: {int((a != b).sum())} of {a.size} pixels differ from the reference alone')
+        assert (a != b).mean() <= MAX_FLIPPED_DET, n  # hard masks: last-bit differences flip a few tied pixels
     ja = json.load(open(os.path.join(ours, 'JSONFiles', f'{vid}.json')))
     jb = json.load(open(os.path.join(theirs, 'JSONFiles', f'{vid}.json')))
     ids = lambda j: [sorted(s['id'] for s in f['segments_info']) for f in j['annotations']]
