@@ -517,6 +517,65 @@ def long4k(args, net, rank, world, device, dist):
         dist.destroy_process_group()
 
 
+def extra_lines(net, device, cfg, args):
+    """the further lines of the metric (`also`): each with its own warm-up and timed frames, each naming its parity gate"""
+    def line(metric, run, steps, warmup, workload, gate, state_key=None, **more):
+        """one further line of the metric; a failure is reported in place and never costs the headline line"""
+        entry = {'metric': metric, 'unit': 'frames/s', 'steps': steps, 'warmup': warmup,
+                 'config': {'workload': workload}, 'parity_gate': gate, **more}
+        try:
+            out = run()
+            fps = out[0] if isinstance(out, tuple) else out
+            entry.update(value=fps, ms_per_step=1e3 / fps)
+            if state_key is not None:
+                entry['config'][state_key] = out[1]
+        except Exception as exc:  # noqa: BLE001
+            entry.update(value=None, error=f'{type(exc).__name__}: {exc}'[:400])
+            torch.cuda.synchronize()
+        return entry
+
+    gate1080 = 'tests/test_gpu_g_fullsize.py::test_1080p_detections_10k_bank_against_oracle'
+    return [
+        line('propagation FPS @480p (5 objects, working memory only) WITH next-frame key-encoder prefetch',
+             lambda: run_prefetched(net, device, cfg, args.height, args.width, args.objects, args.steps, args.warmup,
+                                    seed=100),
+             args.steps, args.warmup,
+             'the headline clip and loop, plus ImageFeatureStore.prefetch(t+1) on a side stream before every step (an '
+             'extension: the unchanged drivers do not call it; identical results)',
+             'tests/test_gpu_e_network.py::test_prefetched_key_encoder_is_bit_identical'),
+        line('propagation FPS @480p (1 object, default flags)',
+             lambda: run_480p_single(net, device, steps=60, warmup=10), 60, 10,
+             'BASELINE configs[0] shape on the GPU: synthetic 854x480 clip, one object, long-term memory on (the '
+             'launch-gap-sensitive regime)',
+             'tests/test_gpu_e_network.py::test_vos_example_against_reference_golden'),
+        line('propagation FPS @1080p (1 object, 10k-token long-term bank)',
+             lambda: run_1080p(net, device, steps=25, warmup=6, detections=False), 25, 6,
+             'north-star target line: synthetic 1920x1080 clip (padded 1088x1920), one object initialised from a '
+             'detection, long-term memory pre-filled to 10 000 tokens + working memory, pure propagation',
+             gate1080, 'state_at_end', target_fps=30.0),
+        line('propagation FPS @1080p (detections merged every 5th frame, 1 object, 10k-token long-term bank)',
+             lambda: run_1080p(net, device, steps=25, warmup=6, detections=True), 25, 6,
+             'the same clip with a fixed-box detection handed to incorporate_detection every 5th frame under '
+             '--max_num_objects 1: the detection is DISCARDED (segment_merging.py:115-122), so this line times the '
+             'forward pass + argmax + histogram of a detection frame, not a merge -- the 8-segment line below is '
+             'BASELINE configs[2]',
+             gate1080, 'state_at_end', target_fps=30.0),
+        line('propagation FPS @1080p (8-segment detections merged every 5th frame, ~10 live objects, 10k-token '
+             'long-term bank)',
+             lambda: run_1080p_segments(net, device, steps=25, warmup=6, segments=8), 25, 6,
+             'BASELINE configs[2] as SURVEY.md 8d defines it: tracker-consistent detections with 8 segments '
+             '(re-detections that match and merge, 2 new objects per detection in a new bucket, objects unseen twice '
+             'purged), online setting, no object cap',
+             'tests/test_gpu_g_fullsize.py::test_1080p_eight_segment_detections_against_oracle (3 segments at 1080p) + '
+             'tests/test_gpu_e_network.py::test_consistent_detection_clip_against_reference_golden', 'state_at_end'),
+        line('propagation FPS @4K (1 object, 50k-token long-term bank), one GPU',
+             lambda: run_long4k(net, device, steps=20, warmup=5, seed=11, shard=None, dist=None)[:2], 20, 5,
+             'BASELINE configs[4] on ONE GPU: synthetic 3840x2160 clip, 1 object, long-term memory pre-filled to '
+             '50 000 tokens',
+             'tests/test_gpu_g_fullsize.py::test_4k_lockstep + test_affinity_at_bench_shapes', 'bank_tokens_at_end'),
+    ]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -662,57 +721,14 @@ def main():
             result['roofline']['traffic'] = d['hbm_bytes_per_frame']
             result['roofline']['traffic_source'] = 'profiles/pmc_r03/conv_traffic.json'
             result['roofline']['traffic_over_algorithmic'] = d['hbm_bytes_per_frame'] / (alg_bytes / n_replay)
-        result['affinity'] = affinity_microbench(device)
+        try:
+            result['affinity'] = affinity_microbench(device)
+        except Exception as exc:  # noqa: BLE001  (never at the cost of the headline line)
+            result['affinity'] = {'error': f'{type(exc).__name__}: {exc}'[:400]}
+            torch.cuda.synchronize()
         if not args.no_extra:
             del core
-            fps480s = run_480p_single(net, device, steps=60, warmup=10)
-            fps_pref = run_prefetched(net, device, cfg, args.height, args.width, args.objects, args.steps, args.warmup,
-                                      seed=100)
-            fps1080, state1080 = run_1080p(net, device, steps=25, warmup=6, detections=False)
-            fps1080d, state1080d = run_1080p(net, device, steps=25, warmup=6, detections=True)
-            fps1080s, state1080s = run_1080p_segments(net, device, steps=25, warmup=6, segments=8)
-            fps4k, bank4k, _ = run_long4k(net, device, steps=20, warmup=5, seed=11, shard=None, dist=None)
-            gate1080 = 'tests/test_gpu_g_fullsize.py::test_1080p_detections_10k_bank_against_oracle'
-            result['also'] = [
-                {'metric': 'propagation FPS @480p (5 objects, working memory only) WITH next-frame key-encoder prefetch',
-                 'value': fps_pref, 'unit': 'frames/s', 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 / fps_pref,
-                 'config': {'workload': 'the headline clip and loop, plus ImageFeatureStore.prefetch(t+1) on a side stream before '
-                                        'every step (an extension: the unchanged drivers do not call it; identical results)'},
-                 'parity_gate': 'tests/test_gpu_e_network.py::test_prefetched_key_encoder_is_bit_identical'},
-                {'metric': 'propagation FPS @480p (1 object, default flags)', 'value': fps480s, 'unit': 'frames/s', 'steps': 60,
-                 'warmup': 10, 'ms_per_step': 1e3 / fps480s,
-                 'config': {'workload': 'BASELINE configs[0] shape on the GPU: synthetic 854x480 clip, one object, long-term '
-                                        'memory on (the launch-gap-sensitive regime)'},
-                 'parity_gate': 'tests/test_gpu_e_network.py::test_vos_example_against_reference_golden'},
-                {'metric': 'propagation FPS @1080p (1 object, 10k-token long-term bank)',
-                 'value': fps1080, 'unit': 'frames/s', 'steps': 25, 'warmup': 6, 'ms_per_step': 1e3 / fps1080,
-                 'config': {'workload': 'north-star target line: synthetic 1920x1080 clip (padded 1088x1920), one object '
-                                        'initialised from a detection, long-term memory pre-filled to 10 000 tokens + working '
-                                        'memory, pure propagation', 'state_at_end': state1080},
-                 'target_fps': 30.0, 'parity_gate': gate1080},
-                {'metric': 'propagation FPS @1080p (detections merged every 5th frame, 1 object, 10k-token long-term bank)',
-                 'value': fps1080d, 'unit': 'frames/s', 'steps': 25, 'warmup': 6, 'ms_per_step': 1e3 / fps1080d,
-                 'config': {'workload': 'the same clip with a fixed-box detection handed to incorporate_detection every 5th frame under '
-                                        '--max_num_objects 1: the detection is DISCARDED (segment_merging.py:115-122), so this line times '
-                                        'the forward pass + argmax + histogram of a detection frame, not a merge -- the 8-segment line '
-                                        'below is BASELINE configs[2]',
-                            'state_at_end': state1080d},
-                 'target_fps': 30.0, 'parity_gate': gate1080},
-                {'metric': 'propagation FPS @1080p (8-segment detections merged every 5th frame, ~10 live objects, '
-                           '10k-token long-term bank)',
-                 'value': fps1080s, 'unit': 'frames/s', 'steps': 25, 'warmup': 6, 'ms_per_step': 1e3 / fps1080s,
-                 'config': {'workload': 'BASELINE configs[2] as SURVEY.md 8d defines it: tracker-consistent detections with 8 '
-                                        'segments (re-detections that match and merge, 2 new objects per detection in a new '
-                                        'bucket, objects unseen twice purged), online setting, no object cap',
-                            'state_at_end': state1080s},
-                 'parity_gate': 'tests/test_gpu_g_fullsize.py::test_1080p_eight_segment_detections_against_oracle (3 segments '
-                                'at 1080p) + tests/test_gpu_e_network.py::test_consistent_detection_clip_against_reference_golden'},
-                {'metric': 'propagation FPS @4K (1 object, 50k-token long-term bank), one GPU',
-                 'value': fps4k, 'unit': 'frames/s', 'steps': 20, 'warmup': 5, 'ms_per_step': 1e3 / fps4k,
-                 'config': {'workload': 'BASELINE configs[4] on ONE GPU: synthetic 3840x2160 clip, 1 object, long-term '
-                                        'memory pre-filled to 50 000 tokens', 'bank_tokens_at_end': bank4k},
-                 'parity_gate': 'tests/test_gpu_g_fullsize.py::test_4k_lockstep + test_affinity_at_bench_shapes'},
-            ]
+            result['also'] = extra_lines(net, device, cfg, args)
         if not args.no_cpu_baseline and world == 1:
             frames_cpu = [f.cpu() for f in frames[:1 + min(args.cpu_frames, len(frames) - 1)]]
             result['cpu_baseline'] = cpu_baseline(sd, cfg, args.height, args.width, args.objects, frames_cpu)
