@@ -304,7 +304,9 @@ def _affinity_workspace(elems: int, device) -> torch.Tensor:
     if ws is None:
         _make_room(_AFF_WS)
     if ws is None or ws.numel() < elems:
-        ws = _AFF_WS[key] = torch.empty((max(elems, 1 << 20),), dtype=torch.int64, device=device)
+        # grow geometrically: the scratch of deva_affinity_read scales with the bank, which grows every memory frame --
+        # an exact-size buffer would be re-allocated (a fresh hipMalloc, the old block parked in the cache) each time
+        ws = _AFF_WS[key] = torch.empty((max(elems + elems // 2, 1 << 20),), dtype=torch.int64, device=device)
     return ws
 
 
