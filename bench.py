@@ -497,7 +497,8 @@ def run_1080p_segments(net, device, steps, warmup, segments=8, seed=7, size=(108
 def long4k(args, net, rank, world, device, dist):
     """`--workload long4k`: strong scaling of ONE clip over the GPUs of the node"""
     mode = args.long4k_mode if dist is not None else None
-    fps, bank, comm = run_long4k(net, device, args.steps, args.warmup, seed=11, shard=mode, dist=dist)
+    tiny = dict(size=(96, 128), bank_tokens=600) if os.environ.get('DEVA_BENCH_EMULATED') == '1' else {}  # (CPU test)
+    fps, bank, comm = run_long4k(net, device, args.steps, args.warmup, seed=11, shard=mode, dist=dist, **tiny)
     what = {None: 'one GPU', 'owner': 'frame owner (rank 0 encodes / decodes) + query-sharded read',
             'queries': 'every rank steps the clip, query-sharded read',
             'bank': 'every rank steps the clip, token-sharded read (candidate keys all-gathered, exact merge)'}[mode]

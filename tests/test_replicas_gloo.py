@@ -77,3 +77,21 @@ def test_bench_gpus_2_launches_two_ranks():
     assert line['value'] > 0 and abs(line['value'] - 2 * 2 / (line['ms_per_step'] * 2 * 1e-3)) < 1e-6 * line['value']
     one_clip = line['also_multi_gpu'][0]
     assert one_clip['scaling'] == 'strong' and one_clip['config']['collective_bytes_per_frame_rank0'] > 0
+
+
+def test_bench_long4k_bank_mode_on_two_ranks():
+    """`bench.py --workload long4k --long4k_mode bank --gpus 2`: ONE clip on two ranks, token-sharded read over a
+    value-sharded bank (BASELINE configs[4]); launch path, collectives and the JSON line on CPU / gloo, tiny frame"""
+    import json
+    import subprocess
+    env = dict(os.environ, DEVA_BENCH_EMULATED='1', OMP_NUM_THREADS='2')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '12', '--warmup', '2',
+                          '--workload', 'long4k', '--long4k_mode', 'bank'],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['value'] > 0
+    assert line['config']['collective_bytes_per_frame_rank0'] > 0
+    assert 'token-sharded' in line['config']['parallelism']
