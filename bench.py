@@ -49,7 +49,8 @@ long-term bank on N GPUs, `--long4k_mode`:
            read-out columns are gathered to rank 0, usage counters all-reduced, new memory rows broadcast;
   queries  every rank steps the whole clip, only the memory read is sharded by query column (all-gather);
   bank     memory read sharded by token range: per-shard top-k keys all-gathered and merged exactly,
-           partial read-outs all-reduced.
+           partial read-outs all-reduced; each rank stores 1/N of the value rows;
+  owner_bank  the same sharded bank with rank 0 as the only encoder / decoder: partial read-outs reduced to it.
 -> "scaling": "strong"; the line reports the bytes every rank moved per frame next to the FPS.
 """
 import argparse
@@ -94,6 +95,8 @@ def start_clip(net, cfg, frames, num_objects, device, lt_prefill=0, shard=None):
     core = DEVAInferenceCore(net, cfg)
     if shard == 'bank':
         core.memory.shard_bank()
+    elif shard == 'owner_bank':
+        core.memory.shard_bank(owner=0)
     elif shard is not None:
         core.memory.shard_queries(owner=0 if shard == 'owner' else None)
     h, w = frames[0].shape[-2:]
@@ -501,7 +504,9 @@ def long4k(args, net, rank, world, device, dist):
     fps, bank, comm = run_long4k(net, device, args.steps, args.warmup, seed=11, shard=mode, dist=dist, **tiny)
     what = {None: 'one GPU', 'owner': 'frame owner (rank 0 encodes / decodes) + query-sharded read',
             'queries': 'every rank steps the clip, query-sharded read',
-            'bank': 'every rank steps the clip, token-sharded read (candidate keys all-gathered, exact merge)'}[mode]
+            'bank': 'every rank steps the clip, token-sharded read (candidate keys all-gathered, exact merge)',
+            'owner_bank': 'frame owner (rank 0 encodes / decodes) + token-sharded read over a value-sharded bank (candidate keys '
+                          'all-gathered, partial read-outs reduced to the owner)'}[mode]
     if rank == 0:
         print(json.dumps({
             'metric': 'propagation FPS @4K (1 object, 50k-token long-term bank)',
@@ -586,7 +591,7 @@ def main():
     ap.add_argument('--width', type=int, default=854)
     ap.add_argument('--objects', type=int, default=5)
     ap.add_argument('--workload', choices=['clips', 'long4k'], default='clips')
-    ap.add_argument('--long4k_mode', choices=['owner', 'queries', 'bank'], default='owner')
+    ap.add_argument('--long4k_mode', choices=['owner', 'queries', 'bank', 'owner_bank'], default='owner')
     ap.add_argument('--cpu_frames', type=int, default=30, help='propagated frames of the CPU-baseline run')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_extra', action='store_true')

@@ -126,7 +126,7 @@ class MemoryManager:
         self._shard_owner = owner
         self.comm_bytes = 0
 
-    def shard_bank(self, group=None, shard_values: bool = True) -> None:
+    def shard_bank(self, group=None, shard_values: bool = True, owner: Optional[int] = None) -> None:
         """Partition every following `match_memory` by MEMORY TOKEN RANGE over `group` (SURVEY.md 8e
         "shard the bank"): rank r matches the queries against rows [r*per, (r+1)*per) of the virtual
         long-then-work bank only, the per-shard top-k candidates (64-bit score|token keys, hw*k*8 B per
@@ -139,7 +139,12 @@ class MemoryManager:
         memory frame / prototype batch rank r appends only its block; sieves and evictions drop only local rows;
         a consolidation forms the prototype values from the local candidate rows and all-reduces the P x CV
         partial sums).  Keys, shrinkage, selection and usage counters (131 of the 131 + 512 x objects floats of a
-        token) stay replicated: every rank scores and ranks them, which is what keeps the decisions identical."""
+        token) stay replicated: every rank scores and ranks them, which is what keeps the decisions identical.
+
+        owner=r: additionally frame-owner mode (see `shard_queries`): rank r alone runs the encoder / decoder and
+        broadcasts the query and the new memory rows; the partial read-outs are then REDUCED to it (`dist.reduce`,
+        half the bytes of the all-reduce every-rank-decodes needs) and nobody else receives them.  The configuration
+        for a bank that outgrows one GPU: every rank stores and scores 1/world of it, one rank decodes."""
         import torch.distributed as dist
         if not dist.is_initialized():
             raise RuntimeError('shard_bank: torch.distributed is not initialised')
@@ -148,7 +153,7 @@ class MemoryManager:
             # deva_affinity_merge takes at most 32 candidate lists (MAX_SPLITS, include/deva_hip.h)
             raise ValueError('shard_bank: at most 32 ranks per group (one candidate list per rank is merged)')
         self._shard_mode = 'bank'
-        self._shard_owner = None
+        self._shard_owner = owner
         self.comm_bytes = 0
         self._values_sharded = bool(shard_values)
         if shard_values:
@@ -301,6 +306,17 @@ class MemoryManager:
             if c1 > c0:
                 flat[:, :, c0:c1] = slab[:, :, :c1 - c0]
 
+    def _sum_partial_readouts(self, rows: torch.Tensor) -> None:
+        """partial read-outs of the ranks' value rows -> their sum: on every rank, or on the frame owner only"""
+        import torch.distributed as dist
+        world = dist.get_world_size(self._shard_group)
+        if self._shard_owner is None:
+            dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=self._shard_group)
+            self.comm_bytes += 2 * rows.numel() * 4 * (world - 1) // world
+        else:
+            dist.reduce(rows, dst=self._owner_global_rank(), op=dist.ReduceOp.SUM, group=self._shard_group)
+            self.comm_bytes += rows.numel() * 4 * (world - 1) // world
+
     def _read_bucket_bank_sharded(self, bucket_id: int, bucket: List[int], qk, qe, rows) -> None:
         import torch.distributed as dist
         with_long, n_long, n_work = self._bucket_extent(bucket_id)
@@ -309,8 +325,7 @@ class MemoryManager:
         if n < max(128, self.top_k + world) * world:  # first frames of a clip: every shard must hold >= top_k tokens
             self._read_bucket(bucket_id, bucket, qk, qe, rows)  # (every rank scores the whole replicated key bank)
             if getattr(self, '_values_sharded', False):  # ... but holds only its share of the value rows
-                dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=self._shard_group)
-                self.comm_bytes += 2 * rows.numel() * 4 * (world - 1) // world
+                self._sum_partial_readouts(rows)
             return
         hi = min(n, lo + per)
         hw = qk.shape[1]
@@ -334,8 +349,7 @@ class MemoryManager:
             self._apply_usage(bucket_id, usage_fix, with_long, n_long)
         for i, obj in enumerate(bucket):
             self._readout_into(rows[i], idx, weight, bucket_id, obj, with_long, n_long, tok_range=(lo, hi))
-        dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=self._shard_group)
-        self.comm_bytes += 2 * rows.numel() * 4 * (world - 1) // world
+        self._sum_partial_readouts(rows)
 
     def broadcast_memory_frame(self, key, shrinkage, value, selection, objects: List[int], h: int, w: int, device):
         """frame-owner mode, memory frame: the owner's new key (1*CK*h*w), shrinkage (1*1*h*w), selection
