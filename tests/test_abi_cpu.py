@@ -78,3 +78,20 @@ def test_version_and_argument_errors_without_a_gpu(library):
     assert L.deva_affinity_force_shape(2) == 0
     assert L.deva_affinity_default_splits(1620, 1620) == 26  # per-wave lists: <= 64 tokens per range, no filtering needed
     assert L.deva_affinity_force_shape(9) != 0 and L.deva_affinity_force_shape(0) == 0
+
+
+def test_read_policy_and_scratch_sizes_are_host_side():
+    """host-only entry points of the read path (no GPU work): the pre-filter policy and the scratch layout"""
+    from deva.hip import lib
+    L = lib()
+    assert L.deva_affinity_prefilter_enabled(2048, 1620, 30) == 0      # small bank: the fp32 kernels
+    assert L.deva_affinity_prefilter_enabled(10000, 300, 30) == 0      # few scores: the fp32 kernels
+    assert L.deva_affinity_prefilter_enabled(10000, 8160, 30) == 1
+    assert L.deva_affinity_prefilter_enabled(244400, 32400, 30) == 1
+    assert L.deva_affinity_force_prefilter(0) == 0 and L.deva_affinity_prefilter_enabled(10000, 8160, 30) == 0
+    assert L.deva_affinity_force_prefilter(1) == 0 and L.deva_affinity_force_prefilter(2) != 0
+    small, big = L.deva_affinity_read_scratch(10000, 8160, 30), L.deva_affinity_read_scratch(244400, 32400, 30)
+    # the scratch always holds the fp32 kernels' hand-over (the fall-back writes there), plus the pre-filter's operands
+    assert small > L.deva_affinity_workspace(8160, 30, L.deva_affinity_default_splits(10000, 8160))
+    assert big > small and big * 8 < 2 << 30                           # < 2 GiB at the 4K bench shape
+    assert L.deva_affinity_force_shape(3) != 0 and L.deva_affinity_force_shape(4) == 0 and L.deva_affinity_force_shape(0) == 0
