@@ -48,7 +48,14 @@ const char* deva_hip_last_error(void);
  *          CHUNK32 walks all taps of a 32-channel slab before moving on, so the 9 shifted
  *          re-reads of a 3x3 convolution hit the same L2 lines back to back.
  * out[b][m][oh][ow] = act( sum_k W[k][m] * in(k, b, oh, ow) + bias[m] + residual ) */
-enum { DEVA_KLAYOUT_TAP_MAJOR = 0, DEVA_KLAYOUT_CHUNK32 = 1 };
+enum {
+  DEVA_KLAYOUT_TAP_MAJOR = 0,
+  DEVA_KLAYOUT_CHUNK32 = 1,
+  /* flag, ORed to one of the K orders above: element (k, m) is stored at ((k/4)*cout_pad + m)*4 + k%4
+   * ("k-quad interleaved", K rounded up to a multiple of 4 with zeros): the lean-loop kernels
+   * (csrc/conv_mfma.hip) read four consecutive k of one output channel with one 16-byte load. */
+  DEVA_KLAYOUT_Q4 = 16
+};
 
 enum {
   DEVA_ACT_NONE = 0,
@@ -86,6 +93,14 @@ typedef struct deva_conv_desc {
 } deva_conv_desc;
 
 int deva_conv2d(const deva_conv_desc* desc, void* stream);
+
+/* Host-side packing of one convolution's weights (HOST pointers; model load, not the frame path):
+ * w_oihw [cout][cin][kh][kw] (BatchNorm already folded) -> out in the layout named by *k_layout / *cout_pad
+ * (32-channel slabs when kh*kw > 1 and cin % 32 == 0, tap-major otherwise; k-quad interleaved when want_q4 != 0
+ * and cout > 1).  Returns the number of floats of the packed weight (out == NULL: size query only), -1 on error.
+ * Replaces nothing in the reference (its nn.Conv2d weights stay [cout][cin][kh][kw], resnet.py:46-114). */
+int64_t deva_conv_pack(const float* w_oihw, float* out, int cout, int cin, int kh, int kw, int want_q4,
+                       int* k_layout, int* cout_pad);
 
 /* ------------------------------------------------------------------------------------------
  * Pooling / resampling / pointwise blocks */

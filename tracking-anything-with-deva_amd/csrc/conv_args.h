@@ -1,0 +1,63 @@
+// Argument blocks shared by the convolution translation units (conv_igemm.hip: dispatch, generic implicit-GEMM
+// kernel, split-K reduction; conv_mfma.hip: the lean-loop kernel generation; conv_cout1.hip: single-channel heads).
+#pragma once
+#include "common.h"
+
+namespace deva {
+
+// conv_cout1.hip
+struct Cout1Args {
+  const float* in0;
+  const float* in1;
+  int64_t bs0, bs1;
+  int c0, ctot;
+  int H, W, OH, OW, OHW;
+  int64_t HW;
+  const float* w;
+  const float* bias;
+  int cout_pad, k_layout;
+  int KH, KW, stride, pad;
+  int n_total;
+  int relu_in;
+  const float* res;
+  int64_t res_bs;
+  int act;
+  float* out;
+};
+int launch_conv_cout1(const Cout1Args& a, hipStream_t st);
+int launch_conv3x3_cout1_rows(const Cout1Args& a, hipStream_t st);
+
+struct ConvArgs {
+  const float* in0;
+  const float* in1;
+  int64_t bs0, bs1;  // batch strides (elements)
+  int c0, c1, ctot;
+  int H, W, OH, OW, OHW;
+  int64_t HW;
+  const float* w;
+  const float* bias;
+  int cout, cout_pad;
+  int k_layout;
+  int KH, KW, stride, pad;
+  int K;        // KH*KW*ctot
+  int n_total;  // batch*OH*OW
+  int relu_in;
+  const float* res;
+  int64_t res_bs;
+  int act;
+  float* out;
+  int vec_ok;        // inputs are guard-banded + 'same' stride-1 geometry: 4-pixel vector gathers allowed
+  int tiles_n, tiles_m;
+  int64_t ws_elems;
+  int splits;        // split-K factor (gridDim.y); > 1 writes raw partial sums to ws
+  int per_split;     // K steps per split
+  float* ws;         // [splits][cout][n_total]
+  int64_t in0_span, in1_span;  // elements from the first to one past the last element of each input
+};
+
+// conv_igemm.hip: out = act(sum_s ws[s] + bias + residual) for a split-K launch (p.splits > 1)
+int launch_splitk_reduce(const ConvArgs& p, hipStream_t st);
+// conv_mfma.hip: lean-loop kernels for weights in the k-quad layout (DEVA_KLAYOUT_Q4)
+int launch_conv_q4(const ConvArgs& a, hipStream_t st);
+
+}  // namespace deva

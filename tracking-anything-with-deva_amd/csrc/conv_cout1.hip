@@ -4,28 +4,10 @@
 //
 // The weights of the one output channel are cached in LDS; each thread keeps 8 independent input
 // loads in flight (a serial load->FMA chain is L2-latency-bound); partial sums meet in LDS.
-#include "common.h"
+#include "conv_args.h"
 
 namespace deva {
 
-struct Cout1Args {
-  const float* in0;
-  const float* in1;
-  int64_t bs0, bs1;
-  int c0, ctot;
-  int H, W, OH, OW, OHW;
-  int64_t HW;
-  const float* w;
-  const float* bias;
-  int cout_pad, k_layout;
-  int KH, KW, stride, pad;
-  int n_total;
-  int relu_in;
-  const float* res;
-  int64_t res_bs;
-  int act;
-  float* out;
-};
 
 namespace {
 

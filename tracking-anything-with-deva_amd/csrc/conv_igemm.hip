@@ -14,33 +14,11 @@
 // Each of the 4 waves owns a (WM x WN) sub-tile made of 32x32 MFMA tiles.  Operand fragments for
 // v_mfma_f32_32x32x2_f32:  A: lane l holds A[i = l&31][k = l>>5],  B: B[k = l>>5][j = l&31],
 // D: reg r of lane l is D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
-#include "common.h"
+#include "conv_args.h"
 #include <cstdlib>
 #include <type_traits>
 
 namespace deva {
-
-// conv_cout1.hip
-struct Cout1Args {
-  const float* in0;
-  const float* in1;
-  int64_t bs0, bs1;
-  int c0, ctot;
-  int H, W, OH, OW, OHW;
-  int64_t HW;
-  const float* w;
-  const float* bias;
-  int cout_pad, k_layout;
-  int KH, KW, stride, pad;
-  int n_total;
-  int relu_in;
-  const float* res;
-  int64_t res_bs;
-  int act;
-  float* out;
-};
-int launch_conv_cout1(const Cout1Args& a, hipStream_t st);
-int launch_conv3x3_cout1_rows(const Cout1Args& a, hipStream_t st);
 
 namespace {
 
@@ -48,32 +26,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef f32x4 f32x4_u __attribute__((aligned(4)));  // 4 consecutive pixels, dword-aligned only
 
-struct ConvArgs {
-  const float* in0;
-  const float* in1;
-  int64_t bs0, bs1;  // batch strides (elements)
-  int c0, c1, ctot;
-  int H, W, OH, OW, OHW;
-  int64_t HW;
-  const float* w;
-  const float* bias;
-  int cout, cout_pad;
-  int k_layout;
-  int KH, KW, stride, pad;
-  int K;        // KH*KW*ctot
-  int n_total;  // batch*OH*OW
-  int relu_in;
-  const float* res;
-  int64_t res_bs;
-  int act;
-  float* out;
-  int vec_ok;        // inputs are guard-banded + 'same' stride-1 geometry: 4-pixel vector gathers allowed
-  int tiles_n, tiles_m;
-  int64_t ws_elems;
-  int splits;        // split-K factor (gridDim.y); > 1 writes raw partial sums to ws
-  int per_split;     // K steps per split
-  float* ws;         // [splits][cout][n_total]
-};
 
 
 // MODE 0: 1x1 kernel with c0 a multiple of BK (source uniform per K step, K tail allowed);
@@ -685,16 +637,20 @@ int launch_tile(const ConvArgs& a, hipStream_t st) {
       hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, 2, SPREAD, 0, 0>), grid, dim3(64 * WAVES_M * WAVES_N), 0, st, p);
     }
   }
-  if (p.splits > 1) {
-    const int64_t total = (int64_t)p.cout * p.n_total;
-    int64_t rb = ceil_div(total, 256);
-    if (rb > 4096) rb = 4096;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, p);
-  }
+  if (p.splits > 1) return launch_splitk_reduce(p, st);
   return check_launch("deva_conv2d");
 }
 
 }  // namespace
+
+int launch_splitk_reduce(const ConvArgs& p, hipStream_t st) {
+  const int64_t total = (int64_t)p.cout * p.n_total;
+  int64_t rb = ceil_div(total, 256);
+  if (rb > 4096) rb = 4096;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, p);
+  return check_launch("deva_conv2d");
+}
+
 }  // namespace deva
 
 extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
@@ -705,7 +661,7 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
   DEVA_REQUIRE(d->batch > 0 && d->height > 0 && d->width > 0 && d->cout > 0, "deva_conv2d: bad shape");
   DEVA_REQUIRE(d->cout_pad % 32 == 0 && d->cout_pad >= d->cout, "deva_conv2d: cout_pad must be cout rounded up to 32");
   DEVA_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "deva_conv2d: bad kernel geometry");
-  DEVA_REQUIRE(d->k_layout == DEVA_KLAYOUT_TAP_MAJOR || d->k_layout == DEVA_KLAYOUT_CHUNK32,
+  DEVA_REQUIRE((d->k_layout & ~DEVA_KLAYOUT_Q4) == DEVA_KLAYOUT_TAP_MAJOR || (d->k_layout & ~DEVA_KLAYOUT_Q4) == DEVA_KLAYOUT_CHUNK32,
                "deva_conv2d: unknown k_layout %d", d->k_layout);
   ConvArgs a;
   a.in0 = d->in0;
@@ -752,6 +708,8 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
   a.splits = 1;
   a.ws = d->workspace;
   a.ws_elems = d->workspace ? d->workspace_elems : 0;
+  a.in0_span = (int64_t)(d->batch - 1) * a.bs0 + (int64_t)a.c0 * a.HW;
+  a.in1_span = a.in1 ? (int64_t)(d->batch - 1) * a.bs1 + (int64_t)a.c1 * a.HW : 0;
 
   hipStream_t st = (hipStream_t)stream;
   // single output channel: VALU kernels (conv_cout1.hip) -- a dot product per pixel on small maps
@@ -790,6 +748,12 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
     if (rows3x3) return launch_conv3x3_cout1_rows(c, st);
     return launch_conv_cout1(c, st);
   }
+  if (a.k_layout & DEVA_KLAYOUT_Q4) {
+    // buffer addressing: 32-bit byte offsets from the tensor bases
+    DEVA_REQUIRE(a.in0_span < (1ll << 29) && a.in1_span < (1ll << 29),
+                 "deva_conv2d: k-quad weights need inputs below 2 GiB (32-bit buffer offsets)");
+    return launch_conv_q4(a, st);
+  }
   // Tile choice (all tiles run 32-deep K steps):
   const int64_t blocks128 = ceil_div(a.cout, 128) * ceil_div(a.n_total, 128);
 #ifdef DEVA_CONV_PROBES  // `make PROBES=1`: A/B runs of the tile policy (tools/conv_microbench.py)
@@ -810,4 +774,33 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
   if (a.cout >= 128 && blocks128 >= 64 && !(blocks128 < 256 && blocks64 >= 256 && a.K <= 512))
     return launch_tile<128, 128, 32, 2, 4>(a, st);
   return launch_tile<64, 64, 32, 2, 2>(a, st);
+}
+
+// Host-side weight packing (model load, not the frame path): [cout][cin][kh][kw] -> the layout deva_conv2d reads.
+extern "C" int64_t deva_conv_pack(const float* w_oihw, float* out, int cout, int cin, int kh, int kw, int want_q4,
+                                  int* k_layout, int* cout_pad_out) {
+  using namespace deva;
+  if (!w_oihw || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0 || !k_layout || !cout_pad_out) {
+    set_error("deva_conv_pack: bad arguments");
+    return -1;
+  }
+  const int taps = kh * kw;
+  const int K = taps * cin;
+  const int cout_pad = (cout + 31) / 32 * 32;
+  const bool chunk = taps > 1 && cin % 32 == 0;
+  const bool q4 = want_q4 && cout > 1;  // the single-channel heads (conv_cout1.hip) read column 0 of [K][cout_pad]
+  const int64_t rows = q4 ? (int64_t)(K + 3) / 4 * 4 : K;
+  const int64_t elems = rows * cout_pad;
+  *k_layout = (chunk ? DEVA_KLAYOUT_CHUNK32 : DEVA_KLAYOUT_TAP_MAJOR) | (q4 ? DEVA_KLAYOUT_Q4 : 0);
+  *cout_pad_out = cout_pad;
+  if (!out) return elems;
+  for (int64_t i = 0; i < elems; ++i) out[i] = 0.0f;
+  for (int m = 0; m < cout; ++m)
+    for (int c = 0; c < cin; ++c)
+      for (int t = 0; t < taps; ++t) {
+        const int64_t k = chunk ? ((int64_t)(c / 32) * taps + t) * 32 + c % 32 : (int64_t)t * cin + c;
+        const int64_t at = q4 ? ((k >> 2) * cout_pad + m) * 4 + (k & 3) : k * cout_pad + m;
+        out[at] = w_oihw[((int64_t)m * cin + c) * taps + t];
+      }
+  return elems;
 }

@@ -1,0 +1,559 @@
+// Implicit-GEMM convolution on v_mfma_f32_32x32x2_f32, second kernel generation: a main loop without VALU work.
+//
+// Why: on gfx950 the fp32 MFMA runs at the fp32 VALU rate and does not co-execute with VALU instructions
+// (SQ_VALU_MFMA_COEXEC_CYCLES = 0 on every conv dispatch, profiles/r04a): every v_cndmask / v_add / 64-bit address
+// computation in the K loop is matrix-pipe time.  The first generation (conv_igemm.hip) issues ~2 VALU instructions
+// per MFMA in its loop and keeps the pipe 77-80 % busy on the big layers.  Here
+//   * operands are fetched with BUFFER loads: per-thread byte offsets are computed once, the K step advances the
+//     scalar base of the resource descriptor (SALU), the tile tails read zeros through the range check -- no address
+//     arithmetic and no selects in the loop;
+//   * the weights are stored k-quad interleaved, Wq[k/4][cout_pad][4] (DEVA_KLAYOUT_Q4): a 16-byte load brings the
+//     four k values one lane needs for four consecutive MFMAs, the LDS image is lane-linear and the A fragments of a
+//     wave are ONE ds_read_b128 per 32x(8 k) block instead of four ds_read_b32;
+//   * the zero padding of the 3x3 row-reuse path (input rows of a (32-channel slab, dy) pair staged once for the
+//     three dx taps, padding applied per consumer pixel) costs ONE select per K step: a lane whose tap falls into
+//     the padding reads an always-zero column of the row tile instead of its own pixel (its LDS base address
+//     changes, the row immediates stay) -- the first generation selected per MFMA pair;
+//   * the activation tile is stored with K rows interleaved in pairs, Bs[k/2][pixel][k%2]: a lane reads two k values
+//     with one ds_read_b64 at base + immediate (ds_read2_b32 with an 8-bit offset field needed a v_add per pair at
+//     the 136-float row pitch); the pair interleave is free at the write (each thread gathers two adjacent K rows
+//     and stores 16-byte pieces {r0[p], r1[p], r0[p+1], r1[p+1]});
+//   * the barrier of a K step sits before the LAST MFMA group: the tile of step s+1 is written to LDS after group 1,
+//     the fragments of the last group are already in registers when the wave reaches the barrier, and the first
+//     fragments of step s+1 are read behind it, under the MFMAs of the last group.
+//
+// GEMM view as before:  M = cout, N = batch*OH*OW (pixels, batch-major), K = KH*KW*(C0+C1).
+// MFMA k assignment inside a 32-deep K step: group q (0..3), MFMA e (0..3): lanes 0-31 feed k = 8q + e, lanes 32-63
+// feed k = 8q + 4 + e  (the order of the fp32 FMA chain of one output; deterministic).
+#include <type_traits>
+
+#include "conv_args.h"
+
+namespace deva {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
+// KIND 0: 1x1, stride 1, guard-banded inputs, c0 % 32 == 0 (vector gathers of 4 pixels; K tail of the second source allowed)
+// KIND 1: 3x3, stride 1, pad 1, 32-channel-slab K order, guard-banded inputs (row reuse)
+// KIND 2: any kernel with c0 and c0+c1 multiples of 32 (tap and source uniform per K step), scalar gathers
+// KIND 3: anything (per-element decode through a table: the 2/3/4-channel stems, odd channel splits)
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KIND, int MINW>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_mfma_kernel(const ConvArgs p) {
+  constexpr int THREADS = 64 * WAVES_M * WAVES_N;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  static_assert(TM >= 1 && TN >= 1, "wave tile");
+  constexpr bool ROW = KIND == 1;
+  constexpr bool VEC = KIND <= 1;
+  static_assert(!ROW || TN == 1, "row reuse: one pixel per lane");
+  constexpr int A_V4 = 8 * BM / THREADS;        // 16-byte loads of the weight tile per thread and K step
+  constexpr int A_PASS = THREADS / BM;          // k-quad rows per pass
+  static_assert(A_V4 >= 1 && A_V4 * THREADS == 8 * BM, "weight tile geometry");
+  constexpr int BNP = ROW ? BN + 8 : BN;        // ROW: columns 3 .. BN+4 hold pixels n0-1 .. n0+BN
+  constexpr int A_FLOATS = BK * BM, B_FLOATS = BK * BNP;
+  constexpr int NQ = BN / 4;                    // pixel quads per tile row
+  constexpr int KGV = THREADS / NQ;             // K rows per pass (vector gather)
+  constexpr int B_V4 = VEC ? BK / KGV : 2;      // rows per thread: PAIRS adjacent row pairs (2a, 2a+1), a = vk + i*KGV
+  constexpr int PAIRS = B_V4 / 2;
+  static_assert(!VEC || (PAIRS >= 1 && PAIRS * 2 * KGV == BK), "vector gather geometry");
+  constexpr int KG = THREADS / BN;              // K rows per pass (scalar gather)
+  constexpr int B_PT = VEC ? 1 : BK / KG;
+  constexpr int KTAB = 1024;
+
+  __shared__ __attribute__((aligned(16))) float smem[2 * A_FLOATS + 2 * B_FLOATS];
+  __shared__ unsigned s_ktab[KIND == 3 ? KTAB : 1];
+  float* const sA = smem;
+  float* const sB = smem + 2 * A_FLOATS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave / WAVES_N) * WM;
+  const int wn0 = (wave % WAVES_N) * WN;
+  const int l31 = lane & 31;
+  const int half = lane >> 5;
+
+  const bool ktab_ok = KIND == 3 && p.K <= KTAB && p.ctot < 65536 && p.KH < 256 && p.KW < 256;
+  if (KIND == 3 && ktab_ok) {
+    for (int k = tid; k < p.K; k += THREADS) {
+      const int tap = k / p.ctot;
+      const int dy = tap / p.KW;
+      s_ktab[k] = (unsigned)(k - tap * p.ctot) | ((unsigned)dy << 16) | ((unsigned)(tap - dy * p.KW) << 24);
+    }
+    __syncthreads();
+  }
+
+  // cout tiles fastest, XCD x gets a contiguous range of logical tiles (workgroup b runs on XCD b % 8)
+  int logical;
+  {
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int q = nb >> 3, r = nb & 7, xcd = b & 7;
+    logical = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int tile_n = logical / p.tiles_m;
+  const int tile_m = logical - tile_n * p.tiles_m;
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  // ---- weights: thread t loads quad row t / BM (+ A_PASS per pass), output channel m0 + t % BM
+  const int a_voff = ((tid / BM) * p.cout_pad + m0 + (tid % BM)) * 16;
+  const int a_pass_bytes = A_PASS * p.cout_pad * 16;
+  const int a_step_bytes = 8 * p.cout_pad * 16;
+  const int a_total_bytes = ((p.K + 3) >> 2) * p.cout_pad * 16;
+
+  // ---- vector gather: 4 consecutive pixels of K row vk (+ KGV per pass)
+  const int vq = tid % NQ, vk = tid / NQ;
+  int b_voff0 = 0, b_voff1 = 0;
+  if (VEC) {
+    const int n4 = n0 + 4 * vq;
+    const int nn = (n4 < p.n_total) ? n4 : 0;  // OHW % 4 == 0: a quad never straddles images or the end
+    const int b = nn / p.OHW;
+    const int pix = nn - b * p.OHW;
+    b_voff0 = (int)(((int64_t)b * p.bs0 + (int64_t)2 * vk * p.HW + pix) * 4);
+    b_voff1 = (int)(((int64_t)b * p.bs1 + (int64_t)2 * vk * p.HW + pix) * 4);
+  }
+  const int b_row_bytes = (int)(p.HW * 4);
+  const int b_pass_bytes = (int)(2 * KGV * p.HW * 4);
+  // ROW: halo pixel (n0-1 or n0+BN) of K row h_row, loaded by every thread (branch-free), stored by wave 0
+  const int h_side = tid & 1, h_row = (tid >> 1) & (BK - 1);
+  int h_voff0 = 0, h_voff1 = 0;
+  unsigned cmask = 0;  // 9-bit validity mask (bit dy*3+dx) of the pixel this lane consumes
+  if (ROW) {
+    int nh = h_side ? n0 + BN : n0 - 1;
+    nh = min(max(nh, 0), p.n_total - 1);
+    const int b = nh / p.OHW;
+    const int pix = nh - b * p.OHW;
+    h_voff0 = (int)(((int64_t)b * p.bs0 + (int64_t)h_row * p.HW + pix) * 4);
+    h_voff1 = (int)(((int64_t)b * p.bs1 + (int64_t)h_row * p.HW + pix) * 4);
+    const int n = n0 + wn0 + l31;
+    if (n < p.n_total) {
+      const int px = n % p.OHW;
+      const int oh = px / p.OW, ow = px - oh * p.OW;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const bool ok = ((unsigned)(oh + t / 3 - 1) < (unsigned)p.H) && ((unsigned)(ow + t % 3 - 1) < (unsigned)p.W);
+        cmask |= ok ? (1u << t) : 0u;
+      }
+    }
+  }
+
+  // ---- scalar gather (KIND 2, 3): this thread always gathers pixel n0 + tid % BN
+  const int bn_local = tid % BN, bk_group = tid / BN;
+  bool n_ok = false;
+  int ih0 = 0, iw0 = 0;
+  const float* src0 = p.in0;
+  const float* src1 = p.in0;
+  if (!VEC) {
+    const int n_g = n0 + bn_local;
+    n_ok = n_g < p.n_total;
+    const int nn = n_ok ? n_g : 0;
+    const int b = nn / p.OHW;
+    const int pix = nn - b * p.OHW;
+    const int oh = pix / p.OW;
+    const int ow = pix - oh * p.OW;
+    ih0 = oh * p.stride - p.pad;
+    iw0 = ow * p.stride - p.pad;
+    src0 = p.in0 + (int64_t)b * p.bs0;
+    src1 = p.in1 ? p.in1 + (int64_t)b * p.bs1 : p.in0;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  // split-K: this workgroup accumulates K steps [ks0, ks0 + ksteps)
+  int ks0 = 0, ksteps = (p.K + BK - 1) / BK;
+  if (p.splits > 1) {
+    ks0 = (int)blockIdx.y * p.per_split;
+    ksteps = max(0, min(ksteps - ks0, p.per_split));
+  }
+  const int ks_last = ks0 + max(ksteps, 1) - 1;
+
+  // ---- staging registers
+  f32x4 ra[A_V4];
+  f32x4 rbv[B_V4];
+  float rh = 0.0f;
+  float rb[B_PT];
+  unsigned ok_b = 0;
+  int rows_valid = BK;  // KIND 0: rows of the staged tile that exist in their source
+
+  // global -> registers for K step t (clamped to the last step of this workgroup: the tail re-loads, unused)
+  auto load_issue = [&](int t_raw, auto row_tile) {
+    constexpr bool WITH_ROWS = decltype(row_tile)::value;  // ROW: also the (slab, dy) row tile that starts at step t
+    const int t = min(t_raw, ks_last);
+    {
+      const int off = t * a_step_bytes;
+      const __amdgpu_buffer_rsrc_t r = make_rsrc(reinterpret_cast<const char*>(p.w) + off, max(a_total_bytes - off, 0));
+#pragma unroll
+      for (int i = 0; i < A_V4; ++i) ra[i] = buf_load4(r, a_voff, i * a_pass_bytes);
+    }
+    if (KIND == 0) {
+      const int cbase = t * BK;
+      const bool first = cbase < p.c0;
+      const int c = first ? cbase : cbase - p.c0;
+      rows_valid = min(BK, (first ? p.c0 : p.c1) - c);
+      const float* base = (first ? p.in0 : p.in1) + (int64_t)c * p.HW;
+      const int64_t span = (first ? p.in0_span : p.in1_span) - (int64_t)c * p.HW;
+      const __amdgpu_buffer_rsrc_t r = make_rsrc(base, (int)min(span * 4, (int64_t)0x7fffffff));
+      const int voff = first ? b_voff0 : b_voff1;
+#pragma unroll
+      for (int i = 0; i < PAIRS; ++i) {
+        rbv[2 * i] = buf_load4(r, voff, i * b_pass_bytes);
+        rbv[2 * i + 1] = buf_load4(r, voff, i * b_pass_bytes + b_row_bytes);
+      }
+    } else if (KIND == 1) {
+      if (WITH_ROWS) {
+        const int chunk = t / 9;
+        const int dy = (t - chunk * 9) / 3;
+        const int cbase = chunk * BK;
+        const bool first = cbase < p.c0;
+        const float* base = (first ? p.in0 : p.in1) + ((int64_t)(first ? cbase : cbase - p.c0) * p.HW + (dy - 1) * p.W);
+        const __amdgpu_buffer_rsrc_t r = make_rsrc(base, 0x7fffffff);
+        const int voff = first ? b_voff0 : b_voff1;
+#pragma unroll
+        for (int i = 0; i < PAIRS; ++i) {
+          rbv[2 * i] = buf_load4(r, voff, i * b_pass_bytes);
+          rbv[2 * i + 1] = buf_load4(r, voff, i * b_pass_bytes + b_row_bytes);
+        }
+        rh = buf_load1(r, first ? h_voff0 : h_voff1, 0);
+      }
+    } else {
+      ok_b = 0;
+      const int k0 = t * BK;
+      if (KIND == 2) {
+        int tap = 0, cbase = k0;
+        if (p.KH * p.KW > 1) {
+          if ((p.k_layout & 0xf) == DEVA_KLAYOUT_CHUNK32) {
+            const int taps = p.KH * p.KW;
+            const int chunk = t / taps;
+            tap = t - chunk * taps;
+            cbase = chunk * BK;
+          } else {
+            tap = k0 / p.ctot;
+            cbase = k0 - tap * p.ctot;
+          }
+        }
+        const int dy = tap / p.KW;
+        const int ih = ih0 + dy, iw = iw0 + (tap - dy * p.KW);
+        const bool first = cbase < p.c0;
+        const bool okp = n_ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+        const float* sp = (first ? (src0 + (int64_t)cbase * p.HW) : (src1 + (int64_t)(cbase - p.c0) * p.HW)) +
+                          (okp ? (ih * p.W + iw) : 0);
+#pragma unroll
+        for (int i = 0; i < B_PT; ++i) {
+          const int ci = bk_group + i * KG;
+          const bool kin = k0 + ci < p.K;
+          rb[i] = sp[kin ? (int64_t)ci * p.HW : 0];
+          ok_b |= (okp && kin) ? (1u << i) : 0u;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < B_PT; ++i) {
+          const int k = k0 + bk_group + i * KG;
+          int c, dy, dx;
+          if (ktab_ok) {
+            const unsigned e = s_ktab[min(k, KTAB - 1)];
+            c = (int)(e & 0xffffu);
+            dy = (int)((e >> 16) & 0xffu);
+            dx = (int)(e >> 24);
+          } else {
+            const int tap = k / p.ctot;
+            c = k - tap * p.ctot;
+            dy = tap / p.KW;
+            dx = tap - dy * p.KW;
+          }
+          const int ih = ih0 + dy, iw = iw0 + dx;
+          const bool ok = n_ok && (k < p.K) && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+          const bool first = ok ? (c < p.c0) : true;
+          const float* sp = first ? src0 : src1;
+          const int64_t off = ok ? ((int64_t)(first ? c : (c - p.c0)) * p.HW + (ih * p.W + iw)) : 0;
+          rb[i] = sp[off];
+          ok_b |= ok ? (1u << i) : 0u;
+        }
+      }
+    }
+  };
+
+  // registers -> LDS buffers of K step t.  Activation tile: element (K row r, column c) lives at ((r/2)*BNP + c)*2 + r%2.
+  auto relu4 = [](f32x4& v) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j], 0.0f, __builtin_inff());  // one v_med3_f32
+  };
+  auto store_pairs = [&](float* bt, int col0) {  // rows (2a, 2a+1), a = vk + i*KGV; pixels col0 + 4*vq .. +3
+#pragma unroll
+    for (int i = 0; i < PAIRS; ++i) {
+      const f32x4 r0 = rbv[2 * i], r1 = rbv[2 * i + 1];
+      float* d = bt + ((vk + i * KGV) * BNP + col0 + 4 * vq) * 2;
+      *reinterpret_cast<f32x4*>(d) = f32x4{r0[0], r1[0], r0[1], r1[1]};
+      *reinterpret_cast<f32x4*>(d + 4) = f32x4{r0[2], r1[2], r0[3], r1[3]};
+    }
+  };
+  auto lds_store = [&](int t, auto row_tile) {
+    constexpr bool WITH_ROWS = decltype(row_tile)::value;
+    float* a = sA + (t & 1) * A_FLOATS + tid * 4;
+#pragma unroll
+    for (int i = 0; i < A_V4; ++i) *reinterpret_cast<f32x4*>(a + i * THREADS * 4) = ra[i];
+    if (KIND == 0) {
+      if (p.relu_in) {
+#pragma unroll
+        for (int i = 0; i < B_V4; ++i) relu4(rbv[i]);
+      }
+      if (rows_valid < BK) {
+#pragma unroll
+        for (int i = 0; i < B_V4; ++i)
+          if (2 * (vk + (i >> 1) * KGV) + (i & 1) >= rows_valid) rbv[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+      store_pairs(sB + (t & 1) * B_FLOATS, 0);
+    } else if (KIND == 1) {
+      if (WITH_ROWS) {
+        float* bt = sB + ((t / 3) & 1) * B_FLOATS;
+        if (p.relu_in) {
+#pragma unroll
+          for (int i = 0; i < B_V4; ++i) relu4(rbv[i]);
+          rh = __builtin_amdgcn_fmed3f(rh, 0.0f, __builtin_inff());
+        }
+        store_pairs(bt, 4);
+        if (tid < 64) bt[((h_row >> 1) * BNP + (h_side ? BN + 4 : 3)) * 2 + (h_row & 1)] = rh;
+      }
+    } else {
+      float* b = sB + (t & 1) * B_FLOATS + bn_local * 2;
+#pragma unroll
+      for (int i = 0; i < B_PT; ++i) {
+        const int r = bk_group + i * KG;
+        float v = rb[i];
+        if (p.relu_in) v = __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff());
+        b[(r >> 1) * BNP * 2 + (r & 1)] = (ok_b & (1u << i)) ? v : 0.0f;
+      }
+    }
+  };
+
+  // ---- fragment reads: A one ds_read_b128 per (32 rows x 8 k), B two ds_read_b64 per (8 k x 32 pixels)
+  const float* const a_rd0 = sA + (half * BM + wm0 + l31) * 4;
+  const float* const b_rd0 = sB + (2 * half * BNP + wn0 + l31 + (ROW ? 3 : 0)) * 2;
+  const float* const b_zero0 = sB + (2 * half * BNP) * 2;  // ROW: column 0 of every row pair stays zero
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x4 fa[2][TM];
+  f32x2 fb[2][TN][2];
+  auto frag_load = [&](int set, const float* a_rd, const float* b_rd, int q) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[set][i] = *reinterpret_cast<const f32x4*>(a_rd + (2 * q * BM + 32 * i) * 4);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e2 = 0; e2 < 2; ++e2)
+        fb[set][j][e2] = *reinterpret_cast<const f32x2*>(b_rd + ((4 * q + e2) * BNP + 32 * j) * 2);
+  };
+  auto mfma_group = [&](int set) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][e], fb[set][j][e >> 1][e & 1], acc[i][j], 0, 0, 0);
+  };
+
+  // ROW: 3-bit validity (dx = 0..2) of this lane's pixel for the dy of K step t; the lane's read base of a step
+  auto taps_of = [&](int t) { return (cmask >> (t % 9 / 3 * 3)) & 7u; };
+  auto b_base = [&](int t, int dx, unsigned m3) {
+    const int buf = (ROW ? ((t / 3) & 1) : (t & 1)) * B_FLOATS;
+    if (!ROW) return b_rd0 + buf;
+    return ((m3 >> dx) & 1u) ? (b_rd0 + buf + 2 * dx) : (b_zero0 + buf);
+  };
+
+  unsigned m3 = ROW ? taps_of(ks0) : 0u;
+  const float* b_cur = b_base(ks0, 0, m3);  // read base of the current step
+
+  // One K step.  DX: the dx tap of the step (ROW; steps come in (slab, dy) groups of three, splits start on group
+  // boundaries).
+  auto step = [&](int s, auto dxc) {
+    constexpr int DX = decltype(dxc)::value;
+    constexpr int DXN = ROW ? (DX + 1) % 3 : 0;
+    const int t = ks0 + s;
+    const float* a_rd = a_rd0 + (t & 1) * A_FLOATS;
+    const float* a_nx = a_rd0 + ((t + 1) & 1) * A_FLOATS;
+    if (ROW && DX == 2) m3 = taps_of(t + 1);
+    const float* b_nx = b_base(t + 1, DXN, m3);
+    // every segment: LDS reads of the NEXT group first (they return under the MFMAs of this one), then the 8 MFMAs
+    frag_load(1, a_rd, b_cur, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(0);
+    __builtin_amdgcn_sched_barrier(0);
+    frag_load(0, a_rd, b_cur, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(1);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_store(t + 1, std::integral_constant<bool, DX == 2>{});
+    frag_load(1, a_rd, b_cur, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    load_issue(t + 2, std::integral_constant<bool, DX == 1>{});
+    frag_load(0, a_nx, b_nx, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(1);
+    __builtin_amdgcn_sched_barrier(0);
+    b_cur = b_nx;
+  };
+
+  // ---- prologue: zero column, tile of the first step, loads of the second, first fragments
+  if (ROW) {
+    for (int i = tid; i < 2 * BK; i += THREADS) sB[(i >> 5) * B_FLOATS + ((i & 31) >> 1) * BNP * 2 + (i & 1)] = 0.0f;
+  }
+  load_issue(ks0, std::true_type{});
+  lds_store(ks0, std::true_type{});
+  __syncthreads();
+  load_issue(ks0 + 1, std::false_type{});
+  frag_load(0, a_rd0 + (ks0 & 1) * A_FLOATS, b_cur, 0);
+
+  if (ROW) {
+    for (int s = 0; s < ksteps; s += 3) {
+      step(s, std::integral_constant<int, 0>{});
+      step(s + 1, std::integral_constant<int, 1>{});
+      step(s + 2, std::integral_constant<int, 2>{});
+    }
+  } else {
+    for (int s = 0; s < ksteps; ++s) step(s, std::integral_constant<int, 0>{});
+  }
+
+  if (p.splits > 1) {
+    // ---- split-K: raw partial sums, reduced (+ bias / residual / activation) by splitk_reduce_kernel
+    float* ws = p.ws + (int64_t)blockIdx.y * p.cout * p.n_total;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn0 + j * 32 + l31;
+      if (n >= p.n_total) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (m < p.cout) ws[(int64_t)m * p.n_total + n] = acc[i][j][r];
+        }
+    }
+    return;
+  }
+
+  // ---- epilogue: bias + residual + activation, NCHW store (32 consecutive pixels per half-wave)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn0 + j * 32 + l31;
+    if (n >= p.n_total) continue;
+    const int b = n / p.OHW;
+    const int pix = n - b * p.OHW;
+    const int64_t obase = (int64_t)b * p.cout * p.OHW + pix;
+    const int64_t rbase = (int64_t)b * p.res_bs + pix;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      float bv[16], rv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int mm = (m < p.cout) ? m : 0;
+        bv[r] = p.bias ? p.bias[mm] : 0.0f;
+        rv[r] = p.res ? p.res[rbase + (int64_t)mm * p.OHW] : 0.0f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = acc[i][j][r];
+        if (p.bias) v += bv[r];
+        if (p.res) v += rv[r];
+        if (p.act == DEVA_ACT_RELU) {
+          v = fmaxf(v, 0.0f);
+        } else if (p.act == DEVA_ACT_SIGMOID) {
+          v = sigmoidf_(v);
+        } else if (p.act == DEVA_ACT_SQUARE_PLUS_ONE) {
+          v = v * v + 1.0f;
+        }
+        if (m < p.cout) p.out[obase + (int64_t)m * p.OHW] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MINW>
+int launch_tile_q4(const ConvArgs& a, hipStream_t st) {
+  ConvArgs p = a;
+  const bool uniform = a.ctot % BK == 0 && a.c0 % BK == 0;  // tap and source uniform per K step
+  int kind;
+  if (a.vec_ok && a.KH == 1 && a.KW == 1 && a.c0 % BK == 0) {
+    kind = 0;
+  } else if (a.vec_ok && uniform && a.KH == 3 && a.KW == 3 && a.pad == 1 && (a.k_layout & 0xf) == DEVA_KLAYOUT_CHUNK32 &&
+             BN / WAVES_N == 32) {
+    kind = 1;
+  } else if (uniform) {
+    kind = 2;
+  } else {
+    kind = 3;
+  }
+  if ((a.k_layout & 0xf) == DEVA_KLAYOUT_CHUNK32 && !uniform) {
+    set_error("deva_conv2d: 32-channel-slab weights need c0 and c1 to be multiples of 32");
+    return 2;
+  }
+  p.tiles_m = (int)ceil_div(a.cout, BM);
+  p.tiles_n = (int)ceil_div(a.n_total, BN);
+  const int ksteps_total = (int)ceil_div(a.K, BK);
+  p.per_split = ksteps_total;
+  const int64_t blocks = (int64_t)p.tiles_m * p.tiles_n;
+  p.splits = 1;
+  const int64_t target_blocks = 512;
+  if (a.ws && blocks < 256 && ksteps_total >= (blocks >= 128 ? 32 : 8)) {
+    int64_t sp = ceil_div(target_blocks, blocks);
+    if (sp > ksteps_total / 4) sp = ksteps_total / 4;
+    if (sp > 16) sp = 16;
+    const int64_t fit = a.ws_elems / ((int64_t)a.cout * a.n_total);
+    if (sp > fit) sp = fit;
+    if (sp >= 2) {
+      int per = (int)ceil_div(ksteps_total, sp);
+      if (kind == 1) per = (per + 2) / 3 * 3;  // row reuse: whole (slab, dy) groups
+      sp = ceil_div(ksteps_total, per);
+      p.splits = (int)sp;
+      p.per_split = per;
+    }
+    if (p.splits < 2) p.splits = 1;
+  }
+  const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splits), block(64 * WAVES_M * WAVES_N);
+  switch (kind) {
+    case 0: hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, 0, MINW>), grid, block, 0, st, p); break;
+    case 1:
+      if constexpr (BN / WAVES_N == 32) hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, 1, MINW>), grid, block, 0, st, p);
+      break;
+    case 2: hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, 2, MINW>), grid, block, 0, st, p); break;
+    default: hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, 3, MINW>), grid, block, 0, st, p); break;
+  }
+  if (p.splits > 1) return launch_splitk_reduce(p, st);
+  return check_launch("deva_conv2d");
+}
+
+}  // namespace
+
+int launch_conv_q4(const ConvArgs& a, hipStream_t st) {
+  if (a.cout <= 32) return launch_tile_q4<32, 128, 1, 4, 1>(a, st);
+  const int64_t blocks128 = ceil_div(a.cout, 128) * ceil_div(a.n_total, 128);
+  const int64_t blocks64 = ceil_div(a.cout, 64) * ceil_div(a.n_total, 64);
+  if (a.cout >= 128 && blocks128 >= 64 && !(blocks128 < 256 && blocks64 >= 256 && a.K <= 512))
+    return launch_tile_q4<128, 128, 2, 4, 4>(a, st);
+  return launch_tile_q4<64, 64, 2, 2, 1>(a, st);
+}
+
+}  // namespace deva
