@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DEVA_HIP_ABI_VERSION 3
+#define DEVA_HIP_ABI_VERSION 4
 
 int deva_hip_version(void);
 const char* deva_hip_last_error(void);

@@ -25,8 +25,12 @@ def pack_conv(weight, bias=None, bn=None, device=None):
 
 
 def _unpack(pc: PackedConv):
-    w = pc.weight[:, :pc.cout]
-    if pc.k_layout == 1:  # [cin/32][tap][32][cout]
+    w = pc.weight
+    if pc.k_layout & real.KLAYOUT_Q4:  # [K/4][cout_pad][4] -> [K][cout_pad]
+        k = pc.kh * pc.kw * pc.cin
+        w = w.view(-1, pc.cout_pad, 4).permute(0, 2, 1).reshape(-1, pc.cout_pad)[:k]
+    w = w[:, :pc.cout]
+    if (pc.k_layout & 0xf) == 1:  # [cin/32][tap][32][cout]
         w = w.reshape(pc.cin // 32, pc.kh * pc.kw, 32, pc.cout).permute(3, 0, 2, 1)
         return w.reshape(pc.cout, pc.cin, pc.kh, pc.kw).contiguous()
     return w.reshape(pc.kh, pc.kw, pc.cin, pc.cout).permute(3, 2, 0, 1).contiguous()

@@ -95,3 +95,24 @@ def test_read_policy_and_scratch_sizes_are_host_side():
     assert small > L.deva_affinity_workspace(8160, 30, L.deva_affinity_default_splits(10000, 8160))
     assert big > small and big * 8 < 2 << 30                           # < 2 GiB at the 4K bench shape
     assert L.deva_affinity_force_shape(3) != 0 and L.deva_affinity_force_shape(4) == 0 and L.deva_affinity_force_shape(0) == 0
+
+
+def test_conv_pack_matches_python_packing(library):
+    """deva_conv_pack (host function of the C ABI) and ops.pack_conv produce the same layout: tap-major / 32-channel
+    slabs, k-quad interleaved for more than one output channel, K padded to a multiple of 4"""
+    import torch
+    from deva import hip
+    from deva.hip import ops
+    L = hip.lib()
+    g = torch.Generator().manual_seed(3)
+    for cout, cin, k in ((64, 3, 7), (48, 64, 3), (1, 32, 3), (40, 33, 1), (128, 64, 1), (2, 2, 7)):
+        w = torch.randn(cout, cin, k, k, generator=g)
+        pc = ops.pack_conv(w)
+        lay, cpad = ctypes.c_int(-1), ctypes.c_int(-1)
+        n = L.deva_conv_pack(w.contiguous().data_ptr(), None, cout, cin, k, k, 1, ctypes.byref(lay), ctypes.byref(cpad))
+        assert n == pc.weight.numel() and lay.value == pc.k_layout and cpad.value == pc.cout_pad, (cout, cin, k)
+        out = torch.full((n,), float('nan'))
+        assert L.deva_conv_pack(w.contiguous().data_ptr(), out.data_ptr(), cout, cin, k, k, 1, ctypes.byref(lay),
+                                ctypes.byref(cpad)) == n
+        assert torch.equal(out.view_as(pc.weight), pc.weight), (cout, cin, k)
+        assert bool(pc.k_layout & hip.KLAYOUT_Q4) == (cout > 1)

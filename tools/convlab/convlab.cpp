@@ -30,6 +30,15 @@
     }                                                                                  \
   } while (0)
 
+// --keepalive: one wave that sleeps for `ticks` of the 100 MHz wall clock on a second stream, so that the GPU is never
+// idle between the timed launches (does the clock / power management react to the gaps between kernels?)
+__global__ void keepalive_kernel(long long ticks, int* sink) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+  if (sink) *sink = 1;
+}
+// --heat N: N workgroups of dependent FMAs beside the timed launches (power / clock probe)
+
 struct Layer {
   const char* name;
   int c0, c1, cout, k, stride, batch, oh, ow;
@@ -120,9 +129,11 @@ static void fill(std::vector<float>& v, unsigned seed, float scale) {
 
 int main(int argc, char** argv) {
   std::string libs = "tracking-anything-with-deva_amd/deva/hip/libdeva_hip.so";
-  std::string only, set = "frame480";
+  std::string only, set = "frame480", shapes;
   int iters = 20;
-  bool check = false;
+  bool check = false, csv = false;
+  int keepalive_ms = 0;
+  double warm_ms = 15.0, time_ms = 20.0;
   int q4 = 1;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -132,7 +143,30 @@ int main(int argc, char** argv) {
     else if (a == "--set" && i + 1 < argc) set = argv[++i];
     else if (a == "--check") check = true;
     else if (a == "--noq4") q4 = 0;
+    else if (a == "--csv") csv = true;
+    else if (a == "--keepalive" && i + 1 < argc) keepalive_ms = atoi(argv[++i]);
+    else if (a == "--warm_ms" && i + 1 < argc) warm_ms = atof(argv[++i]);
+    else if (a == "--time_ms" && i + 1 < argc) time_ms = atof(argv[++i]);
+    else if (a == "--shapes" && i + 1 < argc) shapes = argv[++i];
     else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
+  }
+  std::vector<Layer> layers(std::begin(kLayers), std::end(kLayers));
+  static std::vector<std::string> custom_names;
+  if (!shapes.empty()) {  // --shapes "c0,c1,cout,k,stride,batch,oh,ow,relu,res,act;..."
+    layers.clear();
+    custom_names.reserve(64);
+    for (size_t p = 0; p < shapes.size();) {
+      size_t q = shapes.find(';', p);
+      if (q == std::string::npos) q = shapes.size();
+      const std::string one = shapes.substr(p, q - p);
+      int v[11] = {0};
+      if (sscanf(one.c_str(), "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7, v + 8, v + 9,
+                 v + 10) >= 8) {
+        custom_names.push_back(one);
+        layers.push_back(Layer{custom_names.back().c_str(), v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], 1.0, 1});
+      }
+      p = q + 1;
+    }
   }
   std::vector<Lib> L;
   for (size_t p = 0; p < libs.size();) {
@@ -149,8 +183,9 @@ int main(int argc, char** argv) {
     L.push_back(l);
     p = q + 1;
   }
-  hipStream_t st;
+  hipStream_t st, st2;
   HIP_OK(hipStreamCreate(&st));
+  HIP_OK(hipStreamCreate(&st2));
   hipEvent_t e0, e1;
   HIP_OK(hipEventCreate(&e0));
   HIP_OK(hipEventCreate(&e1));
@@ -166,7 +201,7 @@ int main(int argc, char** argv) {
   printf("\n");
   std::vector<double> frame_us(L.size(), 0.0), big_us(L.size(), 0.0), small_us(L.size(), 0.0);
   double frame_gf = 0.0;
-  for (const Layer& ly : kLayers) {
+  for (const Layer& ly : layers) {
     if (!only.empty() && !strstr(ly.name, only.c_str())) continue;
     if (set == "big" && ly.set != 1) continue;
     if (set == "small" && ly.set != 2) continue;
@@ -247,19 +282,33 @@ int main(int argc, char** argv) {
       d.workspace = ws;
       d.workspace_elems = ws_elems;
       int rc = 0;
-      for (int w = 0; w < 3 && !rc; ++w) rc = l.conv(&d, st);
+      for (int w = 0; w < 2 && !rc; ++w) rc = l.conv(&d, st);
       if (rc) { printf(" | error: %s", l.err ? l.err() : "?"); continue; }
-      HIP_OK(hipStreamSynchronize(st));
+      // calibrate, then warm up for warm_ms and time for >= time_ms WITHOUT an idle gap in between: after an idle period
+      // the chip runs its first milliseconds at a lower clock (a 0.3 ms kernel measured right behind a synchronize is
+      // 15-20 % slower than the same kernel in a busy stream)
       HIP_OK(hipEventRecord(e0, st));
-      for (int it = 0; it < iters; ++it) l.conv(&d, st);
+      l.conv(&d, st);
       HIP_OK(hipEventRecord(e1, st));
       HIP_OK(hipEventSynchronize(e1));
       float ms;
       HIP_OK(hipEventElapsedTime(&ms, e0, e1));
-      const double us = ms * 1e3 / iters;
+      const double est_ms = std::max(1e-3, (double)ms);
+      const int n_warm = (int)std::min(5000.0, std::max(1.0, warm_ms / est_ms));
+      const int n_time = (int)std::min(20000.0, std::max((double)iters, time_ms / est_ms));
+      if (keepalive_ms > 0) hipLaunchKernelGGL(keepalive_kernel, dim3(1), dim3(64), 0, st2, (long long)keepalive_ms * 100000ll, (int*)nullptr);
+      for (int w = 0; w < n_warm; ++w) l.conv(&d, st);
+      HIP_OK(hipEventRecord(e0, st));
+      for (int it = 0; it < n_time; ++it) l.conv(&d, st);
+      HIP_OK(hipEventRecord(e1, st));
+      HIP_OK(hipEventSynchronize(e1));
+      HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+      if (keepalive_ms > 0) HIP_OK(hipStreamSynchronize(st2));
+      const double us = ms * 1e3 / n_time;
       frame_us[li] += us * ly.calls;
       (ly.set == 1 ? big_us : small_us)[li] += us * ly.calls;
-      printf(" | %8.1f us %6.1f TF", us, gf / us * 1e3);
+      if (csv) printf("\ncsv,%s,%zu,%.2f,%.3f,%.1f", ly.name, li, us, gf, ly.calls);
+      else printf(" | %8.1f us %6.1f TF", us, gf / us * 1e3);
       if (check) {
         std::vector<float> o(out_n);
         HIP_OK(hipMemcpy(o.data(), d_out, out_n * 4, hipMemcpyDeviceToHost));

@@ -25,6 +25,7 @@
 // GEMM view as before:  M = cout, N = batch*OH*OW (pixels, batch-major), K = KH*KW*(C0+C1).
 // MFMA k assignment inside a 32-deep K step: group q (0..3), MFMA e (0..3): lanes 0-31 feed k = 8q + e, lanes 32-63
 // feed k = 8q + 4 + e  (the order of the fp32 FMA chain of one output; deterministic).
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv_args.h"
@@ -516,8 +517,23 @@ int launch_tile_q4(const ConvArgs& a, hipStream_t st) {
   p.per_split = ksteps_total;
   const int64_t blocks = (int64_t)p.tiles_m * p.tiles_n;
   p.splits = 1;
-  const int64_t target_blocks = 512;
-  if (a.ws && blocks < 256 && ksteps_total >= (blocks >= 128 ? 32 : 8)) {
+  int64_t target_blocks = 512;
+  // measured (tools/convlab sweep, profiles/r04a): from ~190 tiles up the split (+ its reduction pass) loses
+  bool want_split = a.ws && blocks < 192 && ksteps_total >= (blocks >= 128 ? 32 : 8);
+#ifdef DEVA_CONV_PROBES
+  {
+    static const int forced = [] {
+      const char* e = getenv("DEVA_CONV_SPLIT_TARGET");  // blocks to aim for; 0 = no split-K at all
+      return e ? atoi(e) : -1;
+    }();
+    if (forced == 0) want_split = false;
+    if (forced > 0) {
+      target_blocks = forced;
+      want_split = a.ws && blocks < forced;
+    }
+  }
+#endif
+  if (want_split) {
     int64_t sp = ceil_div(target_blocks, blocks);
     if (sp > ksteps_total / 4) sp = ksteps_total / 4;
     if (sp > 16) sp = 16;
@@ -548,6 +564,21 @@ int launch_tile_q4(const ConvArgs& a, hipStream_t st) {
 }  // namespace
 
 int launch_conv_q4(const ConvArgs& a, hipStream_t st) {
+#ifdef DEVA_CONV_PROBES  // `make PROBES=1`: A/B runs of the tile policy (tools/convlab)
+  {
+    static const int forced = [] {
+      const char* e = getenv("DEVA_CONV_TILE");
+      return e ? atoi(e) : 0;
+    }();
+    switch (forced) {
+      case 128: if (a.cout >= 64) return launch_tile_q4<128, 128, 2, 4, 4>(a, st); break;
+      case 64: if (a.cout > 32) return launch_tile_q4<64, 64, 2, 2, 1>(a, st); break;
+      case 12864: if (a.cout >= 64) return launch_tile_q4<128, 64, 2, 2, 2>(a, st); break;
+      case 64128: if (a.cout > 32) return launch_tile_q4<64, 128, 1, 4, 2>(a, st); break;
+      default: break;
+    }
+  }
+#endif
   if (a.cout <= 32) return launch_tile_q4<32, 128, 1, 4, 1>(a, st);
   const int64_t blocks128 = ceil_div(a.cout, 128) * ceil_div(a.n_total, 128);
   const int64_t blocks64 = ceil_div(a.cout, 64) * ceil_div(a.n_total, 64);

@@ -10,8 +10,8 @@ from typing import Optional, Tuple
 
 import torch
 
-from . import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQUARE_PLUS_ONE, KLAYOUT_CHUNK32, KLAYOUT_TAP_MAJOR, ConvDesc,
-               DevaHipError, check, lib)
+from . import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQUARE_PLUS_ONE, KLAYOUT_CHUNK32, KLAYOUT_Q4, KLAYOUT_TAP_MAJOR,
+               ConvDesc, DevaHipError, check, lib)
 
 __all__ = ['PackedConv', 'pack_conv', 'conv2d', 'maxpool3x3s2', 'upsample2x_add', 'area_downsample',
            'aggregate', 'softmax_channels', 'upsample4x_softmax', 'cbam', 'gru_update',
@@ -55,9 +55,10 @@ def _batched(t: torch.Tensor, name: str) -> Tuple[int, int]:
 # ------------------------------------------------------------------------------------------ conv
 @dataclass
 class PackedConv:
-    """weights of one convolution in the kernel's layout [K][cout_pad]; K ordered tap-major
-    (k = tap*Cin + c) or, for Cin % 32 == 0 and kernels larger than 1x1, in 32-channel slabs
-    (k = ((c/32)*KH*KW + tap)*32 + c%32) -- see include/deva_hip.h"""
+    """weights of one convolution in the kernel's layout; K ordered tap-major (k = tap*Cin + c) or, for
+    Cin % 32 == 0 and kernels larger than 1x1, in 32-channel slabs (k = ((c/32)*KH*KW + tap)*32 + c%32);
+    stored [K][cout_pad], or k-quad interleaved [ceil(K/4)][cout_pad][4] when k_layout carries KLAYOUT_Q4
+    (every convolution with more than one output channel) -- see include/deva_hip.h"""
     weight: torch.Tensor
     bias: Optional[torch.Tensor]
     cin: int
@@ -90,6 +91,13 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
     else:
         layout = KLAYOUT_TAP_MAJOR  # [tap][cin][cout]
         packed[:, :cout] = w.permute(2, 3, 1, 0).reshape(kh * kw * cin, cout)
+    if cout > 1:  # k-quad interleave for the lean-loop kernels (csrc/conv_mfma.hip); same arithmetic as deva_conv_pack
+        k = packed.shape[0]
+        kq = (k + 3) // 4
+        if kq * 4 != k:
+            packed = torch.cat([packed, torch.zeros(kq * 4 - k, cout_pad, dtype=packed.dtype, device=packed.device)], 0)
+        packed = packed.view(kq, 4, cout_pad).permute(0, 2, 1).contiguous().view(kq * 4, cout_pad)
+        layout |= KLAYOUT_Q4
     if device is not None:
         packed = packed.to(device)
         b = None if b is None else b.to(device)
@@ -151,7 +159,7 @@ def conv2d(pc: PackedConv, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, 
     c1 = 0 if x1 is None else x1.shape[1]
     if c0 + c1 != pc.cin:
         raise DevaHipError(f'conv2d: {c0}+{c1} input channels, weights expect {pc.cin}')
-    if pc.k_layout == KLAYOUT_CHUNK32 and (c0 % 32 or c1 % 32):
+    if (pc.k_layout & 0xf) == KLAYOUT_CHUNK32 and (c0 % 32 or c1 % 32):
         raise DevaHipError('conv2d: 32-channel-slab weights need both concatenated inputs to be multiples of 32 channels')
     batch = max(x0.shape[0], 1 if x1 is None else x1.shape[0], 1 if residual is None else residual.shape[0])
     h, w = x0.shape[-2:]
