@@ -53,7 +53,8 @@ __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, int voff, i
 // KIND 2: any kernel with c0 and c0+c1 multiples of 32 (tap and source uniform per K step), scalar gathers
 // KIND 3: anything (per-element decode through a table: the 2/3/4-channel stems, odd channel splits)
 template <int BM, int BN, int WAVES_M, int WAVES_N, int KIND, int MINW>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_mfma_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (KIND <= 1 || MINW < 2) ? MINW : 2) void conv_mfma_kernel(const ConvArgs p) {
+  // (the scalar-gather kinds carry 64-bit pointers and per-element validity: two waves per SIMD, no spills)
   constexpr int THREADS = 64 * WAVES_M * WAVES_N;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -188,37 +189,40 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_mfma_kernel
   }
   const int ks_last = ks0 + max(ksteps, 1) - 1;
 
-  // ---- staging registers
-  f32x4 ra[A_V4];
-  f32x4 rbv[B_V4];
+  // ---- staging registers: TWO sets for the per-step tiles (the loads of step s+3 are issued while those of step s+2
+  // are still in flight: two K steps of latency cover instead of one -- a workgroup alone on its CU has nobody to
+  // hide an HBM miss behind), one for the row tile of the 3x3 path (loaded a whole group ahead)
+  f32x4 ra[2][A_V4];
+  f32x4 rbv[ROW ? 1 : 2][B_V4];
   float rh = 0.0f;
-  float rb[B_PT];
+  float rb[B_PT];  // scalar gathers (KIND 2, 3): one set, loaded one step ahead
   unsigned ok_b = 0;
-  int rows_valid = BK;  // KIND 0: rows of the staged tile that exist in their source
+  int rows_valid[2] = {BK, BK};  // KIND 0: rows of the staged tile that exist in their source
 
-  // global -> registers for K step t (clamped to the last step of this workgroup: the tail re-loads, unused)
-  auto load_issue = [&](int t_raw, auto row_tile) {
-    constexpr bool WITH_ROWS = decltype(row_tile)::value;  // ROW: also the (slab, dy) row tile that starts at step t
+  // global -> registers (set SET) for K step t (clamped to the last step of this workgroup: the tail re-loads, unused)
+  auto load_issue = [&](int t_raw, auto setc, auto row_tile, int tb_raw) {
+    constexpr int SET = decltype(setc)::value;
+    constexpr bool WITH_ROWS = decltype(row_tile)::value;  // ROW: the (slab, dy) row tile that starts at step t
     const int t = min(t_raw, ks_last);
     {
       const int off = t * a_step_bytes;
       const __amdgpu_buffer_rsrc_t r = make_rsrc(reinterpret_cast<const char*>(p.w) + off, max(a_total_bytes - off, 0));
 #pragma unroll
-      for (int i = 0; i < A_V4; ++i) ra[i] = buf_load4(r, a_voff, i * a_pass_bytes);
+      for (int i = 0; i < A_V4; ++i) ra[SET][i] = buf_load4(r, a_voff, i * a_pass_bytes);
     }
     if (KIND == 0) {
       const int cbase = t * BK;
       const bool first = cbase < p.c0;
       const int c = first ? cbase : cbase - p.c0;
-      rows_valid = min(BK, (first ? p.c0 : p.c1) - c);
+      rows_valid[SET] = min(BK, (first ? p.c0 : p.c1) - c);
       const float* base = (first ? p.in0 : p.in1) + (int64_t)c * p.HW;
       const int64_t span = (first ? p.in0_span : p.in1_span) - (int64_t)c * p.HW;
       const __amdgpu_buffer_rsrc_t r = make_rsrc(base, (int)min(span * 4, (int64_t)0x7fffffff));
       const int voff = first ? b_voff0 : b_voff1;
 #pragma unroll
       for (int i = 0; i < PAIRS; ++i) {
-        rbv[2 * i] = buf_load4(r, voff, i * b_pass_bytes);
-        rbv[2 * i + 1] = buf_load4(r, voff, i * b_pass_bytes + b_row_bytes);
+        rbv[ROW ? 0 : SET][2 * i] = buf_load4(r, voff, i * b_pass_bytes);
+        rbv[ROW ? 0 : SET][2 * i + 1] = buf_load4(r, voff, i * b_pass_bytes + b_row_bytes);
       }
     } else if (KIND == 1) {
       if (WITH_ROWS) {
@@ -231,21 +235,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_mfma_kernel
         const int voff = first ? b_voff0 : b_voff1;
 #pragma unroll
         for (int i = 0; i < PAIRS; ++i) {
-          rbv[2 * i] = buf_load4(r, voff, i * b_pass_bytes);
-          rbv[2 * i + 1] = buf_load4(r, voff, i * b_pass_bytes + b_row_bytes);
+          rbv[0][2 * i] = buf_load4(r, voff, i * b_pass_bytes);
+          rbv[0][2 * i + 1] = buf_load4(r, voff, i * b_pass_bytes + b_row_bytes);
         }
         rh = buf_load1(r, first ? h_voff0 : h_voff1, 0);
       }
-    } else {
-      ok_b = 0;
-      const int k0 = t * BK;
+    } else if (tb_raw >= 0) {
+      unsigned okb = 0;
+      const int tb = min(tb_raw, ks_last);
+      const int k0 = tb * BK;
       if (KIND == 2) {
         int tap = 0, cbase = k0;
         if (p.KH * p.KW > 1) {
           if ((p.k_layout & 0xf) == DEVA_KLAYOUT_CHUNK32) {
             const int taps = p.KH * p.KW;
-            const int chunk = t / taps;
-            tap = t - chunk * taps;
+            const int chunk = tb / taps;
+            tap = tb - chunk * taps;
             cbase = chunk * BK;
           } else {
             tap = k0 / p.ctot;
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_mfma_kernel
           const int ci = bk_group + i * KG;
           const bool kin = k0 + ci < p.K;
           rb[i] = sp[kin ? (int64_t)ci * p.HW : 0];
-          ok_b |= (okp && kin) ? (1u << i) : 0u;
+          okb |= (okp && kin) ? (1u << i) : 0u;
         }
       } else {
 #pragma unroll
@@ -287,55 +292,60 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_mfma_kernel
           const float* sp = first ? src0 : src1;
           const int64_t off = ok ? ((int64_t)(first ? c : (c - p.c0)) * p.HW + (ih * p.W + iw)) : 0;
           rb[i] = sp[off];
-          ok_b |= ok ? (1u << i) : 0u;
+          okb |= ok ? (1u << i) : 0u;
         }
       }
+      ok_b = okb;
     }
   };
 
-  // registers -> LDS buffers of K step t.  Activation tile: element (K row r, column c) lives at ((r/2)*BNP + c)*2 + r%2.
+  // registers (set SET) -> LDS buffers SET (per-step tiles) / GB (row tile).  Activation tile: element (K row r,
+  // column c) lives at ((r/2)*BNP + c)*2 + r%2.
   auto relu4 = [](f32x4& v) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j], 0.0f, __builtin_inff());  // one v_med3_f32
   };
-  auto store_pairs = [&](float* bt, int col0) {  // rows (2a, 2a+1), a = vk + i*KGV; pixels col0 + 4*vq .. +3
+  auto store_pairs = [&](const f32x4* rv, float* bt, int col0) {  // rows (2a, 2a+1), a = vk + i*KGV; pixels col0 + 4*vq .. +3
 #pragma unroll
     for (int i = 0; i < PAIRS; ++i) {
-      const f32x4 r0 = rbv[2 * i], r1 = rbv[2 * i + 1];
+      const f32x4 r0 = rv[2 * i], r1 = rv[2 * i + 1];
       float* d = bt + ((vk + i * KGV) * BNP + col0 + 4 * vq) * 2;
       *reinterpret_cast<f32x4*>(d) = f32x4{r0[0], r1[0], r0[1], r1[1]};
       *reinterpret_cast<f32x4*>(d + 4) = f32x4{r0[2], r1[2], r0[3], r1[3]};
     }
   };
-  auto lds_store = [&](int t, auto row_tile) {
+  auto lds_store = [&](auto setc, auto row_tile, auto gbc) {
+    constexpr int SET = decltype(setc)::value;
     constexpr bool WITH_ROWS = decltype(row_tile)::value;
-    float* a = sA + (t & 1) * A_FLOATS + tid * 4;
+    constexpr int GB = decltype(gbc)::value;
+    float* a = sA + SET * A_FLOATS + tid * 4;
 #pragma unroll
-    for (int i = 0; i < A_V4; ++i) *reinterpret_cast<f32x4*>(a + i * THREADS * 4) = ra[i];
+    for (int i = 0; i < A_V4; ++i) *reinterpret_cast<f32x4*>(a + i * THREADS * 4) = ra[SET][i];
     if (KIND == 0) {
+      f32x4* rv = rbv[ROW ? 0 : SET];
       if (p.relu_in) {
 #pragma unroll
-        for (int i = 0; i < B_V4; ++i) relu4(rbv[i]);
+        for (int i = 0; i < B_V4; ++i) relu4(rv[i]);
       }
-      if (rows_valid < BK) {
+      if (rows_valid[SET] < BK) {
 #pragma unroll
         for (int i = 0; i < B_V4; ++i)
-          if (2 * (vk + (i >> 1) * KGV) + (i & 1) >= rows_valid) rbv[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+          if (2 * (vk + (i >> 1) * KGV) + (i & 1) >= rows_valid[SET]) rv[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       }
-      store_pairs(sB + (t & 1) * B_FLOATS, 0);
+      store_pairs(rv, sB + SET * B_FLOATS, 0);
     } else if (KIND == 1) {
       if (WITH_ROWS) {
-        float* bt = sB + ((t / 3) & 1) * B_FLOATS;
+        float* bt = sB + GB * B_FLOATS;
         if (p.relu_in) {
 #pragma unroll
-          for (int i = 0; i < B_V4; ++i) relu4(rbv[i]);
+          for (int i = 0; i < B_V4; ++i) relu4(rbv[0][i]);
           rh = __builtin_amdgcn_fmed3f(rh, 0.0f, __builtin_inff());
         }
-        store_pairs(bt, 4);
+        store_pairs(rbv[0], bt, 4);
         if (tid < 64) bt[((h_row >> 1) * BNP + (h_side ? BN + 4 : 3)) * 2 + (h_row & 1)] = rh;
       }
     } else {
-      float* b = sB + (t & 1) * B_FLOATS + bn_local * 2;
+      float* b = sB + SET * B_FLOATS + bn_local * 2;
 #pragma unroll
       for (int i = 0; i < B_PT; ++i) {
         const int r = bk_group + i * KG;
@@ -372,27 +382,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_mfma_kernel
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][e], fb[set][j][e >> 1][e & 1], acc[i][j], 0, 0, 0);
   };
 
-  // ROW: 3-bit validity (dx = 0..2) of this lane's pixel for the dy of K step t; the lane's read base of a step
+  // ROW: 3-bit validity (dx = 0..2) of this lane's pixel for the dy of K step t; the lane's read base of a step is its
+  // own column (+ dx) or, when the tap falls into the zero padding, the zero column
   auto taps_of = [&](int t) { return (cmask >> (t % 9 / 3 * 3)) & 7u; };
-  auto b_base = [&](int t, int dx, unsigned m3) {
-    const int buf = (ROW ? ((t / 3) & 1) : (t & 1)) * B_FLOATS;
-    if (!ROW) return b_rd0 + buf;
-    return ((m3 >> dx) & 1u) ? (b_rd0 + buf + 2 * dx) : (b_zero0 + buf);
-  };
-
   unsigned m3 = ROW ? taps_of(ks0) : 0u;
-  const float* b_cur = b_base(ks0, 0, m3);  // read base of the current step
+  const float* b_cur = ROW ? ((m3 & 1u) ? b_rd0 : b_zero0) : b_rd0;  // read base of the current step
 
-  // One K step.  DX: the dx tap of the step (ROW; steps come in (slab, dy) groups of three, splits start on group
-  // boundaries).
-  auto step = [&](int s, auto dxc) {
-    constexpr int DX = decltype(dxc)::value;
+  // One K step; all buffer / register-set indices are compile-time (the loop is unrolled over them):
+  // DX: dx tap of the step (ROW: steps come in (slab, dy) groups of three; splits start on group boundaries),
+  // PAR: parity of the step within this workgroup, GB: parity of the row-tile group.
+  auto step = [&](int s, auto dxc, auto parc, auto gbc) {
+    constexpr int DX = decltype(dxc)::value, PAR = decltype(parc)::value, GB = decltype(gbc)::value;
     constexpr int DXN = ROW ? (DX + 1) % 3 : 0;
+    constexpr int GBN = (ROW && DX == 2) ? (GB ^ 1) : GB;
     const int t = ks0 + s;
-    const float* a_rd = a_rd0 + (t & 1) * A_FLOATS;
-    const float* a_nx = a_rd0 + ((t + 1) & 1) * A_FLOATS;
-    if (ROW && DX == 2) m3 = taps_of(t + 1);
-    const float* b_nx = b_base(t + 1, DXN, m3);
+    const float* a_rd = a_rd0 + PAR * A_FLOATS;
+    const float* a_nx = a_rd0 + (PAR ^ 1) * A_FLOATS;
+    const float* b_nx;
+    if (ROW) {
+      if (DX == 2) m3 = taps_of(t + 1);
+      b_nx = ((m3 >> DXN) & 1u) ? (b_rd0 + GBN * B_FLOATS + 2 * DXN) : (b_zero0 + GBN * B_FLOATS);
+    } else {
+      b_nx = b_rd0 + (PAR ^ 1) * B_FLOATS;
+    }
     // every segment: LDS reads of the NEXT group first (they return under the MFMAs of this one), then the 8 MFMAs
     frag_load(1, a_rd, b_cur, 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -402,38 +414,56 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_mfma_kernel
     __builtin_amdgcn_sched_barrier(0);
     mfma_group(1);
     __builtin_amdgcn_sched_barrier(0);
-    lds_store(t + 1, std::integral_constant<bool, DX == 2>{});
     frag_load(1, a_rd, b_cur, 3);
+    lds_store(std::integral_constant<int, PAR ^ 1>{}, std::integral_constant<bool, DX == 2>{}, std::integral_constant<int, GB ^ 1>{});
     __builtin_amdgcn_sched_barrier(0);
     mfma_group(0);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
-    load_issue(t + 2, std::integral_constant<bool, DX == 1>{});
+    load_issue(t + 3, std::integral_constant<int, PAR ^ 1>{}, std::integral_constant<bool, DX == 0>{}, t + 2);
     frag_load(0, a_nx, b_nx, 0);
     __builtin_amdgcn_sched_barrier(0);
     mfma_group(1);
     __builtin_amdgcn_sched_barrier(0);
     b_cur = b_nx;
   };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
 
-  // ---- prologue: zero column, tile of the first step, loads of the second, first fragments
+  // ---- prologue: zero column, tile of the first step, loads of the next two, first fragments
   if (ROW) {
     for (int i = tid; i < 2 * BK; i += THREADS) sB[(i >> 5) * B_FLOATS + ((i & 31) >> 1) * BNP * 2 + (i & 1)] = 0.0f;
   }
-  load_issue(ks0, std::true_type{});
-  lds_store(ks0, std::true_type{});
+  load_issue(ks0, I0{}, std::true_type{}, ks0);
+  lds_store(I0{}, std::true_type{}, I0{});
   __syncthreads();
-  load_issue(ks0 + 1, std::false_type{});
-  frag_load(0, a_rd0 + (ks0 & 1) * A_FLOATS, b_cur, 0);
+  load_issue(ks0 + 1, I1{}, std::false_type{}, ks0 + 1);
+  load_issue(ks0 + 2, I0{}, std::false_type{}, -1);
+  frag_load(0, a_rd0, b_cur, 0);
 
   if (ROW) {
-    for (int s = 0; s < ksteps; s += 3) {
-      step(s, std::integral_constant<int, 0>{});
-      step(s + 1, std::integral_constant<int, 1>{});
-      step(s + 2, std::integral_constant<int, 2>{});
+    int s = 0;
+    for (; s + 6 <= ksteps; s += 6) {
+      step(s, I0{}, I0{}, I0{});
+      step(s + 1, I1{}, I1{}, I0{});
+      step(s + 2, I2{}, I0{}, I0{});
+      step(s + 3, I0{}, I1{}, I1{});
+      step(s + 4, I1{}, I0{}, I1{});
+      step(s + 5, I2{}, I1{}, I1{});
+    }
+    if (s < ksteps) {
+      step(s, I0{}, I0{}, I0{});
+      step(s + 1, I1{}, I1{}, I0{});
+      step(s + 2, I2{}, I0{}, I0{});
     }
   } else {
-    for (int s = 0; s < ksteps; ++s) step(s, std::integral_constant<int, 0>{});
+    int s = 0;
+    for (; s + 2 <= ksteps; s += 2) {
+      step(s, I0{}, I0{}, I0{});
+      step(s + 1, I0{}, I1{}, I0{});
+    }
+    if (s < ksteps) step(s, I0{}, I0{}, I0{});
   }
 
   if (p.splits > 1) {
