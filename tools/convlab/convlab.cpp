@@ -131,7 +131,7 @@ int main(int argc, char** argv) {
   std::string libs = "tracking-anything-with-deva_amd/deva/hip/libdeva_hip.so";
   std::string only, set = "frame480", shapes;
   int iters = 20;
-  bool check = false, csv = false;
+  bool check = false, csv = false, stamps = false;
   int keepalive_ms = 0;
   double warm_ms = 15.0, time_ms = 20.0;
   int q4 = 1;
@@ -144,6 +144,7 @@ int main(int argc, char** argv) {
     else if (a == "--check") check = true;
     else if (a == "--noq4") q4 = 0;
     else if (a == "--csv") csv = true;
+    else if (a == "--stamps") stamps = true;
     else if (a == "--keepalive" && i + 1 < argc) keepalive_ms = atoi(argv[++i]);
     else if (a == "--warm_ms" && i + 1 < argc) warm_ms = atof(argv[++i]);
     else if (a == "--time_ms" && i + 1 < argc) time_ms = atof(argv[++i]);
@@ -307,6 +308,35 @@ int main(int argc, char** argv) {
       const double us = ms * 1e3 / n_time;
       frame_us[li] += us * ly.calls;
       (ly.set == 1 ? big_us : small_us)[li] += us * ly.calls;
+      if (stamps) {  // probes library: wall-clock stamps of one more launch (entry, tile 0 staged, loop end, epilogue end)
+        typedef int (*probe_fn)(unsigned long long*);
+        probe_fn setp = (probe_fn)dlsym(l.h, "deva_conv_set_probe");
+        if (setp) {
+          const int nb = 65536;
+          unsigned long long* dbuf;
+          HIP_OK(hipMalloc(&dbuf, nb * 4 * 8));
+          HIP_OK(hipMemset(dbuf, 0, nb * 4 * 8));
+          setp(dbuf);
+          l.conv(&d, st);
+          HIP_OK(hipStreamSynchronize(st));
+          setp(nullptr);
+          std::vector<unsigned long long> h(nb * 4);
+          HIP_OK(hipMemcpy(h.data(), dbuf, nb * 4 * 8, hipMemcpyDeviceToHost));
+          HIP_OK(hipFree(dbuf));
+          unsigned long long t0 = ~0ull, t3 = 0;
+          int blocks = 0;
+          double s01 = 0, s12 = 0, s23 = 0, first_end = 1e30, last_start = 0;
+          for (int b = 0; b < nb; ++b)
+            if (h[b * 4]) { ++blocks; t0 = std::min(t0, h[b * 4]); t3 = std::max(t3, h[b * 4 + 3]); }
+          for (int b = 0; b < nb; ++b)
+            if (h[b * 4]) {
+              s01 += (double)(h[b * 4 + 1] - h[b * 4]); s12 += (double)(h[b * 4 + 2] - h[b * 4 + 1]); s23 += (double)(h[b * 4 + 3] - h[b * 4 + 2]);
+              first_end = std::min(first_end, (double)(h[b * 4 + 3] - t0)); last_start = std::max(last_start, (double)(h[b * 4] - t0));
+            }
+          printf("\n    stamps: %d workgroups, kernel span %.2f us; mean prologue %.2f, loop %.2f, tail %.2f us; last start +%.2f, first end +%.2f",
+                 blocks, (t3 - t0) * 0.01, s01 / blocks * 0.01, s12 / blocks * 0.01, s23 / blocks * 0.01, last_start * 0.01, first_end * 0.01);
+        }
+      }
       if (csv) printf("\ncsv,%s,%zu,%.2f,%.3f,%.1f", ly.name, li, us, gf, ly.calls);
       else printf(" | %8.1f us %6.1f TF", us, gf / us * 1e3);
       if (check) {

@@ -30,6 +30,17 @@
 
 #include "conv_args.h"
 
+#ifdef DEVA_CONV_PROBES
+// `make PROBES=1` builds only: wall-clock stamps (100 MHz) of wave 0 of every workgroup at four points of the kernel
+__device__ unsigned long long* g_conv_probe = nullptr;
+#define DEVA_STAMP(i)                                                                                       \
+  do {                                                                                                      \
+    if (g_conv_probe && threadIdx.x == 0 && blockIdx.y == 0) g_conv_probe[blockIdx.x * 4 + (i)] = wall_clock64(); \
+  } while (0)
+#else
+#define DEVA_STAMP(i)
+#endif
+
 namespace deva {
 namespace {
 
@@ -52,10 +63,16 @@ __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, int voff, i
 // KIND 1: 3x3, stride 1, pad 1, 32-channel-slab K order, guard-banded inputs (row reuse)
 // KIND 2: any kernel with c0 and c0+c1 multiples of 32 (tap and source uniform per K step), scalar gathers
 // KIND 3: anything (per-element decode through a table: the 2/3/4-channel stems, odd channel splits)
-template <int BM, int BN, int WAVES_M, int WAVES_N, int KIND, int MINW>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (KIND <= 1 || MINW < 2) ? MINW : 2) void conv_mfma_kernel(const ConvArgs p) {
+//
+// WK > 1: K slices inside the workgroup.  The workgroup is WK independent groups of WAVES_M x WAVES_N waves; group k
+// owns its own LDS tiles and the k-th part of the workgroup's K range, all groups share the barriers, and the partial
+// sums meet in LDS in a fixed order (k = 1, 2, ...) before group 0 runs the epilogue.  For layers with few output
+// tiles (batch-1 key encoder at 30x54) this is the split-K that fills the SIMDs without partial sums in HBM and
+// without a reduction launch.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KIND, int MINW, int WK>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (KIND <= 1 || MINW < 2) ? MINW : 2) void conv_mfma_kernel(const ConvArgs p) {
   // (the scalar-gather kinds carry 64-bit pointers and per-element validity: two waves per SIMD, no spills)
-  constexpr int THREADS = 64 * WAVES_M * WAVES_N;
+  constexpr int THREADS = 64 * WAVES_M * WAVES_N;  // threads of one K-slice group
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
   static_assert(TM >= 1 && TN >= 1, "wave tile");
@@ -76,12 +93,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (KIND <= 1 || MINW < 2) ? M
   constexpr int B_PT = VEC ? 1 : BK / KG;
   constexpr int KTAB = 1024;
 
-  __shared__ __attribute__((aligned(16))) float smem[2 * A_FLOATS + 2 * B_FLOATS];
+  constexpr int REGION = 2 * A_FLOATS + 2 * B_FLOATS;
+  __shared__ __attribute__((aligned(16))) float smem[WK * REGION];
   __shared__ unsigned s_ktab[KIND == 3 ? KTAB : 1];
-  float* const sA = smem;
-  float* const sB = smem + 2 * A_FLOATS;
+  const int slice = WK > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / THREADS) : 0;
+  float* const sA = smem + slice * REGION;
+  float* const sB = sA + 2 * A_FLOATS;
 
-  const int tid = threadIdx.x;
+  const int tid = WK > 1 ? (int)threadIdx.x % THREADS : (int)threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave / WAVES_N) * WM;
@@ -89,9 +108,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (KIND <= 1 || MINW < 2) ? M
   const int l31 = lane & 31;
   const int half = lane >> 5;
 
+  DEVA_STAMP(0);
   const bool ktab_ok = KIND == 3 && p.K <= KTAB && p.ctot < 65536 && p.KH < 256 && p.KW < 256;
   if (KIND == 3 && ktab_ok) {
-    for (int k = tid; k < p.K; k += THREADS) {
+    for (int k = threadIdx.x; k < p.K; k += THREADS * WK) {
       const int tap = k / p.ctot;
       const int dy = tap / p.KW;
       s_ktab[k] = (unsigned)(k - tap * p.ctot) | ((unsigned)dy << 16) | ((unsigned)(tap - dy * p.KW) << 24);
@@ -181,13 +201,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (KIND <= 1 || MINW < 2) ? M
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  // split-K: this workgroup accumulates K steps [ks0, ks0 + ksteps)
-  int ks0 = 0, ksteps = (p.K + BK - 1) / BK;
+  // split-K: this workgroup accumulates K steps [ks0, ks0 + ksteps) (its slice group: the slice-th part of them)
+  const int ksteps_total = (p.K + BK - 1) / BK;
+  int ks0 = 0, ksteps = ksteps_total;
   if (p.splits > 1) {
     ks0 = (int)blockIdx.y * p.per_split;
     ksteps = max(0, min(ksteps - ks0, p.per_split));
   }
-  const int ks_last = ks0 + max(ksteps, 1) - 1;
+  int loop_steps = ksteps;  // steps every slice group walks through (the barriers are shared)
+  if (WK > 1) {
+    int per = (ksteps + WK - 1) / WK;
+    if (ROW) per = (per + 2) / 3 * 3;
+    loop_steps = per;
+    ks0 += slice * per;
+    ksteps = max(0, min(ksteps - slice * per, per));
+  }
+  const int ks_end = ks0 + ksteps;                                          // steps from here on contribute zeros
+  const int ks_last = min(ks0 + max(ksteps, 1), ksteps_total) - 1;          // last step whose addresses are loaded
 
   // ---- staging registers: TWO sets for the per-step tiles (the loads of step s+3 are issued while those of step s+2
   // are still in flight: two K steps of latency cover instead of one -- a workgroup alone on its CU has nobody to
@@ -206,7 +236,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (KIND <= 1 || MINW < 2) ? M
     const int t = min(t_raw, ks_last);
     {
       const int off = t * a_step_bytes;
-      const __amdgpu_buffer_rsrc_t r = make_rsrc(reinterpret_cast<const char*>(p.w) + off, max(a_total_bytes - off, 0));
+      // weights of a step beyond this slice's range read as zeros (empty range)
+      const __amdgpu_buffer_rsrc_t r =
+          make_rsrc(reinterpret_cast<const char*>(p.w) + off, (WK > 1 && t_raw >= ks_end) ? 0 : max(a_total_bytes - off, 0));
 #pragma unroll
       for (int i = 0; i < A_V4; ++i) ra[SET][i] = buf_load4(r, a_voff, i * a_pass_bytes);
     }
@@ -438,13 +470,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (KIND <= 1 || MINW < 2) ? M
   load_issue(ks0, I0{}, std::true_type{}, ks0);
   lds_store(I0{}, std::true_type{}, I0{});
   __syncthreads();
+  DEVA_STAMP(1);
   load_issue(ks0 + 1, I1{}, std::false_type{}, ks0 + 1);
   load_issue(ks0 + 2, I0{}, std::false_type{}, -1);
   frag_load(0, a_rd0, b_cur, 0);
 
   if (ROW) {
     int s = 0;
-    for (; s + 6 <= ksteps; s += 6) {
+    for (; s + 6 <= loop_steps; s += 6) {
       step(s, I0{}, I0{}, I0{});
       step(s + 1, I1{}, I1{}, I0{});
       step(s + 2, I2{}, I0{}, I0{});
@@ -452,18 +485,46 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (KIND <= 1 || MINW < 2) ? M
       step(s + 4, I1{}, I0{}, I1{});
       step(s + 5, I2{}, I1{}, I1{});
     }
-    if (s < ksteps) {
+    if (s < loop_steps) {
       step(s, I0{}, I0{}, I0{});
       step(s + 1, I1{}, I1{}, I0{});
       step(s + 2, I2{}, I0{}, I0{});
     }
   } else {
     int s = 0;
-    for (; s + 2 <= ksteps; s += 2) {
+    for (; s + 2 <= loop_steps; s += 2) {
       step(s, I0{}, I0{}, I0{});
       step(s + 1, I0{}, I1{}, I0{});
     }
-    if (s < ksteps) step(s, I0{}, I0{}, I0{});
+    if (s < loop_steps) step(s, I0{}, I0{}, I0{});
+  }
+
+  DEVA_STAMP(2);
+  if (WK > 1) {
+    // ---- the slice groups' partial sums meet in LDS (the tiles are dead), added in the fixed order 1, 2, ...
+    __syncthreads();
+    constexpr int NACC = TM * TN * 16;
+    static_assert((WK - 1) * NACC * THREADS <= WK * REGION, "reduction scratch fits the tile regions");
+    if (slice > 0) {
+      float* red = smem + (slice - 1) * NACC * THREADS + tid;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((i * TN + j) * 16 + r) * THREADS] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (slice > 0) return;
+    for (int k = 1; k < WK; ++k) {
+      const float* red = smem + (k - 1) * NACC * THREADS + tid;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * TN + j) * 16 + r) * THREADS];
+    }
   }
 
   if (p.splits > 1) {
@@ -520,9 +581,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (KIND <= 1 || MINW < 2) ? M
       }
     }
   }
+  DEVA_STAMP(3);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MINW>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MINW, int WK = 1>
 int launch_tile_q4(const ConvArgs& a, hipStream_t st) {
   ConvArgs p = a;
   const bool uniform = a.ctot % BK == 0 && a.c0 % BK == 0;  // tap and source uniform per K step
@@ -545,6 +607,7 @@ int launch_tile_q4(const ConvArgs& a, hipStream_t st) {
   p.tiles_n = (int)ceil_div(a.n_total, BN);
   const int ksteps_total = (int)ceil_div(a.K, BK);
   p.per_split = ksteps_total;
+  const int blocks_eff_scale = WK;  // every workgroup already holds WK slice groups
   const int64_t blocks = (int64_t)p.tiles_m * p.tiles_n;
   p.splits = 1;
   int64_t target_blocks = 512;
@@ -564,28 +627,35 @@ int launch_tile_q4(const ConvArgs& a, hipStream_t st) {
   }
 #endif
   if (want_split) {
-    int64_t sp = ceil_div(target_blocks, blocks);
-    if (sp > ksteps_total / 4) sp = ksteps_total / 4;
+    int64_t sp = ceil_div(target_blocks, blocks * blocks_eff_scale);
+    if (sp > ksteps_total / (4 * WK)) sp = ksteps_total / (4 * WK);
     if (sp > 16) sp = 16;
     const int64_t fit = a.ws_elems / ((int64_t)a.cout * a.n_total);
     if (sp > fit) sp = fit;
     if (sp >= 2) {
       int per = (int)ceil_div(ksteps_total, sp);
-      if (kind == 1) per = (per + 2) / 3 * 3;  // row reuse: whole (slab, dy) groups
+      if (kind == 1) per = (per + 3 * WK - 1) / (3 * WK) * (3 * WK);  // row reuse: whole (slab, dy) groups per slice group
       sp = ceil_div(ksteps_total, per);
       p.splits = (int)sp;
       p.per_split = per;
     }
     if (p.splits < 2) p.splits = 1;
   }
-  const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splits), block(64 * WAVES_M * WAVES_N);
+  const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splits), block(64 * WAVES_M * WAVES_N * WK);
+  if constexpr (BM == 128 && WK > 1) {
+    if (kind >= 2) return launch_tile_q4<BM, BN, WAVES_M, WAVES_N, MINW, 1>(a, st);  // scalar kinds: no K-slice build at 1024 threads
+  }
   switch (kind) {
-    case 0: hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, 0, MINW>), grid, block, 0, st, p); break;
+    case 0: hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, 0, MINW, WK>), grid, block, 0, st, p); break;
     case 1:
-      if constexpr (BN / WAVES_N == 32) hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, 1, MINW>), grid, block, 0, st, p);
+      if constexpr (BN / WAVES_N == 32) hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, 1, MINW, WK>), grid, block, 0, st, p);
       break;
-    case 2: hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, 2, MINW>), grid, block, 0, st, p); break;
-    default: hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, 3, MINW>), grid, block, 0, st, p); break;
+    case 2:
+      if constexpr (!(BM == 128 && WK > 1)) hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, 2, MINW, WK>), grid, block, 0, st, p);
+      break;
+    default:
+      if constexpr (!(BM == 128 && WK > 1)) hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, 3, MINW, WK>), grid, block, 0, st, p);
+      break;
   }
   if (p.splits > 1) return launch_splitk_reduce(p, st);
   return check_launch("deva_conv2d");
@@ -603,6 +673,9 @@ int launch_conv_q4(const ConvArgs& a, hipStream_t st) {
     switch (forced) {
       case 128: if (a.cout >= 64) return launch_tile_q4<128, 128, 2, 4, 4>(a, st); break;
       case 64: if (a.cout > 32) return launch_tile_q4<64, 64, 2, 2, 1>(a, st); break;
+      case 642: if (a.cout > 32) return launch_tile_q4<64, 64, 2, 2, 1, 2>(a, st); break;
+      case 644: if (a.cout > 32) return launch_tile_q4<64, 64, 2, 2, 1, 4>(a, st); break;
+      case 1282: if (a.cout >= 64) return launch_tile_q4<128, 128, 2, 4, 4, 2>(a, st); break;
       case 12864: if (a.cout >= 64) return launch_tile_q4<128, 64, 2, 2, 2>(a, st); break;
       case 64128: if (a.cout > 32) return launch_tile_q4<64, 128, 1, 4, 2>(a, st); break;
       default: break;
@@ -610,11 +683,29 @@ int launch_conv_q4(const ConvArgs& a, hipStream_t st) {
   }
 #endif
   if (a.cout <= 32) return launch_tile_q4<32, 128, 1, 4, 1>(a, st);
+  // Tile policy (warm sweeps over the layers of the 480p frame, tools/convlab/sweep.sh, profiles/r04a):
+  //  * 128x128 (8 waves, wave tile 64x32) from 64 tiles up -- unless it would leave most CUs empty while 64x64 tiles
+  //    fill the chip; with at most one tile per CU the workgroup carries two K-slice groups (16 waves per CU);
+  //  * 64x64 (4 waves) otherwise; layers with few tiles and a long K loop run 2 or 4 K-slice groups per workgroup.
   const int64_t blocks128 = ceil_div(a.cout, 128) * ceil_div(a.n_total, 128);
   const int64_t blocks64 = ceil_div(a.cout, 64) * ceil_div(a.n_total, 64);
-  if (a.cout >= 128 && blocks128 >= 64 && !(blocks128 < 256 && blocks64 >= 256 && a.K <= 512))
+  const int ksteps = (int)ceil_div(a.K, BK);
+  const bool vec_kind = a.vec_ok && a.c0 % BK == 0 &&
+                        ((a.KH == 1 && a.KW == 1) || (a.ctot % BK == 0 && a.KH == 3 && a.KW == 3 && a.pad == 1 &&
+                                                      (a.k_layout & 0xf) == DEVA_KLAYOUT_CHUNK32));
+  if (a.cout >= 128 && blocks128 >= 64 && !(blocks128 < 192 && blocks64 >= 256)) {
+    if (vec_kind && blocks128 <= 256 && ksteps >= 16) return launch_tile_q4<128, 128, 2, 4, 4, 2>(a, st);
     return launch_tile_q4<128, 128, 2, 4, 4>(a, st);
+  }
+  if (ksteps >= 32 && blocks64 >= 64 && blocks64 <= 208) return launch_tile_q4<64, 64, 2, 2, 1, 4>(a, st);
+  if ((ksteps >= 16 && blocks64 <= 208) || (ksteps >= 32 && blocks64 <= 512)) return launch_tile_q4<64, 64, 2, 2, 1, 2>(a, st);
   return launch_tile_q4<64, 64, 2, 2, 1>(a, st);
 }
 
 }  // namespace deva
+
+#ifdef DEVA_CONV_PROBES
+extern "C" int deva_conv_set_probe(unsigned long long* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_probe), &buf, sizeof(buf));
+}
+#endif
