@@ -170,6 +170,24 @@ def test_fp16_prefilter_falls_back_where_its_bound_does_not_hold():
     assert flag & 12, flag
 
 
+def test_fp16_prefilter_fallback_counts_usage_once():
+    """A few LATE queries with 2 049 .. 4 096 candidates spread thinly over the sub-lists (no sub-list overflows: flag 8
+    alone, not 4): the fall-back decision must be taken before the re-score kernel has added any query's weights to
+    the usage counters, otherwise the fp32 fall-back counts the earlier queries twice (affinity.hip)."""
+    n, hw, k = 9000, 2048, 30
+    mk, ms, qk, qe = synth.affinity_inputs(n, hw, seed=11)
+    mk, ms, qk, qe = mk.clone(), ms.clone(), qk.clone(), qe.clone()
+    dup = torch.arange(0, n, 3)  # 3 000 identical tokens, spread over every token range
+    mk[:, dup] = mk[:, :1].clone()
+    ms[:, dup] = ms[:, :1].clone()
+    for q in (hw - 1, hw - 7, hw - 300):  # the duplicated key is THE best match of these queries: 3 000-way tie
+        qk[:, q] = mk[:, 0]
+        qe[:, q] = 1.0
+    fp32, pre, flag = _both_paths(mk, ms, qk, qe, k)
+    assert flag & 8 and not (flag & 4), f'expected the re-score capacity flag alone, got {flag}'
+    _assert_identical('thinly spread candidates', fp32, pre)
+
+
 def test_fp16_prefilter_shard_keys_equal_the_fp32_select():
     """the hand-over format of a bank shard (affinity_candidates) through both paths"""
     if os.environ.get('DEVA_TEST_DRYRUN') == '1':

@@ -1751,6 +1751,24 @@ __global__ __launch_bounds__(256) void affinity_pf_tau_kernel(const float* __res
   if (lane == 0) thr[q] = (T == 0u ? -INFINITY : from_orderable(T)) - 2.0f * (PF_ABS + eq[q]);
 }
 
+// Candidate totals per query, checked BEFORE the re-score kernel commits anything: a query with more candidates than
+// the re-score buffer holds (or fewer than k) raises the fall-back flag here, so that the re-score kernel -- which
+// writes idx / weight and adds to the usage counters -- either runs for every query or for none (it reads the flag
+// at entry; raised from inside it, the flag let earlier workgroups' usage additions stand and the fp32 fall-back
+// counted those queries twice).
+__global__ __launch_bounds__(256) void affinity_pf_check_kernel(const uint32_t* __restrict__ cand_cnt, int hw, int k,
+                                                                int n_sub, PfState* st) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  bool bad = false;
+  if (q < hw) {
+    const uint32_t* c = cand_cnt + (int64_t)q * n_sub;
+    uint32_t total = 0u;
+    for (int i = 0; i < n_sub; ++i) total += c[i] < (uint32_t)PF_SUB ? c[i] : (uint32_t)PF_SUB;
+    bad = total > (uint32_t)PF_RESC_MAX || total < (uint32_t)k;
+  }
+  if (__builtin_amdgcn_ballot_w64(bad) && (threadIdx.x & 63) == 0) atomicOr(&st->flag, 8u);
+}
+
 struct PfRescoreArgs {
   PfBank bank;
   const float* qk;
@@ -1829,10 +1847,7 @@ __global__ __launch_bounds__(256) void affinity_pf_rescore_kernel(const PfRescor
     const uint32_t other = (uint32_t)__shfl_xor((int)longest, o, 64);
     longest = other > longest ? other : longest;
   }
-  if (total > PF_RESC_MAX || total < k) {  // flat bank (or a bug): the fp32 kernels take over
-    if (lane == 0) atomicOr(&p.st->flag, 8u);
-    return;
-  }
+  if (total > PF_RESC_MAX || total < k) return;  // unreachable: affinity_pf_check_kernel raised the flag (same totals)
   const uint64_t* my_sub = p.cand + (sub0 + lane) * PF_SUB;
   for (uint32_t s0 = 0; s0 < longest; s0 += 4) {  // four independent loads in flight per lane
     uint64_t ent[4];
@@ -2339,6 +2354,8 @@ extern "C" int deva_affinity_read(const float* key_long, const float* shr_long, 
     } else {
       hipLaunchKernelGGL((affinity_pf_pass_kernel<1, 1>), grid, dim3(PF_QW * 64), 0, st, a);
     }
+    hipLaunchKernelGGL(affinity_pf_check_kernel, dim3((unsigned)ceil_div(hw, 256)), dim3(256), 0, st, a.cand_cnt, hw, k,
+                       L.splits * 2, state);
     PfRescoreArgs r;
     r.bank = b;
     r.qk = qk;

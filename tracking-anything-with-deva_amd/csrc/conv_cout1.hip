@@ -2,8 +2,9 @@
 // 2->1): on the matrix cores 31 of 32 output rows of the smallest MFMA tile would be padding, so these
 // run as a coalesced VALU dot product instead -- HBM/L2-bound, a few tens of microseconds.
 //
-// The weights of the one output channel are cached in LDS; each thread keeps 8 independent input
-// loads in flight (a serial load->FMA chain is L2-latency-bound); partial sums meet in LDS.
+// The weights of the one output channel and the decoded (channel, tap) of every reduction index are cached in LDS;
+// each thread keeps 8-16 independent input loads in flight (a serial load->FMA chain is L2-latency-bound); partial
+// sums meet in LDS.
 #include "conv_args.h"
 
 namespace deva {
@@ -11,16 +12,32 @@ namespace deva {
 
 namespace {
 
-// PX pixels x CG channel groups per 256-thread block: wide frames use 64 x 4, small frames 16 x 16 so
-// that a 30x54 feature map still spreads over ~100 workgroups
-template <int PX, int CG>
+// PX pixels x CG k-groups per 256-thread block.  The reduction index k = (tap, channel) is FLAT: a table in LDS
+// holds, per k, the decoded (channel, dy, dx) and the weight, thread (px, g) walks k = g, g + CG, ... with U loads in
+// flight.  (The first version looped over taps and split only the channels: the 7x7 gate over 2 channels ran 49
+// dependent load rounds on 2 of its 16 channel groups -- 46 us for 0.8 MFLOP.)
+template <int PX, int CG, int U>
 __global__ __launch_bounds__(256) void conv_cout1_kernel(const Cout1Args p) {
   static_assert(PX * CG == 256, "256 threads");
-  extern __shared__ float smem[];  // [K] weights of the single output channel, then [CG][PX] partials
+  extern __shared__ uint2 tab[];  // [K] {channel | dy << 16 | dx << 24, weight bits}, then [CG][PX] partials
   const int K = p.KH * p.KW * p.ctot;
-  float* wsm = smem;
-  float* red = smem + ((K + 63) & ~63);
-  for (int k = threadIdx.x; k < K; k += 256) wsm[k] = p.w[(int64_t)k * p.cout_pad];
+  float* red = reinterpret_cast<float*>(tab + ((K + 63) & ~63));
+  const int taps = p.KH * p.KW;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    int tap, c;
+    if (p.k_layout == DEVA_KLAYOUT_CHUNK32) {  // k = ((c/32)*taps + tap)*32 + c%32
+      const int slab = k >> 5;
+      const int chunk = slab / taps;
+      tap = slab - chunk * taps;
+      c = chunk * 32 + (k & 31);
+    } else {  // k = tap*ctot + c
+      tap = k / p.ctot;
+      c = k - tap * p.ctot;
+    }
+    const int dy = tap / p.KW;
+    tab[k] = make_uint2((unsigned)c | ((unsigned)dy << 16) | ((unsigned)(tap - dy * p.KW) << 24),
+                        __float_as_uint(p.w[(int64_t)k * p.cout_pad]));
+  }
   __syncthreads();
 
   const int px = threadIdx.x % PX;
@@ -34,33 +51,25 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const Cout1Args p) {
   const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
   const float* src0 = p.in0 + (int64_t)b * p.bs0;
   const float* src1 = p.in1 ? p.in1 + (int64_t)b * p.bs1 : p.in0;
-  const int taps = p.KH * p.KW;
-  constexpr int U = 8;  // channels in flight per thread
   float acc = 0.0f;
-  for (int tap = 0; tap < taps; ++tap) {
-    const int dy = tap / p.KW;
-    const int ih = ih0 + dy, iw = iw0 + (tap - dy * p.KW);
-    const bool ok = n_ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
-    const int off = ok ? (ih * p.W + iw) : 0;
-    // channels cg, cg+CG, cg+2CG, ...: U independent loads are issued before the FMAs consume them
-    for (int c0 = cg; c0 < p.ctot; c0 += CG * U) {
-      float v[U], wv[U];
+  for (int k0 = cg; k0 < K; k0 += CG * U) {
+    float v[U], wv[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int c = c0 + u * CG;
-        const bool in = c < p.ctot;
-        const int cc = in ? c : 0;
-        const float* sp = (cc < p.c0) ? (src0 + (int64_t)cc * p.HW) : (src1 + (int64_t)(cc - p.c0) * p.HW);
-        v[u] = sp[off];
-        const int k = (p.k_layout == DEVA_KLAYOUT_CHUNK32) ? (((cc >> 5) * taps + tap) * 32 + (cc & 31))
-                                                          : (tap * p.ctot + cc);
-        wv[u] = (in && ok) ? wsm[k] : 0.0f;
-      }
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + u * CG;
+      const bool in = k < K;
+      const uint2 e = tab[in ? k : 0];
+      const int c = (int)(e.x & 0xffffu);
+      const int ih = ih0 + (int)((e.x >> 16) & 0xffu), iw = iw0 + (int)(e.x >> 24);
+      const bool ok = in && n_ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+      const float* sp = (c < p.c0) ? (src0 + (int64_t)c * p.HW) : (src1 + (int64_t)(c - p.c0) * p.HW);
+      v[u] = sp[ok ? (ih * p.W + iw) : 0];
+      wv[u] = ok ? __uint_as_float(e.y) : 0.0f;
+    }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const float x = p.relu_in ? fmaxf(v[u], 0.0f) : v[u];
-        acc += wv[u] * x;
-      }
+    for (int u = 0; u < U; ++u) {
+      const float x = p.relu_in ? fmaxf(v[u], 0.0f) : v[u];
+      acc += wv[u] * x;
     }
   }
   red[cg * PX + px] = acc;
@@ -194,8 +203,20 @@ int launch_conv3x3_cout1_rows(const Cout1Args& a, hipStream_t st) {
 
 int launch_conv_cout1(const Cout1Args& a, hipStream_t st) {
   const int K = a.KH * a.KW * a.ctot;
-  const size_t smem = sizeof(float) * (((size_t)K + 63) / 64 * 64 + 256);
-  hipLaunchKernelGGL((conv_cout1_kernel<16, 16>), dim3((unsigned)ceil_div(a.n_total, 16)), dim3(256), smem, st, a);
+  if (a.ctot >= 65536 || a.KH >= 256 || a.KW >= 256) {
+    set_error("deva_conv2d(cout=1): channel / kernel size beyond the 16 / 8-bit table fields");
+    return 2;
+  }
+  const size_t smem = sizeof(uint2) * (((size_t)K + 63) / 64 * 64) + sizeof(float) * 256;
+  // short reductions: a wave of pixels x 4 k-groups; long ones on small maps: 8 pixels x 32 k-groups (the map is
+  // L2-resident, 32-byte runs are fine) so that ~100 k values per thread remain
+  if (K <= 512) {
+    hipLaunchKernelGGL((conv_cout1_kernel<64, 4, 8>), dim3((unsigned)ceil_div(a.n_total, 64)), dim3(256), smem, st, a);
+  } else if (a.n_total >= 8192) {
+    hipLaunchKernelGGL((conv_cout1_kernel<16, 16, 16>), dim3((unsigned)ceil_div(a.n_total, 16)), dim3(256), smem, st, a);
+  } else {
+    hipLaunchKernelGGL((conv_cout1_kernel<8, 32, 16>), dim3((unsigned)ceil_div(a.n_total, 8)), dim3(256), smem, st, a);
+  }
   return check_launch("deva_conv2d(cout=1)");
 }
 

@@ -717,7 +717,7 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
   // anything else stays on the MFMA tile
   const bool rows3x3 = a.cout == 1 && a.vec_ok && a.KH == 3 && a.KW == 3 && a.pad == 1 && a.OW % 4 == 0 &&
                        a.n_total >= 16384 && a.ctot <= 1024 && (int64_t)d->in_guard_elems >= a.W + 8;
-  if (rows3x3 || (a.cout == 1 && a.K <= 12288 && a.n_total < 16384)) {
+  if (rows3x3 || (a.cout == 1 && a.K <= 7168 && a.n_total < 16384)) {  // 8 bytes of LDS table per reduction index
     Cout1Args c;
     c.in0 = a.in0;
     c.in1 = a.in1;
