@@ -67,6 +67,17 @@ for p in (ROOT, os.path.join(ROOT, 'tracking-anything-with-deva_amd')):
 import torch  # noqa: E402
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md, dense fp32-in MFMA
+
+
+def conv_source_sha1():
+    """identity of the convolution kernels' build: the PMC traffic file of a round records it"""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, 'tracking-anything-with-deva_amd', 'csrc')
+    for name in ('conv_args.h', 'conv_igemm.hip', 'conv_mfma.hip', 'conv_cout1.hip', 'common.h'):
+        with open(os.path.join(d, name), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -223,14 +234,134 @@ def affinity_microbench(device, n=10000, hw=8160, k=30, iters=20):
                 prefilter_fell_back=bool(flag),
                 bound='f16 MFMA operand delivery + VALU scoring (the fp32 matrix rate no longer binds: only ~35 of the '
                       f'{n} tokens per query are scored in fp32)',
-                fp32_equivalent_tflops=flops / t / 1e12, peak_fp32_matrix_tflops=PEAK_FP32_MATRIX_TFLOPS,
-                frac_of_fp32_matrix_roof=flops / t / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
-                fp32_kernels_frac_of_fp32_matrix_roof=flops / (us[0] * 1e-6) / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
+                # the roofline fractions of what the kernels actually execute come first ...
                 f16_mfma_tflops=f16_flops / t / 1e12, f16_mfma_frac=f16_flops / t / 1e12 / PEAK_F16_MATRIX_TFLOPS,
                 hbm_algorithmic_gbps=b_alg / t / 1e9, hbm_algorithmic_frac=b_alg / t / 1e9 / PEAK_HBM_GBPS,
+                hbm_counter_traffic_over_algorithmic=_affinity_counter_ratio(b_alg),
+                fp32_kernels_frac_of_fp32_matrix_roof=flops / (us[0] * 1e-6) / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
+                # ... then the NOMINAL figure (the reference's 4*64*N*HW FLOPs, which the pre-filter no longer performs,
+                # over the read time): a speed-up expressed in TFLOP/s, NOT a roofline fraction
+                reference_flops_over_read_time_tflops_nominal=flops / t / 1e12,
+                reference_flops_over_read_time_vs_fp32_matrix_peak_nominal=flops / t / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
+                peak_fp32_matrix_tflops=PEAK_FP32_MATRIX_TFLOPS,
                 hbm_materialised_equiv_gbps=b_mat / t / 1e9,
                 parity_gate='tests/test_gpu_g_fullsize.py::test_affinity_at_bench_shapes + '
                             'tests/test_gpu_d_affinity.py::test_fp16_prefilter_is_bit_identical_to_the_fp32_kernels')
+
+
+def _affinity_counter_ratio(b_alg):
+    """HBM counter traffic of one read (committed PMC pass of this round, or the last one) over the algorithmic bytes"""
+    for d in ('pmc_r04', 'pmc_r03'):
+        path = os.path.join(ROOT, 'profiles', d, 'affinity_read.json')
+        if os.path.exists(path):
+            try:
+                with open(path) as f:
+                    j = json.load(f)
+                for key in ('hbm_bytes_per_read', 'hbm_bytes_per_launch'):
+                    if key in j:
+                        return {'ratio': j[key] / b_alg, 'source': f'profiles/{d}/affinity_read.json'}
+            except Exception:  # noqa: BLE001
+                pass
+    return None
+
+
+def pointwise_rooflines(device, tag, no, h16, w16, iters=20):
+    """HBM-bound kernels of one frame, each event-timed on its own with the tensor shapes of the
+    frame: algorithmic bytes (every operand once) / time / 8 TB/s.  h16 x w16 = the 1/16 map, no = objects."""
+    from deva.hip import ops
+    g = torch.Generator(device='cpu').manual_seed(5)
+
+    def t(*shape):
+        x = ops._alloc(shape, device)
+        x.copy_(torch.randn(*shape, generator=g))
+        return x
+
+    rows = []
+
+    def bench(name, fn, nbytes):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / iters * 1e3
+        rows.append({'kernel': name, 'shape': tag, 'us': us, 'algorithmic_bytes': nbytes, 'gbps': nbytes / us / 1e3,
+                     'frac_of_hbm_peak': nbytes / us / 1e3 / PEAK_HBM_GBPS})
+
+    f = 4.0
+    p16, d8 = t(no, 512, h16, w16), t(1, 512, 2 * h16, 2 * w16)
+    bench('upsample2x_add_kernel (p16 -> 1/8, 512 ch)', lambda: ops.upsample2x_add(p16, d8),
+          f * (p16.numel() + d8.numel() + no * 512 * 4 * h16 * w16))
+    p8, d4 = t(no, 256, 2 * h16, 2 * w16), t(1, 256, 4 * h16, 4 * w16)
+    bench('upsample2x_add_kernel (p8 -> 1/4, 256 ch)', lambda: ops.upsample2x_add(p8, d4),
+          f * (p8.numel() + d4.numel() + no * 256 * 16 * h16 * w16))
+    p4 = t(no, 256, 4 * h16, 4 * w16)
+    bench('area_downsample_kernel (p4, factor 4)', lambda: ops.area_downsample(p4, 4), f * (p4.numel() + p4.numel() / 16))
+    bench('area_downsample_kernel (p8, factor 2)', lambda: ops.area_downsample(p8, 2), f * (p8.numel() + p8.numel() / 4))
+    pc = ops.pack_conv(torch.randn(1, 256, 3, 3, generator=g) * 0.02, torch.zeros(1), device=device)
+    bench('conv3x3_cout1_rows_kernel (mask-logit head 256 -> 1)', lambda: ops.conv2d(pc, p4, pad=1, relu_in=True),
+          f * (p4.numel() + no * 16 * h16 * w16 + 9 * 256))
+    stem = t(1, 64, 8 * h16, 8 * w16)
+    bench('maxpool3x3s2_kernel (key-encoder stem, 64 ch)', lambda: ops.maxpool3x3s2(stem), f * (stem.numel() * 1.25))
+    logits = t(no + 1, 4 * h16, 4 * w16)
+    bench('upsample4x_softmax_kernel (logits -> full resolution)', lambda: ops.upsample4x_softmax(logits, need_logits=False),
+          f * (logits.numel() * 17))
+    return rows
+
+
+def readout_roofline(device, tag, no, hw, n, k=30, iters=20):
+    """readout_sparse_kernel at one shape: SURVEY 8d's B_ro = 4*no*CV*(min(N, k*HW) + HW) + 8*k*HW"""
+    from deva.hip import ops
+    g = torch.Generator(device='cpu').manual_seed(6)
+    cv = 512
+    vals = torch.randn(n, no * cv, generator=g).to(device)
+    idx = torch.randint(0, n, (hw, k), generator=g, dtype=torch.int32).to(device)
+    w = torch.rand(hw, k, generator=g).to(device)
+    out = torch.empty((no * cv, hw), dtype=torch.float32, device=device)
+
+    def fn():
+        ops.readout_sparse(idx, w, None, 0, vals, n, out)
+
+    try:
+        for _ in range(3):
+            fn()
+    except Exception as exc:  # noqa: BLE001  (signature drift must not cost the line)
+        return [{'kernel': 'readout_sparse_kernel', 'shape': tag, 'error': f'{type(exc).__name__}: {exc}'[:200]}]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / iters * 1e3
+    nbytes = 4.0 * no * cv * (min(n, k * hw) + hw) + 8.0 * k * hw
+    return [{'kernel': 'readout_sparse_kernel', 'shape': tag, 'us': us, 'algorithmic_bytes': nbytes, 'gbps': nbytes / us / 1e3,
+             'frac_of_hbm_peak': nbytes / us / 1e3 / PEAK_HBM_GBPS}]
+
+
+def cpu_affinity_kernels(budget_s=25.0):
+    """the reference's get_similarity + do_softmax(top_k=30, return_usage) on the host cores at the five
+    kernel-only shapes of SURVEY 8d (oracle port, bit-identical arithmetic), one call each, within a time budget"""
+    from oracle import deva_oracle as O
+    from workload import synth
+    rows, t_start = [], time.perf_counter()
+    for n, hw in ((10000, 1620), (24580, 1620), (10000, 8160), (83440, 8160), (50000, 32400)):
+        if time.perf_counter() - t_start > budget_s:
+            rows.append({'n': n, 'hw': hw, 'skipped': 'time budget of the bounded CPU sample'})
+            continue
+        mk, ms, qk, qe = synth.affinity_inputs(n, hw, seed=0)
+        t0 = time.perf_counter()
+        sim = O.get_similarity(mk, ms, qk, qe)
+        t1 = time.perf_counter()
+        O.dense_affinity(sim, 30)  # top-30 -> exp / normalise -> scatter into the dense matrix -> usage (row sums)
+        t2 = time.perf_counter()
+        rows.append({'n': n, 'hw': hw, 'get_similarity_ms': (t1 - t0) * 1e3, 'do_softmax_top30_ms': (t2 - t1) * 1e3,
+                     'cores': torch.get_num_threads()})
+        del sim
+    return rows
 
 
 def cpu_baseline(sd, cfg, height, width, num_objects, frames_cpu, segments=3):
@@ -595,6 +726,7 @@ def main():
     ap.add_argument('--cpu_frames', type=int, default=30, help='propagated frames of the CPU-baseline run')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_extra', action='store_true')
+    ap.add_argument('--no_affinity', action='store_true', help='skip the affinity / pointwise micro-benchmarks (profiling passes)')
     args = ap.parse_args()
 
     torch.set_grad_enabled(False)
@@ -706,8 +838,8 @@ def main():
                 json.dump(ct.per_layer(n_replay), f, indent=1)
         ach = flops / (ms * 1e-3) / 1e12
         result['roofline'] = {
-            'kernel': 'conv_igemm_kernel (+ splitk_reduce_kernel / conv_cout1 kernels of the same deva_conv2d call), '
-                      'fp32 MFMA implicit GEMM',
+            'kernel': 'conv_mfma_kernel / conv_igemm_kernel (+ splitk_reduce_kernel / conv_cout1 kernels of the same '
+                      'deva_conv2d call), fp32 MFMA implicit GEMM',
             'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MATRIX_TFLOPS, 'unit': 'TFLOP/s',
             'frac': ach / PEAK_FP32_MATRIX_TFLOPS, 'traffic': None,
             'method': 'HIP events around every deva_conv2d launch on the launch stream, no synchronisation, '
@@ -720,24 +852,63 @@ def main():
         }
         # HBM traffic of these kernels per frame, from the committed rocprofv3 --pmc passes over this same
         # command (tools/pmc_bench.sh; FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes)
-        pmc = os.path.join(ROOT, 'profiles', 'pmc_r03', 'conv_traffic.json')
-        if os.path.exists(pmc):
+        for pmc_dir in ('pmc_r04', 'pmc_r03'):
+            pmc = os.path.join(ROOT, 'profiles', pmc_dir, 'conv_traffic.json')
+            if not os.path.exists(pmc):
+                continue
             with open(pmc) as f:
                 d = json.load(f)
             result['roofline']['traffic'] = d['hbm_bytes_per_frame']
-            result['roofline']['traffic_source'] = 'profiles/pmc_r03/conv_traffic.json'
+            result['roofline']['traffic_source'] = f'profiles/{pmc_dir}/conv_traffic.json'
             result['roofline']['traffic_over_algorithmic'] = d['hbm_bytes_per_frame'] / (alg_bytes / n_replay)
+            # the PMC passes ran `python bench.py --steps 5 --warmup 2 --no_cpu_baseline --no_extra --no_affinity` (this
+            # workload, this loop); they belong to THIS build if the conv sources hash the same
+            result['roofline']['traffic_measured_on_this_build'] = d.get('conv_source_sha1') == conv_source_sha1()
+            break
+        # ---- the same loop timed the reference's way (evaluation/eval_vos.py:150-186): an event pair + synchronize per
+        # frame around step + argmax / id remap (prob_to_obj_cls); no resize at 480p (video_reader.py:139-144)
         try:
-            result['affinity'] = affinity_microbench(device)
-        except Exception as exc:  # noqa: BLE001  (never at the cost of the headline line)
-            result['affinity'] = {'error': f'{type(exc).__name__}: {exc}'[:400]}
+            ref_ms = []
+            for f in replay[2:2 + min(20, args.steps)]:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                prob = core.step(f)
+                core.object_manager.prob_to_obj_cls(prob)
+                b.record()
+                torch.cuda.synchronize()
+                ref_ms.append(a.elapsed_time(b))
+            result['timed_like_eval_vos'] = {
+                'fps': 1e3 * len(ref_ms) / sum(ref_ms), 'ms_per_frame': sum(ref_ms) / len(ref_ms), 'frames': len(ref_ms),
+                'method': 'per frame: start.record(); step(); argmax + id remap; end.record(); torch.cuda.synchronize() '
+                          '(evaluation/eval_vos.py:150-186) -- the per-frame synchronize exposes the launch latency of the '
+                          'first kernels of every frame, `value` above is the un-synchronised loop'}
+        except Exception as exc:  # noqa: BLE001
+            result['timed_like_eval_vos'] = {'error': f'{type(exc).__name__}: {exc}'[:300]}
             torch.cuda.synchronize()
+        if not args.no_affinity:
+            try:
+                result['affinity'] = affinity_microbench(device)
+            except Exception as exc:  # noqa: BLE001  (never at the cost of the headline line)
+                result['affinity'] = {'error': f'{type(exc).__name__}: {exc}'[:400]}
+                torch.cuda.synchronize()
+            try:
+                result['also_kernels'] = (pointwise_rooflines(device, '480p, 5 objects', 5, 30, 54) +
+                                          readout_roofline(device, '480p, 5 objects, 16 200-token bank', 5, 1620, 16200) +
+                                          pointwise_rooflines(device, '1080p, 1 object', 1, 68, 120) +
+                                          readout_roofline(device, '1080p, 1 object, 10 000 + 8 160-token bank', 1, 8160, 18160))
+            except Exception as exc:  # noqa: BLE001
+                result['also_kernels'] = {'error': f'{type(exc).__name__}: {exc}'[:400]}
+                torch.cuda.synchronize()
         if not args.no_extra:
             del core
             result['also'] = extra_lines(net, device, cfg, args)
         if not args.no_cpu_baseline and world == 1:
             frames_cpu = [f.cpu() for f in frames[:1 + min(args.cpu_frames, len(frames) - 1)]]
             result['cpu_baseline'] = cpu_baseline(sd, cfg, args.height, args.width, args.objects, frames_cpu)
+            try:
+                result['cpu_baseline']['affinity_kernels'] = cpu_affinity_kernels()
+            except Exception as exc:  # noqa: BLE001
+                result['cpu_baseline']['affinity_kernels'] = {'error': f'{type(exc).__name__}: {exc}'[:300]}
         print(json.dumps(result))
     if distributed:
         dist.barrier()

@@ -35,9 +35,21 @@ def load(prefix):
     return counters, {k: (v[0], len(v[1])) for k, v in durations.items()}
 
 
+def _conv_sha1():
+    """the same digest as bench.py:conv_source_sha1 (bench.py imports torch at module level: hashed here directly)"""
+    import hashlib
+    import os
+    h = hashlib.sha1()
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tracking-anything-with-deva_amd', 'csrc')
+    for name in ('conv_args.h', 'conv_igemm.hip', 'conv_mfma.hip', 'conv_cout1.hip', 'common.h'):
+        with open(os.path.join(d, name), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def conv(prefix, out):
     counters, durations = load(prefix)
-    is_conv = lambda n: n.startswith('conv_') or n.startswith('splitk_reduce')
+    is_conv = lambda n: n.startswith('conv_') or n.startswith('splitk_reduce')  # conv_mfma, conv_igemm, conv_cout1, conv3x3_cout1_rows
     frames = counters.get('upsample4x_softmax_kernel', {}).get('FETCH_SIZE', [0, 0])[1]
     frames = max(frames, 1) + 1  # one decoder pass per propagated frame + the annotated first frame
     rd = sum(c['FETCH_SIZE'][0] for n, c in counters.items() if is_conv(n) and 'FETCH_SIZE' in c) * 1024 * 2
@@ -49,18 +61,19 @@ def conv(prefix, out):
         per_kernel[n] = {k: v[0] / v[1] for k, v in c.items()}
         per_kernel[n]['dispatches_per_pass'] = max(v[1] for v in c.values())
     res = {
-        'command': 'python bench.py --steps 5 --warmup 2 --no_cpu_baseline --no_extra (480p, 5 objects)',
+        'command': 'python bench.py --steps 5 --warmup 2 --no_cpu_baseline --no_extra --no_affinity (480p, 5 objects)',
+        'conv_source_sha1': _conv_sha1(),
         'frames_in_a_pass': frames,
         'hbm_read_bytes_per_frame (FETCH_SIZE KiB x 1024 x 2, gfx950 correction)': rd / frames,
         'hbm_write_bytes_per_frame (WRITE_SIZE KiB x 1024)': wr / frames,
         'hbm_bytes_per_frame': (rd + wr) / frames,
-        'kernels': 'conv_igemm_kernel*, splitk_reduce_kernel, conv_cout1 kernels (everything deva_conv2d launches)',
+        'kernels': 'conv_mfma_kernel*, conv_igemm_kernel*, splitk_reduce_kernel, conv_cout1 kernels (everything deva_conv2d launches)',
         'per_dispatch_averages': per_kernel,
     }
-    g = counters.get('conv_igemm_kernel', None) or next((c for n, c in counters.items() if n.startswith('conv_igemm')), {})
+    g = counters.get('conv_mfma_kernel', None) or next((c for n, c in counters.items() if n.startswith('conv_mfma')), {})
     if 'SQ_INSTS_MFMA' in g and 'SQ_VALU_MFMA_BUSY_CYCLES' in g and 'GRBM_GUI_ACTIVE' in g:
         # busy cycles are summed over the SIMDs: 1024 SIMDs x active cycles = 100 %
-        res['conv_igemm_mfma_util_frac'] = (g['SQ_VALU_MFMA_BUSY_CYCLES'][0] / g['SQ_VALU_MFMA_BUSY_CYCLES'][1]) / (
+        res['conv_mfma_mfma_util_frac'] = (g['SQ_VALU_MFMA_BUSY_CYCLES'][0] / g['SQ_VALU_MFMA_BUSY_CYCLES'][1]) / (
             g['GRBM_GUI_ACTIVE'][0] / g['GRBM_GUI_ACTIVE'][1] / 8.0 * 1024)
     with open(out, 'w') as f:
         json.dump(res, f, indent=1)
