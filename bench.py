@@ -316,14 +316,15 @@ def readout_roofline(device, tag, no, hw, n, k=30, iters=20):
     """readout_sparse_kernel at one shape: SURVEY 8d's B_ro = 4*no*CV*(min(N, k*HW) + HW) + 8*k*HW"""
     from deva.hip import ops
     g = torch.Generator(device='cpu').manual_seed(6)
-    cv = 512
-    vals = torch.randn(n, no * cv, generator=g).to(device)
+    cv = 512  # one launch per object (memory_manager.py:_readout_into): the row is one object's read-out
+    vals = torch.randn(n, cv, generator=g).to(device)
     idx = torch.randint(0, n, (hw, k), generator=g, dtype=torch.int32).to(device)
     w = torch.rand(hw, k, generator=g).to(device)
-    out = torch.empty((no * cv, hw), dtype=torch.float32, device=device)
+    out = torch.empty((cv, hw), dtype=torch.float32, device=device)
+    no = 1
 
     def fn():
-        ops.readout_sparse(idx, w, None, 0, vals, n, out)
+        ops.readout_sparse(idx, w, None, 0, vals, out)
 
     try:
         for _ in range(3):
@@ -338,7 +339,7 @@ def readout_roofline(device, tag, no, hw, n, k=30, iters=20):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / iters * 1e3
     nbytes = 4.0 * no * cv * (min(n, k * hw) + hw) + 8.0 * k * hw
-    return [{'kernel': 'readout_sparse_kernel', 'shape': tag, 'us': us, 'algorithmic_bytes': nbytes, 'gbps': nbytes / us / 1e3,
+    return [{'kernel': 'readout_sparse_kernel (one object)', 'shape': tag, 'us': us, 'algorithmic_bytes': nbytes, 'gbps': nbytes / us / 1e3,
              'frac_of_hbm_peak': nbytes / us / 1e3 / PEAK_HBM_GBPS}]
 
 
@@ -348,9 +349,18 @@ def cpu_affinity_kernels(budget_s=25.0):
     from oracle import deva_oracle as O
     from workload import synth
     rows, t_start = [], time.perf_counter()
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available
+    except Exception:  # noqa: BLE001
+        avail = 16 << 30
     for n, hw in ((10000, 1620), (24580, 1620), (10000, 8160), (83440, 8160), (50000, 32400)):
         if time.perf_counter() - t_start > budget_s:
             rows.append({'n': n, 'hw': hw, 'skipped': 'time budget of the bounded CPU sample'})
+            continue
+        if 6 * 4 * n * hw > avail // 4:  # the materialised N x HW passes need ~6 such matrices; never risk the box
+            rows.append({'n': n, 'hw': hw, 'skipped': f'needs ~{6 * 4 * n * hw / 2**30:.0f} GiB of host memory for the reference\'s '
+                                                      'materialised N x HW matrices'})
             continue
         mk, ms, qk, qe = synth.affinity_inputs(n, hw, seed=0)
         t0 = time.perf_counter()

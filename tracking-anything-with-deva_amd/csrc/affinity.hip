@@ -1223,24 +1223,51 @@ __global__ __launch_bounds__(256) void readout_sparse_kernel(const int32_t* __re
     const int ql = wave * (RQ / 4) + qi;
     const int q = q0 + ql;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (q < hw && c_ok) {
-      for (int j = 0; j < k; ++j) {
-        const int t = idx[(int64_t)q * k + j];
-        if (t < tok_lo || t >= tok_hi) continue;  // token of another bank shard: its owner adds that term
-        const float w = weight[(int64_t)q * k + j];
-        // value-sharded storage: the arenas hold this rank's rows only; map[token] = local row, < 0 = another rank's
-        int r = (t < n_long) ? t : t - n_long;
-        const int32_t* map = (t < n_long) ? map_long : map_work;
-        if (map) {
-          r = map[r];
-          if (r < 0) continue;
+    if (q < hw) {  // (wave-uniform)
+      // lane j resolves term j of the query once: arena row and weight (0 for a term this launch does not add:
+      // token of another bank shard, row stored on another rank); then the rows are fetched eight at a time --
+      // independent 16-byte loads in flight instead of an index -> row dependency chain per term
+      int row = 0, is_long = 0;
+      float wj = 0.0f;
+      if (lane < k) {
+        const int t = idx[(int64_t)q * k + lane];
+        wj = weight[(int64_t)q * k + lane];
+        is_long = (t < n_long) ? 1 : 0;
+        row = is_long ? t : t - n_long;
+        bool live = t >= tok_lo && t < tok_hi;
+        const int32_t* map = is_long ? map_long : map_work;
+        if (live && map) {
+          row = map[row];
+          live = row >= 0;
         }
-        const float* row = ((t < n_long) ? val_long : val_work) + (int64_t)r * cv;
-        const float4 v = *reinterpret_cast<const float4*>(row + c0 + cl);
-        acc.x += w * v.x;
-        acc.y += w * v.y;
-        acc.z += w * v.z;
-        acc.w += w * v.w;
+        if (!live) {
+          row = 0;
+          wj = 0.0f;
+          is_long = n_long > 0 ? is_long : 0;
+        }
+      }
+      const float* col = nullptr;
+      for (int j0 = 0; j0 < k; j0 += 8) {
+        float4 v[8];
+        float w8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = min(j0 + u, k - 1);
+          const int r = __builtin_amdgcn_readlane(row, j);
+          const int lg = __builtin_amdgcn_readlane(is_long, j);
+          w8[u] = (j0 + u < k) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wj), j)) : 0.0f;
+          col = (lg ? val_long : val_work) + (int64_t)r * cv + c0 + cl;
+          v[u] = c_ok ? *reinterpret_cast<const float4*>(col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {  // terms in index order, like the one-at-a-time loop: same sums
+          if (w8[u] != 0.0f || j0 + u < k) {
+            acc.x += w8[u] * v[u].x;
+            acc.y += w8[u] * v[u].y;
+            acc.z += w8[u] * v[u].z;
+            acc.w += w8[u] * v[u].w;
+          }
+        }
       }
     }
     tile[cl + 0][ql] = acc.x;

@@ -80,6 +80,45 @@ __global__ void upsample2x_add_kernel(const float* __restrict__ in, const float*
   }
 }
 
+// Four consecutive output pixels of a row per thread (OW % 4 == 0): 32-bit index arithmetic (the plane is a grid
+// dimension; the one-pixel kernel above spends its time in two 64-bit divisions per output), one 16-byte load of the
+// skip tensor and one 16-byte store; the eight input values (2 rows x columns 2j-1 .. 2j+2) come from L1/L2.  Same
+// per-pixel arithmetic as upsample2x_add_kernel (lerp_index / bilerp): bit-identical results.
+__global__ __launch_bounds__(256) void upsample2x_add_quad_kernel(const float* __restrict__ in, const float* __restrict__ skip,
+                                                                  float* __restrict__ out, int C, int h, int w) {
+  const int OH = 2 * h, OW = 2 * w, QW = OW >> 2;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= OH * QW) return;
+  const int plane = blockIdx.y;  // b*C + c
+  const int oy = q / QW, j = q - oy * QW;
+  const float* src = in + (int64_t)plane * h * w;
+  const Lerp ly = lerp_index(oy, 0.5f, h);
+  const float* r0 = src + ly.i0 * w;
+  const float* r1 = src + ly.i1 * w;
+  const int xa = max(2 * j - 1, 0), xb = 2 * j, xc = 2 * j + 1, xd = min(2 * j + 2, w - 1);
+  const float a0 = r0[xa], b0 = r0[xb], c0 = r0[xc], d0 = r0[xd];
+  const float a1 = r1[xa], b1 = r1[xb], c1 = r1[xc], d1 = r1[xd];
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const Lerp lx = lerp_index(4 * j + e, 0.5f, w);
+    // columns of the four outputs: (2j-1, 2j), (2j, 2j+1), (2j, 2j+1), (2j+1, 2j+2) -- clamped like lerp_index clamps
+    const float t0 = e == 0 ? a0 : (e == 3 ? c0 : b0), t1 = e == 0 ? b0 : (e == 3 ? d0 : c0);
+    const float u0 = e == 0 ? a1 : (e == 3 ? c1 : b1), u1 = e == 0 ? b1 : (e == 3 ? d1 : c1);
+    const float top = lx.w0 * t0 + lx.w1 * t1;
+    const float bot = lx.w0 * u0 + lx.w1 * u1;
+    v[e] = ly.w0 * top + ly.w1 * bot;
+  }
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int64_t o = ((int64_t)plane * OH + oy) * OW + 4 * j;
+  f4 r = {v[0], v[1], v[2], v[3]};
+  if (skip) {
+    const f4 sk = *reinterpret_cast<const f4*>(skip + ((int64_t)(plane % C) * OH + oy) * OW + 4 * j);
+    r = f4{sk[0] + v[0], sk[1] + v[1], sk[2] + v[2], sk[3] + v[3]};
+  }
+  *reinterpret_cast<f4*>(out + o) = r;
+}
+
 // ------------------------------------------------------------------ area downsample (integer factor)
 __global__ void area_downsample_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t total,
                                        int H, int W, int f) {
@@ -388,6 +427,14 @@ extern "C" int deva_upsample2x_add(const float* in, const float* skip, float* ou
                                    int height, int width, void* stream) {
   DEVA_REQUIRE(in && out && batch > 0 && channels > 0 && height > 0 && width > 0, "deva_upsample2x_add: bad args");
   const int64_t total = (int64_t)batch * channels * height * 2 * width * 2;
+  const int64_t planes = (int64_t)batch * channels;
+  const bool aligned = (((uintptr_t)out | (uintptr_t)skip) & 15) == 0;  // 16-byte rows: OW % 4 == 0 and aligned bases
+  if (width % 2 == 0 && width >= 2 && planes <= 65535 && aligned) {
+    const int quads = height * 2 * (width * 2 / 4);
+    hipLaunchKernelGGL(upsample2x_add_quad_kernel, dim3((unsigned)ceil_div(quads, 256), (unsigned)planes), dim3(256), 0,
+                       (hipStream_t)stream, in, skip, out, channels, height, width);
+    return check_launch("deva_upsample2x_add");
+  }
   hipLaunchKernelGGL(upsample2x_add_kernel, grid_for(total), dim3(TPB), 0, (hipStream_t)stream, in, skip, out,
                      total, channels, height, width);
   return check_launch("deva_upsample2x_add");
