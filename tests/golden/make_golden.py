@@ -287,6 +287,34 @@ def gen_consensus_auto(net):
     torch.save(out, os.path.join(HERE, 'consensus_auto.pt'))
 
 
+def gen_driver_semionline(net):
+    """the semi-online loop of evaluation/eval_with_detections.py:150-297 (restated against the public interface in
+    tests/driver_loops.py) driven on the REFERENCE: buffering, vote_in_temporary_buffer -> find_consensus_auto_association
+    (0/1 programme by the package's exact enumeration, like gen_consensus_auto: no PuLP / Gurobi here),
+    incorporate_detection, propagation, clear_buffer.  Stored: the index masks the driver would write."""
+    import importlib
+    import driver_loops
+    from deva.inference import consensus_automatic as CA
+    from deva.inference.object_info import ObjectInfo
+    spec = importlib.util.spec_from_file_location(
+        '_pkg_consensus', os.path.join(ROOT, 'tracking-anything-with-deva_amd', 'deva', 'inference', 'consensus_automatic.py'))
+    src = open(spec.origin).read()
+    ns = {}
+    exec(src[src.index('def solve_exact'):src.index('def solve(')], {'np': np, 'List': list, 'Tuple': tuple}, ns)
+    CA.solve_with_pulp = lambda iou, ind, n: ns['solve_exact'](iou, ind, n)
+    CA.use_gurobi = False
+    frames, dets = driver_loops.semionline_clip()
+    cfg = dict(synth.base_config(mem_every=2, max_missed_detection_count=2, max_num_objects=-1), num_voting_frames=3)
+    masks, alive = driver_loops.semionline_loop(lambda c: DEVAInferenceCore(net, c), cfg, frames, dets, lambda **kw: ObjectInfo(**kw),
+                                                num_voting_frames=3, detection_every=5, device='cpu')
+    names = sorted(masks)
+    np.savez_compressed(os.path.join(HERE, 'driver_semionline.npz'), names=np.array(names),
+                        masks=np.stack([masks[n].numpy() for n in names]).astype(np.int32), alive=np.array(alive),
+                        config=json.dumps({k: v for k, v in cfg.items() if isinstance(v, (int, float, bool, str))}))
+    print('driver_semionline', len(names), 'frames, objects alive at the end', alive,
+          'labels per frame', [sorted(set(masks[n].flatten().tolist())) for n in names])
+
+
 def gen_read_memory(net):
     """DEVA.read_memory (network.py:72-92): dense full-softmax read, B=2, 2 objects, T=3 memory frames"""
     g = torch.Generator().manual_seed(31)
@@ -353,6 +381,10 @@ if __name__ == '__main__':
     if only == 'api':
         gen_api_surface()
         sys.exit(0)
+    if only == 'drivers':
+        net, _, _ = build_reference(synth.base_config())
+        gen_driver_semionline(net)
+        sys.exit(0)
     if only == 'consensus':
         net, _, _ = build_reference(synth.base_config())
         gen_consensus_auto(net)
@@ -375,6 +407,7 @@ if __name__ == '__main__':
     gen_detection_e2e(net)
     gen_alignment(net)
     gen_consensus_auto(net)
+    gen_driver_semionline(net)
     gen_edge(net)
     gen_read_memory(net)
     gen_api_surface()

@@ -31,6 +31,22 @@ def _sim(mk_rows: torch.Tensor, ms: torch.Tensor, qk: torch.Tensor, qe: torch.Te
     return O.get_similarity(mk_rows.t().contiguous(), ms.reshape(1, -1), qk, qe)
 
 
+def roundoff_floor(mk_rows: torch.Tensor, ms: torch.Tensor, qk_col: torch.Tensor, qe_col: torch.Tensor, tokens) -> float:
+    """fp32 round-off scale of the reference's OWN score formula for these tokens and this query: the score is the small
+    difference of three 64-term sums (memory_utils.py:29-43), so two correct fp32 evaluations of it (ATen's blocked
+    sgemm, the kernels' natural-order FMA chain) differ by ulps of the TERMS, not of the result:
+    2^-22 * ms/8 * (sum mk^2 qe + 2 |sum mk qk qe| + sum qe qk^2) -- two ulps of the largest intermediate.  On the
+    1080p clip the terms are ~200x the score: ~1e-5, the size of the measured bank noise; a selection that differs by
+    less than a few of these is a tie of the arithmetic, whatever the inputs' noise happened to be for that pair."""
+    rows = mk_rows[list(tokens)].double()                      # [t, 64]
+    qk, qe = qk_col.double().reshape(-1), qe_col.double().reshape(-1)
+    a_sq = (rows * rows) @ qe
+    two_ab = 2 * (rows @ (qk * qe))
+    b_sq = (qe * qk * qk).sum()
+    scale = ms.reshape(-1)[list(tokens)].double().abs() / 8.0
+    return float(((a_sq + two_ab.abs() + b_sq) * scale).max()) * 2.0 ** -22
+
+
 class ReadTap:
     """records the inputs and the selection of every `ops.affinity_topk` call"""
 
@@ -112,7 +128,8 @@ def explain_flips(tag: str, hip_read: Dict, ref_read: Dict, slack: float = 4.0):
         boundary = 0.5 * (vals[k - 1, q] + vals[k, q]).item() if n > k else vals[k - 1, q].item()
         gap = max(abs(sim_ref[t, q].item() - boundary) for t in swapped)
         noise = max(abs(sim_hip[t, q].item() - sim_ref[t, q].item()) for t in swapped)
-        noise = max(noise, 1e-6 * abs(boundary))  # fp32 evaluation noise of the score itself
+        noise = max(noise, 1e-6 * abs(boundary),  # fp32 evaluation noise of the score itself ...
+                    roundoff_floor(hip_read['mk'], hip_read['ms'], hip_read['qk'][:, q], hip_read['qe'][:, q], swapped))
         excess = gap / noise
         worst_excess = max(worst_excess, excess)
         lines.append(f'{tag}: query {q}: {len(swapped) // 2} token(s) swapped, boundary score {boundary:.6g}, '
@@ -179,7 +196,8 @@ class TieFollowing:
             swapped = sorted(set(hip_set.tolist()) ^ set(ref_set.tolist()))
             col_hip = _sim(hr['mk'], hr['ms'], hr['qk'][:, q:q + 1], hr['qe'][:, q:q + 1])[:, 0]
             gap = max(abs(col[t].item() - boundary) for t in swapped)
-            noise = max(max(abs(col_hip[t].item() - col[t].item()) for t in swapped), 1e-6 * abs(boundary))
+            noise = max(max(abs(col_hip[t].item() - col[t].item()) for t in swapped), 1e-6 * abs(boundary),
+                        roundoff_floor(hr['mk'], hr['ms'], hr['qk'][:, q], hr['qe'][:, q], swapped))
             excess = gap / noise
             line = (f'{self.tag} read {self.reads} query {q}: {len(swapped) // 2} token(s) swapped, boundary score '
                     f'{boundary:.6g}, reference gap {gap:.3e}, measured score noise {noise:.3e} (ratio {excess:.2f})')
