@@ -38,7 +38,9 @@ def network(recipe_state_dict):
     return net.to(dev()).eval()
 
 
-@pytest.mark.parametrize('n,hw,cols', [(10000, 8160, None), (83440, 8160, 2048), (50000, 32400, 2048)])
+# every query at all three shapes (round 3 sampled 2 048 queries of the two larger ones; the GPU boxes' hosts compute the
+# chunked CPU reference of all 83 440 x 8 160 scores in ~10 s)
+@pytest.mark.parametrize('n,hw,cols', [(10000, 8160, None), (83440, 8160, None), (50000, 32400, None)])
 def test_affinity_at_bench_shapes(n, hw, cols):
     k = 30
     mk, ms, qk, qe = synth.affinity_inputs(n, hw, seed=n + hw, key_scale=1.0)  # SURVEY §8d microbench inputs
@@ -125,6 +127,47 @@ def test_1080p_eight_segment_detections_against_oracle(network, recipe_state_dic
     assert any(i['id'] > 100000 for _, info in recorded.values() for i in info), 'no re-detection was generated'
     print('1080p 8-segment detection clip:', json.dumps({k: float(f'{v:.3g}') for k, v in report.items()}),
           'objects at the end', [int(o.id) for o in hip.object_manager.obj_to_tmp_id])
+
+
+def test_4k_free_running_50k_bank_against_oracle(network, recipe_state_dict):
+    """BASELINE configs[4] on one GPU, FREE-RUNNING (round 3 had two teacher-forced frames only): 2160x3840, one
+    object, long-term bank pre-filled to 50 000 tokens after the annotated frame, three frames -- the reads see
+    50 000 + 32 400 (+ 32 400) tokens x 32 400 queries.  HIP vs the tie-following oracle under the north-star bound as
+    written; the plain (clean) oracle and the reference's own drift under a 1e-6 input perturbation are printed beside
+    it.  Reference: inference_core.py:200-290, memory_manager.py:91-169."""
+    from deva.inference.inference_core import DEVAInferenceCore
+    P, _ = recipe_state_dict
+    dry = os.environ.get('DEVA_TEST_DRYRUN') == '1'
+    (H, W), bank, frames = ((144, 256), 600, 3) if dry else ((2160, 3840), 50000, 3)
+    cfg = synth.base_config(max_long_term_elements=bank, mem_every=2)
+    hip = DEVAInferenceCore(network, cfg)
+    following, clean, noisy = (O.OracleCore(P, cfg) for _ in range(3))
+    gen = torch.Generator().manual_seed(0)
+    stream = synth.FrameStream(H, W, seed=11)
+    imgs = [stream.next() for _ in range(frames)]
+    mask0 = synth.box_mask(H, W, 1)
+    key, shr, vals = synth.prefill_bank(bank - cfg['num_prototypes'], [1], seed=2)
+
+    def hip_step(t):
+        out = hip.step(imgs[t].to(dev()), mask0.to(dev()) if t == 0 else None, [1] if t == 0 else None).cpu()
+        if t == 0:  # bucket 0 exists now (SURVEY.md 8d: pre-fill through the store's own add)
+            hip.memory.long_mem.add(key.to(dev()), {o: v.to(dev()) for o, v in vals.items()}, shr.to(dev()),
+                                    selection=None, supposed_bucket_id=0)
+        return out
+
+    def orc_step(core, perturb=False):
+        def step(t):
+            img = imgs[t] * (1 + 1e-6 * torch.randn(imgs[t].shape, generator=gen)) if perturb else imgs[t]
+            out = core.step(img, mask0 if t == 0 else None, [1] if t == 0 else None)
+            if t == 0:
+                core.memory.long.add(key, vals, shr, None, bucket_id=0)
+            return out
+        return step
+
+    report = memory_audit.paired_steps('4K/free-running/50k-bank', frames, hip_step, orc_step(following), orc_step(clean),
+                                       orc_step(noisy, perturb=True))
+    assert hip.memory.long_mem.size(0) == following.memory.long.size(0) == bank - cfg['num_prototypes']
+    print('4K free-running clip:', json.dumps({k: float(f'{v:.3g}') for k, v in report.items()}))
 
 
 def test_4k_lockstep(network, recipe_state_dict):
