@@ -141,7 +141,11 @@ def test_4k_free_running_50k_bank_against_oracle(network, recipe_state_dict):
     (H, W), bank, frames = ((144, 256), 600, 3) if dry else ((2160, 3840), 50000, 3)
     cfg = synth.base_config(max_long_term_elements=bank, mem_every=2)
     hip = DEVAInferenceCore(network, cfg)
-    following, clean, noisy = (O.OracleCore(P, cfg) for _ in range(3))
+    following = O.OracleCore(P, cfg)
+    # the clean oracle and the 1e-6-perturbed one cost two more minutes each at 4K: DEVA_TEST_FULL_REPORT=1 runs them
+    # (profiles/r04/test_gpu_g_4k_free_running_full_report.log: vs clean 1.01e-2, the reference's own drift 1.11e-2)
+    full = dry or os.environ.get('DEVA_TEST_FULL_REPORT') == '1'
+    clean, noisy = (O.OracleCore(P, cfg), O.OracleCore(P, cfg)) if full else (None, None)
     gen = torch.Generator().manual_seed(0)
     stream = synth.FrameStream(H, W, seed=11)
     imgs = [stream.next() for _ in range(frames)]
@@ -164,8 +168,8 @@ def test_4k_free_running_50k_bank_against_oracle(network, recipe_state_dict):
             return out
         return step
 
-    report = memory_audit.paired_steps('4K/free-running/50k-bank', frames, hip_step, orc_step(following), orc_step(clean),
-                                       orc_step(noisy, perturb=True))
+    report = memory_audit.paired_steps('4K/free-running/50k-bank', frames, hip_step, orc_step(following),
+                                       orc_step(clean) if full else None, orc_step(noisy, perturb=True) if full else None)
     assert hip.memory.long_mem.size(0) == following.memory.long.size(0) == bank - cfg['num_prototypes']
     print('4K free-running clip:', json.dumps({k: float(f'{v:.3g}') for k, v in report.items()}))
 
