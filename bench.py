@@ -713,13 +713,15 @@ def extra_lines(net, device, cfg, args):
              'BASELINE configs[2] as SURVEY.md 8d defines it: tracker-consistent detections with 8 segments '
              '(re-detections that match and merge, 2 new objects per detection in a new bucket, objects unseen twice '
              'purged), online setting, no object cap',
-             'tests/test_gpu_g_fullsize.py::test_1080p_eight_segment_detections_against_oracle (3 segments at 1080p) + '
-             'tests/test_gpu_e_network.py::test_consistent_detection_clip_against_reference_golden', 'state_at_end'),
+             'tests/test_gpu_g_fullsize.py::test_1080p_eight_segment_detections_against_oracle (8 segments, 14 live objects '
+             'at 1080p, the same generator) + tests/test_gpu_e_network.py::test_consistent_detection_clip_against_reference_golden',
+             'state_at_end'),
         line('propagation FPS @4K (1 object, 50k-token long-term bank), one GPU',
              lambda: run_long4k(net, device, steps=20, warmup=5, seed=11, shard=None, dist=None)[:2], 20, 5,
              'BASELINE configs[4] on ONE GPU: synthetic 3840x2160 clip, 1 object, long-term memory pre-filled to '
              '50 000 tokens',
-             'tests/test_gpu_g_fullsize.py::test_4k_lockstep + test_affinity_at_bench_shapes', 'bank_tokens_at_end'),
+             'tests/test_gpu_g_fullsize.py::test_4k_free_running_50k_bank_against_oracle + test_4k_lockstep + '
+             'test_affinity_at_bench_shapes (every query)', 'bank_tokens_at_end'),
     ]
 
 

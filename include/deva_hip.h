@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DEVA_HIP_ABI_VERSION 4
+#define DEVA_HIP_ABI_VERSION 5
 
 int deva_hip_version(void);
 const char* deva_hip_last_error(void);
@@ -90,9 +90,21 @@ typedef struct deva_conv_desc {
    * K ranges in parallel and a second kernel reduces them in a fixed order); NULL disables it */
   float* workspace;
   int64_t workspace_elems;
+  /* opt-in fp16 OPERANDS with fp32 accumulation (the reference's --amp: deva/inference/eval_args.py:17,
+   * evaluation/eval_vos.py:137 wrap the frame loop in fp16 autocast): amp != 0 and weight_f16 != NULL run
+   * v_mfma_f32_32x32x16_f16 on the inputs rounded to fp16 while they are staged and on fp16 weights packed by
+   * deva_conv_pack_f16 (layout DEVA_KLAYOUT_H8: element (k, m) at ((k/8)*cout_pad + m)*8 + k%8; K tap-major for 1x1,
+   * 64-channel slabs otherwise); bias / residual / activation / output stay fp32.  Shapes the fp16 kernels do not
+   * cover (stride 2, channel counts that are not multiples of 64, single-channel heads, unguarded inputs) run the
+   * fp32 kernels on `weight` as if amp were 0. */
+  const void* weight_f16;
+  int32_t amp;
 } deva_conv_desc;
 
 int deva_conv2d(const deva_conv_desc* desc, void* stream);
+/* fp16 weights of the amp path (HOST pointers, model load): -> number of uint16 elements (out == NULL: size query),
+ * -1 when the layer is not eligible (cin % 64 != 0) or on bad arguments */
+int64_t deva_conv_pack_f16(const float* w_oihw, uint16_t* out, int cout, int cin, int kh, int kw, int* cout_pad);
 
 /* Host-side packing of one convolution's weights (HOST pointers; model load, not the frame path):
  * w_oihw [cout][cin][kh][kw] (BatchNorm already folded) -> out in the layout named by *k_layout / *cout_pad
@@ -219,7 +231,8 @@ int64_t deva_affinity_workspace(int hw, int k, int splits);
 /* splits the library would pick for a bank/query size (>= 1) */
 int deva_affinity_default_splits(int n_total, int hw);
 
-/* The whole read in one call, with the fp16 pre-filter where it pays (banks of >= 2 048 tokens):
+/* The whole read in one call, with the fp16 pre-filter where it pays (banks of >= 4 096 tokens AND >= 8 000 000
+ * (token, query) scores: PF_MIN_TOKENS / PF_MIN_SCORES of csrc/affinity.hip; deva_affinity_prefilter_enabled tells):
  *   every (token, query) score is first bounded from both sides with v_mfma_f32_32x32x16_f16 on fp16 copies of the
  *   operands (1/16 of the fp32 matrix time) under a rigorous error bound, a filter threshold is derived from group
  *   maxima of the lower bounds, and only the tokens whose upper bound reaches it (~k + 5 per query) are re-scored with

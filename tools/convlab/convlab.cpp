@@ -100,6 +100,7 @@ static const Layer kLayers[] = {
 typedef int (*conv_fn)(const deva_conv_desc*, void*);
 typedef int64_t (*pack_fn)(const float*, float*, int, int, int, int, int, int*, int*);
 typedef const char* (*err_fn)(void);
+typedef int64_t (*pack16_fn)(const float*, uint16_t*, int, int, int, int, int*);
 
 struct Lib {
   std::string path;
@@ -107,6 +108,7 @@ struct Lib {
   conv_fn conv;
   pack_fn pack;  // optional (newer libraries): deva_conv_pack of include/deva_hip.h
   err_fn err;
+  pack16_fn pack16;  // optional: deva_conv_pack_f16 (amp path)
 };
 
 static constexpr int64_t kGuard = 8192;  // like deva/hip/ops.py:_alloc
@@ -131,7 +133,7 @@ int main(int argc, char** argv) {
   std::string libs = "tracking-anything-with-deva_amd/deva/hip/libdeva_hip.so";
   std::string only, set = "frame480", shapes;
   int iters = 20;
-  bool check = false, csv = false, stamps = false;
+  bool check = false, csv = false, stamps = false, amp = false;
   int keepalive_ms = 0;
   double warm_ms = 15.0, time_ms = 20.0;
   int q4 = 1;
@@ -145,6 +147,7 @@ int main(int argc, char** argv) {
     else if (a == "--noq4") q4 = 0;
     else if (a == "--csv") csv = true;
     else if (a == "--stamps") stamps = true;
+    else if (a == "--amp") amp = true;  // fp16 operands on every library but the first (which stays the fp32 reference)
     else if (a == "--keepalive" && i + 1 < argc) keepalive_ms = atoi(argv[++i]);
     else if (a == "--warm_ms" && i + 1 < argc) warm_ms = atof(argv[++i]);
     else if (a == "--time_ms" && i + 1 < argc) time_ms = atof(argv[++i]);
@@ -180,6 +183,7 @@ int main(int argc, char** argv) {
     l.conv = (conv_fn)dlsym(l.h, "deva_conv2d");
     l.pack = (pack_fn)dlsym(l.h, "deva_conv_pack");
     l.err = (err_fn)dlsym(l.h, "deva_hip_last_error");
+    l.pack16 = (pack16_fn)dlsym(l.h, "deva_conv_pack_f16");
     if (!l.conv) { fprintf(stderr, "%s: no deva_conv2d\n", l.path.c_str()); return 1; }
     L.push_back(l);
     p = q + 1;
@@ -282,6 +286,18 @@ int main(int argc, char** argv) {
       d.in_guard_elems = (int32_t)kGuard;
       d.workspace = ws;
       d.workspace_elems = ws_elems;
+      if (amp && li > 0 && l.pack16) {
+        int cp = 0;
+        const int64_t n16 = l.pack16(h_w.data(), nullptr, ly.cout, cin, ly.k, ly.k, &cp);
+        if (n16 > 0) {
+          std::vector<uint16_t> w16(n16);
+          l.pack16(h_w.data(), w16.data(), ly.cout, cin, ly.k, ly.k, &cp);
+          float* d_w16 = dev_alloc_guarded((n16 + 1) / 2, keep);
+          HIP_OK(hipMemcpy(d_w16, w16.data(), n16 * 2, hipMemcpyHostToDevice));
+          d.weight_f16 = d_w16;
+          d.amp = 1;
+        }
+      }
       int rc = 0;
       for (int w = 0; w < 2 && !rc; ++w) rc = l.conv(&d, st);
       if (rc) { printf(" | error: %s", l.err ? l.err() : "?"); continue; }

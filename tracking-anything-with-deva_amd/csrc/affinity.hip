@@ -1320,8 +1320,8 @@ __global__ __launch_bounds__(256) void readout_sparse_kernel(const int32_t* __re
 //               just under 2^15 (fp16 max 65 504); non-finite input -> fall-back flag;
 //   pf_prep     the bank as fp16 MFMA A-operands, tile-major [tile][9 K-blocks][64 lanes][8 halfs]: every
 //               operand load of the passes is one fully coalesced 1-KiB instruction;
-//   pass A      group maxima of lo: per (token range, query) 64 groups (token slot in the tile x tile
-//               parity) of DISTINCT tokens, so the k-th largest group maximum over all ranges is a valid
+//   pass A      group maxima of lo: per (token range, query) PF_GROUPS = 32 groups (one per token slot of the
+//               tiles) of DISTINCT tokens, so the k-th largest group maximum over all ranges is a valid
 //               lower bound of the k-th best score -- with 512 groups at 1080p it sits within a few per
 //               cent of the true k-th best (expected ~k+2 tokens above it); 2 VALU per score;
 //   pf_tau      one wave per query: k-th largest of its group maxima -> filter threshold;
@@ -2426,7 +2426,7 @@ extern "C" int deva_affinity_read_flag(const uint64_t* scratch, void* stream) {
 }
 
 // test / tuning hook: candidate statistics of the last pre-filtered read on `scratch` (synchronises the stream):
-// out[0] = fall-back flag, out[1] = largest sub-list count (capacity 32 per (range, query, half-lane)), out[2] = largest
+// out[0] = fall-back flag, out[1] = largest sub-list count (capacity PF_SUB = 64 per (range, query, half-lane)), out[2] = largest
 // number of candidates of one query, out[3] = mean candidates per query x 1000, out[4] = ranges (splits)
 extern "C" int deva_affinity_read_stats(const uint64_t* scratch, int n_total, int hw, int k, int64_t* out, void* stream) {
   DEVA_REQUIRE(scratch && out && hw > 0, "deva_affinity_read_stats: bad args");

@@ -53,11 +53,14 @@ struct ConvArgs {
   int per_split;     // K steps per split
   float* ws;         // [splits][cout][n_total]
   int64_t in0_span, in1_span;  // elements from the first to one past the last element of each input
+  const void* w16;   // conv_f16.hip: fp16 weights (DEVA_KLAYOUT_H8) or null
 };
 
 // conv_igemm.hip: out = act(sum_s ws[s] + bias + residual) for a split-K launch (p.splits > 1)
 int launch_splitk_reduce(const ConvArgs& p, hipStream_t st);
 // conv_mfma.hip: lean-loop kernels for weights in the k-quad layout (DEVA_KLAYOUT_Q4)
 int launch_conv_q4(const ConvArgs& a, hipStream_t st);
+// conv_f16.hip: fp16-operand kernels (opt-in amp path); -1 = shape not eligible, run the fp32 kernels
+int launch_conv_f16(const ConvArgs& a, hipStream_t st);
 
 }  // namespace deva

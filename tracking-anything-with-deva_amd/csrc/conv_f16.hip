@@ -1,0 +1,359 @@
+// Implicit-GEMM convolution with fp16 OPERANDS and fp32 accumulation: v_mfma_f32_32x32x16_f16 (16x the fp32 matrix
+// rate of gfx950).  The opt-in `--amp` path (deva/inference/eval_args.py:17, evaluation/eval_vos.py:137: the reference
+// wraps its frame loop in fp16 autocast): activations stay fp32 in HBM and are rounded to fp16 (RNE) while they are
+// staged, the weights are packed as fp16 once, products are exact in fp32, sums / bias / residual / activation / output
+// are fp32 -- the arithmetic the oracle's amp mode restates (conv inputs and weights rounded to fp16).
+//
+// Same tile machinery as conv_mfma.hip (buffer-addressed staging two K steps ahead, barrier before the last MFMA
+// group, row reuse of the 3x3 path with the zero column, compile-time buffer indices), with
+//   * 64-deep K steps (four MFMA K-blocks of 16): an fp16 K step of 32 would be 128 matrix-pipe cycles per wave,
+//     less than the barrier and the staging around it cost;
+//   * weights Wh[K/8][cout_pad][8] fp16 (DEVA_KLAYOUT_H8: eight consecutive k of one output channel = 16 bytes = the
+//     A fragment of one lane for one K-block), K ordered in 64-channel slabs for kernels larger than 1x1;
+//   * the activation tile as Bs[k/8][pixel][8] fp16: every thread gathers EIGHT channels x two pixels (eight 8-byte
+//     fp32 loads), converts, and writes one 16-byte octet per pixel -- the transposition costs no shuffles, only the
+//     register naming of the converts; a lane's B fragment of a K-block is one ds_read_b128.
+// Kinds: 0 = 1x1 stride 1, 1 = 3x3 stride 1 pad 1 (row reuse); both on guard-banded inputs whose channel counts are
+// multiples of 64.  Everything else stays on the fp32 kernels (the caller falls back).
+#include <type_traits>
+
+#include "conv_epilogue.h"
+
+namespace deva {
+namespace {
+
+typedef conv_f32x16 f32x16;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+constexpr int BKH = 64;  // K step
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KIND, int MINW>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(const ConvArgs p) {
+  constexpr int THREADS = 64 * WAVES_M * WAVES_N;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  static_assert(TM >= 1 && TN == 1, "wave tile: one pixel per lane");
+  constexpr bool ROW = KIND == 1;
+  constexpr int OCT = BKH / 8;                     // k-octets per K step
+  constexpr int A_V4 = OCT * BM / THREADS;         // 16-byte loads of the weight tile per thread and K step
+  constexpr int A_PASS = THREADS / BM;             // octet rows per pass
+  static_assert(A_V4 >= 1 && A_V4 * THREADS == OCT * BM, "weight tile geometry");
+  constexpr int BNP = ROW ? BN + 8 : BN;           // ROW: columns 3 .. BN+4 hold pixels n0-1 .. n0+BN, column 0 stays zero
+  constexpr int NQ = BN / 2;                       // pixel pairs per tile row
+  constexpr int TASKS = OCT * NQ;                  // (octet, pixel pair) gather tasks per tile: one per thread
+  static_assert(TASKS == THREADS, "one gather task per thread");
+  constexpr int A_HALFS = OCT * BM * 8, B_HALFS = OCT * BNP * 8;
+
+  __shared__ __attribute__((aligned(16))) _Float16 smem[2 * A_HALFS + 2 * B_HALFS];
+  _Float16* const sA = smem;
+  _Float16* const sB = smem + 2 * A_HALFS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave / WAVES_N) * WM;
+  const int wn0 = (wave % WAVES_N) * WN;
+  const int l31 = lane & 31;
+  const int half = lane >> 5;
+
+  const int logical = conv_logical_tile();
+  const int tile_n = logical / p.tiles_m;
+  const int tile_m = logical - tile_n * p.tiles_m;
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  // ---- weights: thread t loads octet row t / BM (+ A_PASS per pass), output channel m0 + t % BM
+  const int a_voff = ((tid / BM) * p.cout_pad + m0 + (tid % BM)) * 16;
+  const int a_pass_bytes = A_PASS * p.cout_pad * 16;
+  const int a_step_bytes = OCT * p.cout_pad * 16;
+  const int a_total_bytes = ((p.K + 7) >> 3) * p.cout_pad * 16;
+
+  // ---- gather task of this thread: octet `oct` (8 channels), pixels n0 + 2*vq, +1
+  const int oct = tid / NQ, vq = tid % NQ;
+  int b_voff0 = 0, b_voff1 = 0;
+  {
+    const int n4 = n0 + 2 * vq;
+    const int nn = (n4 < p.n_total) ? n4 : 0;  // OHW % 4 == 0: a pair never straddles images or the end
+    const int b = nn / p.OHW;
+    const int pix = nn - b * p.OHW;
+    b_voff0 = (int)(((int64_t)b * p.bs0 + (int64_t)8 * oct * p.HW + pix) * 4);
+    b_voff1 = (int)(((int64_t)b * p.bs1 + (int64_t)8 * oct * p.HW + pix) * 4);
+  }
+  const int b_row_bytes = (int)(p.HW * 4);
+  // ROW: halo pixels (n0-1, n0+BN) of every octet: 2 * OCT tasks of eight scalar loads, on the first threads
+  const bool has_halo = ROW && tid < 2 * OCT;
+  const int h_side = tid & 1, h_oct = (tid >> 1) % OCT;
+  int h_voff0 = 0, h_voff1 = 0;
+  unsigned cmask = 0;  // 9-bit validity mask (bit dy*3+dx) of the pixel this lane consumes
+  if (ROW) {
+    int nh = h_side ? n0 + BN : n0 - 1;
+    nh = min(max(nh, 0), p.n_total - 1);
+    const int b = nh / p.OHW;
+    const int pix = nh - b * p.OHW;
+    h_voff0 = (int)(((int64_t)b * p.bs0 + (int64_t)8 * h_oct * p.HW + pix) * 4);
+    h_voff1 = (int)(((int64_t)b * p.bs1 + (int64_t)8 * h_oct * p.HW + pix) * 4);
+    const int n = n0 + wn0 + l31;
+    if (n < p.n_total) {
+      const int px = n % p.OHW;
+      const int oh = px / p.OW, ow = px - oh * p.OW;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const bool ok = ((unsigned)(oh + t / 3 - 1) < (unsigned)p.H) && ((unsigned)(ow + t % 3 - 1) < (unsigned)p.W);
+        cmask |= ok ? (1u << t) : 0u;
+      }
+    }
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.0f;
+
+  const int ksteps_total = (p.K + BKH - 1) / BKH;
+  int ks0 = 0, ksteps = ksteps_total;
+  if (p.splits > 1) {
+    ks0 = (int)blockIdx.y * p.per_split;
+    ksteps = max(0, min(ksteps - ks0, p.per_split));
+  }
+  const int ks_last = ks0 + max(ksteps, 1) - 1;
+
+  // ---- staging registers: two sets for the weights (loads two K steps ahead), one for the activation gather
+  constexpr int ASETS = 2;
+  f32x4 ra[ASETS][A_V4];
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 rb[8];     // eight channels x two pixels
+  float rh[ROW ? 8 : 1];  // halo threads: eight channels of their one pixel
+
+  auto load_a = [&](int t_raw, auto setc) {
+    constexpr int SET = decltype(setc)::value % ASETS;
+    const int t = min(t_raw, ks_last);
+    const int off = t * a_step_bytes;
+    const __amdgpu_buffer_rsrc_t r = make_rsrc(reinterpret_cast<const char*>(p.w16) + off, max(a_total_bytes - off, 0));
+#pragma unroll
+    for (int i = 0; i < A_V4; ++i) ra[SET][i] = buf_load4(r, a_voff, i * a_pass_bytes);
+  };
+  // activation tile of K step t (KIND 0) / the (64-channel slab, dy) row tile that starts at step t (KIND 1)
+  auto load_b = [&](int t_raw) {
+    const int t = min(t_raw, ks_last);
+    int cbase = t * BKH, shift = 0;
+    if (ROW) {
+      const int chunk = t / 9;
+      cbase = chunk * BKH;
+      shift = ((t - chunk * 9) / 3 - 1) * p.W;
+    }
+    const bool first = cbase < p.c0;
+    const float* base = (first ? p.in0 : p.in1) + ((int64_t)(first ? cbase : cbase - p.c0) * p.HW + shift);
+    const __amdgpu_buffer_rsrc_t r = make_rsrc(base, 0x7fffffff);
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      rb[c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, first ? b_voff0 : b_voff1, c * b_row_bytes, 0));
+    if (has_halo) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) rh[c] = buf_load1(r, first ? h_voff0 : h_voff1, c * b_row_bytes);
+    }
+  };
+  auto store_a = [&](auto setc) {
+    constexpr int BUF = decltype(setc)::value, SET = BUF % ASETS;
+    _Float16* a = sA + BUF * A_HALFS + tid * 8;
+#pragma unroll
+    for (int i = 0; i < A_V4; ++i) *reinterpret_cast<f32x4*>(a + i * THREADS * 8) = ra[SET][i];
+  };
+  // fp32 -> fp16 (round to nearest even, like torch's .half()), relu-on-load first; one 16-byte octet per pixel
+  auto store_b = [&](int buf) {
+    _Float16* bt = sB + buf * B_HALFS;
+#pragma unroll
+    for (int px = 0; px < 2; ++px) {
+      h8 o;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float v = rb[c][px];
+        if (p.relu_in) v = fmaxf(v, 0.0f);
+        o[c] = (_Float16)v;
+      }
+      *reinterpret_cast<h8*>(bt + (oct * BNP + (ROW ? 4 : 0) + 2 * vq + px) * 8) = o;
+    }
+    if (has_halo) {
+      h8 o;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float v = rh[c];
+        if (p.relu_in) v = fmaxf(v, 0.0f);
+        o[c] = (_Float16)v;
+      }
+      *reinterpret_cast<h8*>(bt + (h_oct * BNP + (h_side ? BN + 4 : 3)) * 8) = o;
+    }
+  };
+
+  // ---- fragments: lane (row or pixel l31, k-group half) holds k = 16*kb + 8*half + 0..7 of K-block kb: one ds_read_b128
+  const _Float16* const a_rd0 = sA + (half * BM + wm0 + l31) * 8;
+  const _Float16* const b_rd0 = sB + (half * BNP + wn0 + l31 + (ROW ? 3 : 0)) * 8;
+  const _Float16* const b_zero0 = sB + (half * BNP) * 8;
+  h8 fa[2][TM], fb[2];
+  auto frag_load = [&](int set, const _Float16* a_rd, const _Float16* b_rd, int kb) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[set][i] = *reinterpret_cast<const h8*>(a_rd + (2 * kb * BM + 32 * i) * 8);
+    fb[set] = *reinterpret_cast<const h8*>(b_rd + (2 * kb * BNP) * 8);
+  };
+  auto mfma_block = [&](int set) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][i], fb[set], acc[i][0], 0, 0, 0);
+  };
+
+  auto taps_of = [&](int t) { return (cmask >> (t % 9 / 3 * 3)) & 7u; };
+  unsigned m3 = ROW ? taps_of(ks0) : 0u;
+  const _Float16* b_cur = ROW ? ((m3 & 1u) ? b_rd0 : b_zero0) : b_rd0;
+
+  // One K step of four K-blocks; buffer / register-set indices are compile-time (see conv_mfma.hip).
+  auto step = [&](int s, auto dxc, auto parc, auto gbc) {
+    constexpr int DX = decltype(dxc)::value, PAR = decltype(parc)::value, GB = decltype(gbc)::value;
+    constexpr int DXN = ROW ? (DX + 1) % 3 : 0;
+    constexpr int GBN = (ROW && DX == 2) ? (GB ^ 1) : GB;
+    const int t = ks0 + s;
+    const _Float16* a_rd = a_rd0 + PAR * A_HALFS;
+    const _Float16* a_nx = a_rd0 + (PAR ^ 1) * A_HALFS;
+    const _Float16* b_nx;
+    if (ROW) {
+      if (DX == 2) m3 = taps_of(t + 1);
+      b_nx = ((m3 >> DXN) & 1u) ? (b_rd0 + GBN * B_HALFS + 8 * DXN) : (b_zero0 + GBN * B_HALFS);
+    } else {
+      b_nx = b_rd0 + (PAR ^ 1) * B_HALFS;
+    }
+    frag_load(1, a_rd, b_cur, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block(0);
+    __builtin_amdgcn_sched_barrier(0);
+    frag_load(0, a_rd, b_cur, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block(1);
+    __builtin_amdgcn_sched_barrier(0);
+    frag_load(1, a_rd, b_cur, 3);
+    store_a(std::integral_constant<int, PAR ^ 1>{});
+    if (ROW) {
+      if (DX == 2) store_b(GB ^ 1);
+    } else {
+      store_b(PAR ^ 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    load_a(t + 1 + ASETS, std::integral_constant<int, PAR ^ 1>{});
+    if (ROW) {
+      if (DX == 0) load_b(t + 3);
+    } else {
+      load_b(t + 2);
+    }
+    frag_load(0, a_nx, b_nx, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block(1);
+    __builtin_amdgcn_sched_barrier(0);
+    b_cur = b_nx;
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+
+  // ---- prologue
+  if (ROW) {
+    for (int i = tid; i < 2 * OCT * 8; i += THREADS) sB[(i / (OCT * 8)) * B_HALFS + ((i / 8) % OCT) * BNP * 8 + (i & 7)] = (_Float16)0.0f;
+  }
+  load_a(ks0, I0{});
+  load_b(ks0);
+  store_a(I0{});
+  store_b(0);
+  __syncthreads();
+  load_a(ks0 + 1, I1{});
+  if (ASETS == 2) load_a(ks0 + 2, I0{});
+  if (!ROW) load_b(ks0 + 1);
+  frag_load(0, a_rd0, b_cur, 0);
+
+  if (ROW) {
+    int s = 0;
+    for (; s + 6 <= ksteps; s += 6) {
+      step(s, I0{}, I0{}, I0{});
+      step(s + 1, I1{}, I1{}, I0{});
+      step(s + 2, I2{}, I0{}, I0{});
+      step(s + 3, I0{}, I1{}, I1{});
+      step(s + 4, I1{}, I0{}, I1{});
+      step(s + 5, I2{}, I1{}, I1{});
+    }
+    if (s < ksteps) {
+      step(s, I0{}, I0{}, I0{});
+      step(s + 1, I1{}, I1{}, I0{});
+      step(s + 2, I2{}, I0{}, I0{});
+    }
+  } else {
+    int s = 0;
+    for (; s + 2 <= ksteps; s += 2) {
+      step(s, I0{}, I0{}, I0{});
+      step(s + 1, I0{}, I1{}, I0{});
+    }
+    if (s < ksteps) step(s, I0{}, I0{}, I0{});
+  }
+
+  conv_store_tile<TM, TN>(p, acc, m0, wm0, n0, wn0, l31, half);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MINW>
+int launch_tile_f16(const ConvArgs& a, int kind, hipStream_t st) {
+  ConvArgs p = a;
+  p.tiles_m = (int)ceil_div(a.cout, BM);
+  p.tiles_n = (int)ceil_div(a.n_total, BN);
+  const int ksteps_total = (int)ceil_div(a.K, BKH);
+  p.per_split = ksteps_total;
+  p.splits = 1;
+  const int64_t blocks = (int64_t)p.tiles_m * p.tiles_n;
+  if (a.ws && blocks < 192 && ksteps_total >= 12) {  // few tiles, long K: deterministic split-K like the fp32 kernels
+    int64_t sp = ceil_div(512, blocks);
+    if (sp > ksteps_total / 6) sp = ksteps_total / 6;
+    if (sp > 16) sp = 16;
+    const int64_t fit = a.ws_elems / ((int64_t)a.cout * a.n_total);
+    if (sp > fit) sp = fit;
+    if (sp >= 2) {
+      int per = (int)ceil_div(ksteps_total, sp);
+      if (kind == 1) per = (per + 2) / 3 * 3;
+      p.splits = (int)ceil_div(ksteps_total, per);
+      p.per_split = per;
+    }
+  }
+  const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splits), block(64 * WAVES_M * WAVES_N);
+  if (kind == 0) {
+    hipLaunchKernelGGL((conv_f16_kernel<BM, BN, WAVES_M, WAVES_N, 0, MINW>), grid, block, 0, st, p);
+  } else {
+    hipLaunchKernelGGL((conv_f16_kernel<BM, BN, WAVES_M, WAVES_N, 1, MINW>), grid, block, 0, st, p);
+  }
+  if (p.splits > 1) return launch_splitk_reduce(p, st);
+  return check_launch("deva_conv2d (fp16 operands)");
+}
+
+}  // namespace
+
+// -> 0 launched, 1 launch error, -1 not eligible (the caller runs the fp32 kernels)
+int launch_conv_f16(const ConvArgs& a, hipStream_t st) {
+  if (!a.w16 || !a.vec_ok || a.stride != 1 || a.cout < 64 || a.c0 % BKH || a.c1 % BKH) return -1;
+  int kind;
+  if (a.KH == 1 && a.KW == 1) {
+    kind = 0;
+  } else if (a.KH == 3 && a.KW == 3 && a.pad == 1) {
+    kind = 1;
+  } else {
+    return -1;
+  }
+  const int64_t blocks128 = ceil_div(a.cout, 128) * ceil_div(a.n_total, 128);
+  if (a.cout >= 128 && blocks128 >= 64) return launch_tile_f16<128, 128, 2, 4, 4>(a, kind, st);
+  return launch_tile_f16<64, 64, 2, 2, 2>(a, kind, st);
+}
+
+}  // namespace deva

@@ -708,6 +708,7 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
   a.splits = 1;
   a.ws = d->workspace;
   a.ws_elems = d->workspace ? d->workspace_elems : 0;
+  a.w16 = d->amp ? d->weight_f16 : nullptr;
   a.in0_span = (int64_t)(d->batch - 1) * a.bs0 + (int64_t)a.c0 * a.HW;
   a.in1_span = a.in1 ? (int64_t)(d->batch - 1) * a.bs1 + (int64_t)a.c1 * a.HW : 0;
 
@@ -747,6 +748,13 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
     c.out = a.out;
     if (rows3x3) return launch_conv3x3_cout1_rows(c, st);
     return launch_conv_cout1(c, st);
+  }
+  if (a.w16 && a.cout > 1) {
+    // opt-in fp16 operands (fp32 accumulation): eligible shapes only, everything else stays exact fp32
+    DEVA_REQUIRE(a.in0_span < (1ll << 29) && a.in1_span < (1ll << 29),
+                 "deva_conv2d: fp16-operand path needs inputs below 2 GiB (32-bit buffer offsets)");
+    const int rc = launch_conv_f16(a, st);
+    if (rc >= 0) return rc;
   }
   if (a.k_layout & DEVA_KLAYOUT_Q4) {
     // buffer addressing: 32-bit byte offsets from the tensor bases
@@ -801,6 +809,35 @@ extern "C" int64_t deva_conv_pack(const float* w_oihw, float* out, int cout, int
         const int64_t k = chunk ? ((int64_t)(c / 32) * taps + t) * 32 + c % 32 : (int64_t)t * cin + c;
         const int64_t at = q4 ? ((k >> 2) * cout_pad + m) * 4 + (k & 3) : k * cout_pad + m;
         out[at] = w_oihw[((int64_t)m * cin + c) * taps + t];
+      }
+  return elems;
+}
+
+// fp16 weights of the opt-in amp path (host side, model load): element (k, m) at ((k/8)*cout_pad + m)*8 + k%8, IEEE
+// binary16 bits, round to nearest even; K order: tap-major for 1x1, 64-channel slabs otherwise
+// (k = ((c/64)*taps + tap)*64 + c%64; needs cin % 64 == 0, else -1: the layer stays fp32).
+extern "C" int64_t deva_conv_pack_f16(const float* w_oihw, uint16_t* out, int cout, int cin, int kh, int kw, int* cout_pad_out) {
+  using namespace deva;
+  if (!w_oihw || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0 || !cout_pad_out) {
+    set_error("deva_conv_pack_f16: bad arguments");
+    return -1;
+  }
+  const int taps = kh * kw;
+  if (cin % 64 != 0) return -1;
+  const int K = taps * cin;
+  const int cout_pad = (cout + 31) / 32 * 32;
+  const int64_t elems = (int64_t)K * cout_pad;
+  *cout_pad_out = cout_pad;
+  if (!out) return elems;
+  for (int64_t i = 0; i < elems; ++i) out[i] = 0;
+  for (int m = 0; m < cout; ++m)
+    for (int c = 0; c < cin; ++c)
+      for (int t = 0; t < taps; ++t) {
+        const int64_t k = taps > 1 ? ((int64_t)(c / 64) * taps + t) * 64 + c % 64 : c;
+        const _Float16 h = (_Float16)w_oihw[((int64_t)m * cin + c) * taps + t];
+        uint16_t bits;
+        __builtin_memcpy(&bits, &h, 2);
+        out[((k >> 3) * cout_pad + m) * 8 + (k & 7)] = bits;
       }
   return elems;
 }

@@ -28,7 +28,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include "conv_args.h"
+#include "conv_epilogue.h"
 
 #ifdef DEVA_CONV_PROBES
 // `make PROBES=1` builds only: wall-clock stamps (100 MHz) of wave 0 of every workgroup at four points of the kernel
@@ -44,7 +44,7 @@ __device__ unsigned long long* g_conv_probe = nullptr;
 namespace deva {
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef conv_f32x16 f32x16;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;
@@ -119,13 +119,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (KIND <= 1 || MINW < 2
     __syncthreads();
   }
 
-  // cout tiles fastest, XCD x gets a contiguous range of logical tiles (workgroup b runs on XCD b % 8)
-  int logical;
-  {
-    const int nb = gridDim.x, b = blockIdx.x;
-    const int q = nb >> 3, r = nb & 7, xcd = b & 7;
-    logical = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-  }
+  const int logical = conv_logical_tile();
   const int tile_n = logical / p.tiles_m;
   const int tile_m = logical - tile_n * p.tiles_m;
   const int m0 = tile_m * BM;
@@ -527,60 +521,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (KIND <= 1 || MINW < 2
     }
   }
 
-  if (p.splits > 1) {
-    // ---- split-K: raw partial sums, reduced (+ bias / residual / activation) by splitk_reduce_kernel
-    float* ws = p.ws + (int64_t)blockIdx.y * p.cout * p.n_total;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn0 + j * 32 + l31;
-      if (n >= p.n_total) continue;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (m < p.cout) ws[(int64_t)m * p.n_total + n] = acc[i][j][r];
-        }
-    }
-    return;
-  }
-
-  // ---- epilogue: bias + residual + activation, NCHW store (32 consecutive pixels per half-wave)
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn0 + j * 32 + l31;
-    if (n >= p.n_total) continue;
-    const int b = n / p.OHW;
-    const int pix = n - b * p.OHW;
-    const int64_t obase = (int64_t)b * p.cout * p.OHW + pix;
-    const int64_t rbase = (int64_t)b * p.res_bs + pix;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      float bv[16], rv[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int mm = (m < p.cout) ? m : 0;
-        bv[r] = p.bias ? p.bias[mm] : 0.0f;
-        rv[r] = p.res ? p.res[rbase + (int64_t)mm * p.OHW] : 0.0f;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float v = acc[i][j][r];
-        if (p.bias) v += bv[r];
-        if (p.res) v += rv[r];
-        if (p.act == DEVA_ACT_RELU) {
-          v = fmaxf(v, 0.0f);
-        } else if (p.act == DEVA_ACT_SIGMOID) {
-          v = sigmoidf_(v);
-        } else if (p.act == DEVA_ACT_SQUARE_PLUS_ONE) {
-          v = v * v + 1.0f;
-        }
-        if (m < p.cout) p.out[obase + (int64_t)m * p.OHW] = v;
-      }
-    }
-  }
+  conv_store_tile<TM, TN>(p, acc, m0, wm0, n0, wn0, l31, half);
   DEVA_STAMP(3);
 }
 

@@ -314,7 +314,9 @@ def _affinity_workspace(elems: int, device) -> torch.Tensor:
     if ws is None or ws.numel() < elems:
         # grow geometrically: the scratch of deva_affinity_read scales with the bank, which grows every memory frame --
         # an exact-size buffer would be re-allocated (a fresh hipMalloc, the old block parked in the cache) each time
-        ws = _AFF_WS[key] = torch.empty((max(elems + elems // 2, 1 << 20),), dtype=torch.int64, device=device)
+        # (+50 % for small buffers, +12.5 % once the buffer is beyond 256 MiB: the 4K read's scratch is ~0.7 GiB)
+        slack = elems // 2 if elems < (32 << 20) else elems // 8
+        ws = _AFF_WS[key] = torch.empty((max(elems + slack, 1 << 20),), dtype=torch.int64, device=device)
     return ws
 
 

@@ -121,6 +121,11 @@ class MemoryManager:
         import torch.distributed as dist
         if not dist.is_initialized():
             raise RuntimeError('shard_queries: torch.distributed is not initialised')
+        if getattr(self, '_values_sharded', False):
+            # the value rows of a value-sharded manager live on different ranks: a query-sharded read would return
+            # un-summed partial read-outs
+            raise RuntimeError('shard_queries: this manager stores value-sharded banks (shard_bank(shard_values=True)); '
+                               'build a new MemoryManager to change the mode')
         self._shard_group = group if group is not None else dist.group.WORLD
         self._shard_mode = 'queries'
         self._shard_owner = owner
@@ -152,6 +157,9 @@ class MemoryManager:
         if dist.get_world_size(self._shard_group) > 32:
             # deva_affinity_merge takes at most 32 candidate lists (MAX_SPLITS, include/deva_hip.h)
             raise ValueError('shard_bank: at most 32 ranks per group (one candidate list per rank is merged)')
+        if shard_values and (self.work_mem.buckets or (self.use_long_term and self.long_mem.buckets)):
+            raise RuntimeError('shard_bank(shard_values=True) must be called before the first memory frame: the stores '
+                               'already hold replicated value rows (pass shard_values=False to shard the read only)')
         self._shard_mode = 'bank'
         self._shard_owner = owner
         self.comm_bytes = 0
@@ -463,13 +471,22 @@ class MemoryManager:
             import torch.distributed as dist
             n_own = int(owned_rows.numel())
             gemm_own = ops.PackedConv(aff.index_select(0, owned_rows).contiguous(), None, n_own, P, aff.shape[1], 1, 1) if n_own else None
-            for obj, v in candidate_value.items():
+            # the partial sums of ALL objects travel in one collective (one all_reduce per object is latency-bound with
+            # many objects; the sum per element is the same)
+            objs = list(candidate_value)
+            world = dist.get_world_size(self._shard_group)
+            parts = []
+            for obj in objs:
+                v = candidate_value[obj]
                 cv = v.shape[1]
-                part = (ops.conv2d(gemm_own, v.contiguous().reshape(1, n_own, 1, cv)).view(P, cv) if n_own
-                        else torch.zeros((P, cv), dtype=torch.float32, device=aff.device))
-                dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self._shard_group)
-                self.comm_bytes += 2 * part.numel() * 4
-                proto_val[obj] = part
+                parts.append(ops.conv2d(gemm_own, v.contiguous().reshape(1, n_own, 1, cv)).view(P, cv) if n_own
+                             else torch.zeros((P, cv), dtype=torch.float32, device=aff.device))
+            if parts:
+                stacked = torch.stack(parts, 0)
+                dist.all_reduce(stacked, op=dist.ReduceOp.SUM, group=self._shard_group)
+                self.comm_bytes += 2 * stacked.numel() * 4 * (world - 1) // world  # like _sum_partial_readouts
+                for i, obj in enumerate(objs):
+                    proto_val[obj] = stacked[i]
         for obj, v in ([] if owned_rows is not None else candidate_value.items()):
             cv = v.shape[1]
             proto_val[obj] = ops.conv2d(gemm, v.reshape(1, n_cand, 1, cv)).view(P, cv)
