@@ -81,13 +81,13 @@ def conv_source_sha1():
 PEAK_HBM_GBPS = 8000.0
 
 
-def build_network(device):
+def build_network(device, amp=False):
     from workload import synth, weights
     from deva.model.network import DEVA
     with open(os.path.join(ROOT, 'tests', 'golden', 'state_dict_spec.json')) as f:
         spec = json.load(f)['tensors']
     sd = weights.make_state_dict([(k, tuple(s), getattr(torch, d)) for k, s, d in spec], seed=0)
-    net = DEVA(synth.base_config())
+    net = DEVA(dict(synth.base_config(), amp=amp))
     net.load_weights(sd)
     return net.to(device).eval(), sd
 
@@ -150,11 +150,14 @@ class ConvTimer:
                             + cin * d.kh * d.kw * d.cout + d.cout * oh * ow * d.batch
                             + (d.cout * oh * ow * br if d.residual else 0) + (d.cout if d.bias else 0))
             sig = (cin, d.cout, d.kh, d.stride, d.batch, oh, ow)
+            # the shapes csrc/conv_f16.hip takes when amp is requested (launch_conv_f16 + the vector-gather geometry)
+            f16 = bool(d.amp and d.weight_f16 and d.stride == 1 and d.cout >= 64 and d.c0 % 64 == 0 and d.c1 % 64 == 0
+                       and ((d.kh == 1 and d.pad == 0) or (d.kh == 3 and d.pad == 1)) and (oh * ow) % 4 == 0 and ow >= 4)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             rc = self.real(desc_ref, stream)
             e.record()
-            self.records.append((flops, s, e, sig, nbytes))
+            self.records.append((flops, s, e, sig, nbytes, f16))
             return rc
 
         self.handle.deva_conv2d = timed
@@ -169,10 +172,20 @@ class ConvTimer:
         ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
         return flops, ms, len(self.records), sum(r[4] for r in self.records)
 
+    def split_by_precision(self):
+        """-> {'f16': (flops, ms, launches), 'f32': (...)}: launches the fp16-operand kernels took vs the fp32 ones"""
+        out = {'f16': [0.0, 0.0, 0], 'f32': [0.0, 0.0, 0]}
+        for r in self.records:
+            o = out['f16' if r[5] else 'f32']
+            o[0] += r[0]
+            o[1] += r[1].elapsed_time(r[2])
+            o[2] += 1
+        return out
+
     def per_layer(self, frames):
         """time and achieved TFLOP/s per distinct (cin, cout, k, stride, batch, OH, OW)"""
         agg = {}
-        for fl, s, e, sig, _ in self.records:
+        for fl, s, e, sig, _, _ in self.records:
             a = agg.setdefault(sig, [0, 0.0, 0.0])
             a[0] += 1
             a[1] += fl
@@ -562,7 +575,7 @@ def run_1080p(net, device, steps, warmup, detections, seed=7):
     return steps / elapsed, state
 
 
-def run_1080p_segments(net, device, steps, warmup, segments=8, seed=7, size=(1080, 1920)):
+def run_1080p_segments(net, device, steps, warmup, segments=8, seed=7, size=(1080, 1920), conv_roofline=False):
     """BASELINE configs[2] as SURVEY.md 8d defines it: 1920x1080, a precomputed detection with `segments` segments
     merged every 5th frame through incorporate_detection (online setting of evaluation/eval_with_detections.py:
     280-297, --max_missed_detection_count 1, no object cap), long-term memory pre-filled to 10 000 tokens.
@@ -635,6 +648,27 @@ def run_1080p_segments(net, device, steps, warmup, segments=8, seed=7, size=(108
              'segments_per_detection': segments,
              'matched_segments': sum(1 for t, (_, info) in dets.items() if t > warmup for i in info if i['id'] > 100000),
              'object_table_at_end(id, missed detections)': table(core)}
+    if conv_roofline:
+        # event-timed replay of the same clip (third pass): convolution FLOPs / time, split by the kernels that took them
+        core2 = DEVAInferenceCore(net, cfg)
+        live.clear()
+        core, core2 = core2, core
+        run(0)
+        prefill(core)
+        for t in range(1, 1 + warmup):
+            run(t)
+        torch.cuda.synchronize()
+        with ConvTimer() as ct:
+            for t in range(1 + warmup, n_frames):
+                run(t)
+        sp = ct.split_by_precision()
+        f16, f32 = sp['f16'], sp['f32']
+        state['conv_roofline'] = {
+            'f16_kernels': {'tflops': f16[0] / max(f16[1], 1e-9) / 1e9, 'frac_of_f16_mfma_peak': f16[0] / max(f16[1], 1e-9) / 1e9 / PEAK_F16_MATRIX_TFLOPS,
+                            'gflop_per_frame': f16[0] / steps / 1e9, 'ms_per_frame': f16[1] / steps, 'launches_per_frame': f16[2] / steps},
+            'f32_kernels': {'tflops': f32[0] / max(f32[1], 1e-9) / 1e9, 'frac_of_fp32_mfma_peak': f32[0] / max(f32[1], 1e-9) / 1e9 / PEAK_FP32_MATRIX_TFLOPS,
+                            'gflop_per_frame': f32[0] / steps / 1e9, 'ms_per_frame': f32[1] / steps, 'launches_per_frame': f32[2] / steps},
+            'method': 'HIP events around every deva_conv2d launch of a replay of the timed frames (bench.py:ConvTimer)'}
     return steps / elapsed, state
 
 
@@ -716,6 +750,16 @@ def extra_lines(net, device, cfg, args):
              'tests/test_gpu_g_fullsize.py::test_1080p_eight_segment_detections_against_oracle (8 segments, 14 live objects '
              'at 1080p, the same generator) + tests/test_gpu_e_network.py::test_consistent_detection_clip_against_reference_golden',
              'state_at_end'),
+        line('propagation FPS @1080p, --amp (8-segment detections merged every 5th frame, ~10 live objects, 10k-token '
+             'long-term bank)',
+             lambda: run_1080p_segments(build_network(device, amp=True)[0], device, steps=25, warmup=6, segments=8,
+                                        conv_roofline=True), 25, 6,
+             'the 8-segment clip above with --amp: fp16 operands / fp32 accumulation (v_mfma_f32_32x32x16_f16) in the '
+             'value encoder and the mask decoder, key encoder / key projection / memory read / aggregate / mask-logit head '
+             'fp32 (NOT the parity target: the headline and every other line are fp32)',
+             'tests/test_gpu_a_conv.py::test_conv_amp_matches_fp16_rounded_cpu (single convolutions, 2e-5) + '
+             'tests/test_gpu_e_network.py::test_amp_lockstep_teacher_forced (stages, quantisation-noise bounds)',
+             'state_at_end', dtype='f16-in/f32-acc (value encoder, mask decoder); f32 elsewhere', target_fps=25.0),
         line('propagation FPS @4K (1 object, 50k-token long-term bank), one GPU',
              lambda: run_long4k(net, device, steps=20, warmup=5, seed=11, shard=None, dist=None)[:2], 20, 5,
              'BASELINE configs[4] on ONE GPU: synthetic 3840x2160 clip, 1 object, long-term memory pre-filled to '

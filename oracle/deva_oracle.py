@@ -36,8 +36,43 @@ Params = Dict[str, torch.Tensor]
 # --------------------------------------------------------------------------------------
 
 
+# --amp of this project's HIP path (NOT the reference's autocast, which also rounds every activation to fp16): the
+# convolutions of the value encoder and the mask decoder that the fp16 kernels take (csrc/conv_f16.hip: 1x1 or 3x3/pad 1,
+# stride 1, >= 64 output channels, input channels a multiple of 64, map of a multiple of 4 pixels) see their INPUTS and
+# WEIGHTS rounded to fp16 (round to nearest even); products, sums, bias, everything else stay fp32.  Off by default.
+AMP = False
+
+
+class amp:
+    """`with O.amp():` -- the oracle restates the amp arithmetic inside the block"""
+
+    def __init__(self, on: bool = True):
+        self.on = on
+
+    def __enter__(self):
+        global AMP
+        self.prev, AMP = AMP, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global AMP
+        AMP = self.prev
+
+
+def _amp_takes(name: str, x: torch.Tensor, w: torch.Tensor, stride: int, padding: int) -> bool:
+    if not AMP or not name.startswith(('mask_encoder.', 'mask_decoder.')):
+        return False
+    cout, cin, kh, kw = w.shape
+    hh, ww = x.shape[-2:]
+    return (stride == 1 and cout >= 64 and cin % 64 == 0 and ((kh == 1 and padding == 0) or (kh == 3 and padding == 1))
+            and (hh * ww) % 4 == 0 and ww >= 4)
+
+
 def _conv(P: Params, name: str, x: torch.Tensor, stride: int = 1, padding: int = 0):
-    return F.conv2d(x, P[name + '.weight'], P.get(name + '.bias'), stride=stride, padding=padding)
+    w = P[name + '.weight']
+    if _amp_takes(name, x, w, stride, padding):
+        x, w = x.half().float(), w.half().float()
+    return F.conv2d(x, w, P.get(name + '.bias'), stride=stride, padding=padding)
 
 
 def _bn(P: Params, name: str, x: torch.Tensor):
@@ -71,10 +106,23 @@ def _bottleneck(P: Params, pre: str, x: torch.Tensor, stride: int):
     return F.relu(y + x)
 
 
+def _conv_bn(P: Params, conv: str, bn: str, x: torch.Tensor, stride: int = 1, padding: int = 0):
+    """conv -> eval-mode BatchNorm.  Under amp the HIP path rounds the BatchNorm-FOLDED weights (w * gamma / sqrt(var + eps),
+    deva/hip/ops.py:pack_conv) to fp16, so the amp restatement folds first, in the same order of operations."""
+    w = P[conv + '.weight']
+    if not _amp_takes(conv, x, w, stride, padding):
+        return _bn(P, bn, _conv(P, conv, x, stride=stride, padding=padding))
+    scale = P[bn + '.weight'] / torch.sqrt(P[bn + '.running_var'] + 1e-5)
+    shift = P[bn + '.bias'] - P[bn + '.running_mean'] * scale
+    bias = P.get(conv + '.bias')
+    bias = shift if bias is None else bias * scale + shift
+    return F.conv2d(x.half().float(), (w * scale.view(-1, 1, 1, 1)).half().float(), bias, stride=stride, padding=padding)
+
+
 def _basic_block(P: Params, pre: str, x: torch.Tensor, stride: int):
     # resnet.py:46-75
-    y = F.relu(_bn(P, pre + '.bn1', _conv(P, pre + '.conv1', x, stride=stride, padding=1)))
-    y = _bn(P, pre + '.bn2', _conv(P, pre + '.conv2', y, padding=1))
+    y = F.relu(_conv_bn(P, pre + '.conv1', pre + '.bn1', x, stride=stride, padding=1))
+    y = _conv_bn(P, pre + '.conv2', pre + '.bn2', y, padding=1)
     if (pre + '.downsample.0.weight') in P:
         x = _bn(P, pre + '.downsample.1', _conv(P, pre + '.downsample.0', x, stride=stride))
     return F.relu(y + x)

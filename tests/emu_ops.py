@@ -20,8 +20,8 @@ def require_hip(device, what):  # the emulation runs on the CPU
     return None
 
 
-def pack_conv(weight, bias=None, bn=None, device=None):
-    return _real_pack_conv(weight, bias, bn, None)
+def pack_conv(weight, bias=None, bn=None, device=None, amp=False):
+    return _real_pack_conv(weight, bias, bn, None, amp)
 
 
 def _unpack(pc: PackedConv):
@@ -46,7 +46,16 @@ def _act(y, act):
     return y
 
 
-def conv2d(pc, x0, x1=None, *, stride=1, pad=0, relu_in=False, residual=None, act=real.ACT_NONE, out=None):
+def amp_takes(pc, x0, x1, stride, pad):
+    """the shapes csrc/conv_f16.hip takes (launch_conv_f16 + the vector-gather geometry of deva_conv2d); everything
+    else runs fp32 even under amp"""
+    c0, c1 = x0.shape[1], 0 if x1 is None else x1.shape[1]
+    h, w = x0.shape[-2:]
+    return (pc.weight_f16 is not None and stride == 1 and pc.cout >= 64 and c0 % 64 == 0 and c1 % 64 == 0 and
+            ((pc.kh == 1 and pad == 0) or (pc.kh == 3 and pad == 1)) and (h * w) % 4 == 0 and w >= 4)
+
+
+def conv2d(pc, x0, x1=None, *, stride=1, pad=0, relu_in=False, residual=None, act=real.ACT_NONE, out=None, amp=False):
     batch = max(x0.shape[0], 1 if x1 is None else x1.shape[0], 1 if residual is None else residual.shape[0])
     xs = [x0.expand(batch, -1, -1, -1)]
     if x1 is not None:
@@ -55,7 +64,10 @@ def conv2d(pc, x0, x1=None, *, stride=1, pad=0, relu_in=False, residual=None, ac
     assert x.shape[1] == pc.cin
     if relu_in:
         x = F.relu(x)
-    y = F.conv2d(x, _unpack(pc), pc.bias, stride=stride, padding=pad)
+    w = _unpack(pc)
+    if amp and amp_takes(pc, x0, x1, stride, pad):  # fp16 operands (round to nearest even), fp32 products and sums
+        x, w = x.half().float(), w.half().float()
+    y = F.conv2d(x, w, pc.bias, stride=stride, padding=pad)
     if residual is not None:
         y = y + residual
     y = _act(y, act)

@@ -101,6 +101,55 @@ def test_conv_matches_cpu(case, guarded):
     assert err <= 2e-5 * max(1.0, want.abs().max().item()), (name, err)
 
 
+# --amp: fp16 operands / fp32 accumulation (csrc/conv_f16.hip) against F.conv2d on the inputs and weights rounded to fp16
+# (tests/emu_ops.py: products of fp16 values are exact in fp32, so only the accumulation order differs).  The last
+# three cases are shapes the fp16 kernels do not take: they must run exact fp32 although amp is requested.
+# (name, c0, c1, cout, k, stride, batch, H, W, bcast0, relu_in, residual, act, takes)
+AMP_CASES = [
+    ('amp_1x1_small', 64, 0, 64, 1, 1, 1, 6, 8, False, False, 'none', ops.ACT_NONE, True),
+    ('amp_1x1_res_relu', 256, 0, 1024, 1, 1, 1, 30, 54, False, False, 'full', ops.ACT_RELU, True),
+    ('amp_1x1_cat_bcast', 512, 512, 512, 1, 1, 3, 6, 8, True, False, 'none', ops.ACT_NONE, True),
+    ('amp_3x3_rowwrap', 64, 0, 64, 3, 1, 2, 6, 10, False, True, 'full', ops.ACT_NONE, True),
+    ('amp_3x3_cat_relu_in', 512, 256 + 64, 512, 3, 1, 2, 6, 8, True, True, 'none', ops.ACT_NONE, True),
+    ('amp_3x3_gru', 512, 512, 1536, 3, 1, 2, 6, 8, False, False, 'none', ops.ACT_NONE, True),
+    ('amp_3x3_big_tile', 256, 0, 256, 3, 1, 4, 60, 108, False, True, 'full', ops.ACT_NONE, True),
+    ('amp_3x3_splitk', 256, 0, 256, 3, 1, 1, 30, 54, False, False, 'none', ops.ACT_RELU, True),
+    ('amp_1x1_splitk', 1024, 0, 256, 1, 1, 1, 30, 54, False, False, 'none', ops.ACT_RELU, True),
+    ('amp_not_taken_stride2', 128, 0, 128, 3, 2, 1, 24, 32, False, False, 'none', ops.ACT_RELU, False),
+    ('amp_not_taken_513', 512, 1, 512, 1, 1, 2, 6, 8, False, False, 'full', ops.ACT_NONE, False),
+    ('amp_not_taken_odd_map', 64, 0, 64, 3, 1, 1, 5, 7, False, False, 'none', ops.ACT_NONE, False),
+]
+
+
+@pytest.mark.parametrize('case', AMP_CASES, ids=[c[0] for c in AMP_CASES])
+def test_conv_amp_matches_fp16_rounded_cpu(case):
+    name, c0, c1, cout, k, stride, batch, H, W, bcast0, relu_in, res, act, takes = case
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 100000)
+    cin, pad = c0 + c1, k // 2
+    w = rand(g, cout, cin, k, k, scale=(2.0 / (cin * k * k))**0.5)
+    b = rand(g, cout, scale=0.1)
+    pc = ops.pack_conv(w, b, None, amp=True)
+    x0 = rand(g, 1 if bcast0 else batch, c0, H, W)
+    x1 = rand(g, batch, c1, H, W) if c1 else None
+    oh, ow = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    residual = rand(g, batch, cout, oh, ow) if res == 'full' else None
+    assert emu_ops.amp_takes(pc, x0, x1, stride, pad) == takes, 'the eligibility rule of the test and of the kernels disagree'
+    want = emu_ops.conv2d(pc, x0, x1, stride=stride, pad=pad, relu_in=relu_in, residual=residual, act=act, amp=True)
+    exact = emu_ops.conv2d(pc, x0, x1, stride=stride, pad=pad, relu_in=relu_in, residual=residual, act=act)
+    got = ops.conv2d(to_dev(pc), _guarded(x0), _guarded(x1), stride=stride, pad=pad, relu_in=relu_in,
+                     residual=to_dev(residual), act=act, amp=True)
+    torch.cuda.synchronize()
+    assert not torch.isnan(got).any(), f'{name}: guard-band values leaked into the result'
+    err, scale = max_err(got, want), max(1.0, want.abs().max().item())
+    print(f'{name}: max abs err vs the fp16-rounded reference {err:.3e}; the rounding itself moves the output by '
+          f'{max_err(want, exact):.3e} (|ref|max {scale:.3e})')
+    assert err <= 2e-5 * scale, (name, err)
+    if takes:
+        assert max_err(want, exact) > 0, 'the case does not exercise the rounding'
+    else:
+        assert torch.equal(want, exact)
+
+
 def test_conv_rejects_cpu_tensors():
     pc = ops.pack_conv(torch.zeros(32, 16, 1, 1))
     with pytest.raises(Exception):

@@ -67,10 +67,30 @@ class PackedConv:
     kh: int
     kw: int
     k_layout: int = KLAYOUT_TAP_MAJOR
+    # opt-in amp path: the same weights rounded to fp16 in the layout of csrc/conv_f16.hip (None: the layer stays fp32)
+    weight_f16: Optional[torch.Tensor] = None
+
+
+def pack_f16(w: torch.Tensor) -> Optional[torch.Tensor]:
+    """[cout][cin][kh][kw] fp32 (BatchNorm already folded) -> fp16 weights of the amp kernels, element (k, m) at
+    ((k/8)*cout_pad + m)*8 + k%8; K tap-major for 1x1, 64-channel slabs otherwise (k = ((c/64)*taps + tap)*64 + c%64).
+    None when the kernels cannot take the layer (cin % 64 != 0, a single output channel).  Same arithmetic as
+    deva_conv_pack_f16 (round to nearest even)."""
+    cout, cin, kh, kw = w.shape
+    taps = kh * kw
+    if cin % 64 or cout < 2:
+        return None
+    cout_pad = (cout + 31) // 32 * 32
+    wk = torch.zeros(taps * cin, cout_pad, dtype=torch.float32, device=w.device)
+    if taps > 1:
+        wk[:, :cout] = w.reshape(cout, cin // 64, 64, taps).permute(1, 3, 2, 0).reshape(-1, cout)
+    else:
+        wk[:, :cout] = w.reshape(cout, cin).t()
+    return wk.view(-1, 8, cout_pad).permute(0, 2, 1).contiguous().to(torch.float16).reshape(-1)
 
 
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None,
-              device=None) -> PackedConv:
+              device=None, amp: bool = False) -> PackedConv:
     """One-time weight preparation (model load, not the frame path): fold an eval-mode BatchNorm
     `bn = (gamma, beta, running_mean, running_var, eps)` into the convolution and repack
     [cout][cin][kh][kw] -> [kh*kw*cin][cout_pad]."""
@@ -98,11 +118,13 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
             packed = torch.cat([packed, torch.zeros(kq * 4 - k, cout_pad, dtype=packed.dtype, device=packed.device)], 0)
         packed = packed.view(kq, 4, cout_pad).permute(0, 2, 1).contiguous().view(kq * 4, cout_pad)
         layout |= KLAYOUT_Q4
+    w16 = pack_f16(w) if amp else None
     if device is not None:
         packed = packed.to(device)
         b = None if b is None else b.to(device)
+        w16 = None if w16 is None else w16.to(device)
     return PackedConv(packed.contiguous(), None if b is None else b.contiguous(), cin, cout, cout_pad, kh, kw,
-                      layout)
+                      layout, w16)
 
 
 GUARD = 8192  # floats of readable slack on both sides of every tensor this module allocates
@@ -153,8 +175,10 @@ def _workspace(device) -> torch.Tensor:
 
 def conv2d(pc: PackedConv, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *, stride: int = 1,
            pad: int = 0, relu_in: bool = False, residual: Optional[torch.Tensor] = None,
-           act: int = ACT_NONE, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out = act(conv(cat([x0, x1], 1)) + bias + residual); batch-1 operands broadcast."""
+           act: int = ACT_NONE, out: Optional[torch.Tensor] = None, amp: bool = False) -> torch.Tensor:
+    """out = act(conv(cat([x0, x1], 1)) + bias + residual); batch-1 operands broadcast.
+    amp: fp16 operands (inputs rounded while they are staged, `pc.weight_f16`) with fp32 accumulation where the fp16
+    kernels take the shape, exact fp32 otherwise (include/deva_hip.h: deva_conv_desc.amp)."""
     c0 = x0.shape[1]
     c1 = 0 if x1 is None else x1.shape[1]
     if c0 + c1 != pc.cin:
@@ -199,6 +223,10 @@ def conv2d(pc: PackedConv, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, 
     d.in_guard_elems = min(_guard_elems(x0), _guard_elems(x1), (1 << 31) - 1)
     ws = _workspace(out.device)
     d.workspace, d.workspace_elems = ws.data_ptr(), ws.numel()
+    if amp and pc.weight_f16 is not None:
+        d.weight_f16, d.amp = _p(pc.weight_f16, torch.float16, 'fp16 weight'), 1
+    else:
+        d.weight_f16, d.amp = None, 0
     check(lib().deva_conv2d(d, _stream()), 'deva_conv2d')
     return out
 

@@ -14,7 +14,8 @@ _FLAGS = (
     ('model', str, './saves/DEVA-propagation.pth', 'checkpoint with the 420 propagation tensors'),
     ('output', str, None, 'where the driver writes its results'),
     ('save_all', None, False, 'Save all frames'),
-    ('amp', None, False, 'accepted for compatibility; the HIP path always computes in fp32'),
+    ('amp', None, False, 'fp16 operands / fp32 accumulation in the value encoder and the mask decoder (key encoder and '
+                         'memory read stay fp32); off: everything fp32, the parity target'),
     # network widths (C^k, C^v, pixel feature)
     ('key_dim', int, 64, None),
     ('value_dim', int, 512, None),
@@ -47,11 +48,6 @@ def get_model_and_config(parser: ArgumentParser) -> Tuple['torch.nn.Module', Dic
     """-> (network on the current HIP device in eval mode, config dict, parsed args)"""
     from deva.model.network import DEVA
     args = parser.parse_args()
-    if args.amp:
-        import warnings
-        # the reference's --amp wraps the frame loop in fp16 autocast (evaluation/eval_vos.py:137); this path has one
-        # arithmetic, fp32, which is also the parity target -- say so once instead of silently ignoring the flag
-        warnings.warn('--amp is accepted for compatibility and ignored: the HIP path computes in fp32', UserWarning)
     config = dict(vars(args), enable_long_term=not args.disable_long_term)
     network = DEVA(config).cuda().eval()
     if args.model is None:

@@ -105,17 +105,24 @@ def build_parameter_tree(pix_feat_dim: int, key_dim: int, value_dim: int) -> Dic
 class CompiledGraph:
     """Packed weights + the launch sequences of the four stages (all tensors fp32 NCHW on HIP)."""
 
-    def __init__(self, sd: Dict[str, torch.Tensor], device: torch.device):
+    # modules whose convolutions take fp16 operands under --amp: the value encoder and the mask decoder.  The key
+    # encoder and the key projection stay exact fp32 (the memory read's top-k stays bit-faithful), and so do the
+    # reference's own fp32 islands (network.py:34 aggregate, big_modules.py:189 pred: a single-channel VALU kernel here)
+    AMP_SCOPES = ('mask_encoder.', 'mask_decoder.')
+
+    def __init__(self, sd: Dict[str, torch.Tensor], device: torch.device, amp: bool = False):
         ops.require_hip(device, 'DEVA network')
         self.device = device
         self.sd = sd
+        self.amp = bool(amp)
         self.convs: Dict[str, PackedConv] = {}
         self.vecs: Dict[str, torch.Tensor] = {}
         for name in sd:
             if not name.endswith('.weight') or sd[name].dim() != 4:
                 continue
             base = name[:-len('.weight')]
-            self.convs[base] = ops.pack_conv(sd[name], sd.get(base + '.bias'), self._bn_after(base), device)
+            self.convs[base] = ops.pack_conv(sd[name], sd.get(base + '.bias'), self._bn_after(base), device,
+                                             amp=self._amp_of(base))
         for name, t in sd.items():
             if '.ChannelGate.mlp.' in name:
                 self.vecs[name] = t.detach().float().contiguous().to(device)
@@ -139,6 +146,9 @@ class CompiledGraph:
             torch.cat([w1, w2], 0), torch.cat([sd['pixel_encoder.proj1.bias'], sd['pixel_encoder.proj2.bias']], 0), None,
             device)
 
+    def _amp_of(self, base: str) -> bool:
+        return self.amp and base.startswith(self.AMP_SCOPES)
+
     def _split_pack(self, base: str, cx: int) -> Tuple[PackedConv, PackedConv]:
         """(image part without bias, per-object part with the bias) of convolution `base`, BatchNorm folded"""
         w = self.sd[base + '.weight'].detach().float()
@@ -151,17 +161,22 @@ class CompiledGraph:
             shift = beta - mean * scale
             w = w * scale.view(-1, 1, 1, 1)
             b = shift if b is None else b * scale + shift
-        return (ops.pack_conv(w[:, :cx].contiguous(), None, None, self.device),
-                ops.pack_conv(w[:, cx:].contiguous(), b, None, self.device))
+        return (ops.pack_conv(w[:, :cx].contiguous(), None, None, self.device, amp=self._amp_of(base)),
+                ops.pack_conv(w[:, cx:].contiguous(), b, None, self.device, amp=self._amp_of(base)))
+
+    def _conv(self, base: str, *inputs, **kw):
+        """convolution `base` of the value encoder / mask decoder: fp16 operands under --amp where eligible"""
+        return ops.conv2d(self.convs[base], *inputs, amp=self._amp_of(base), **kw)
 
     def _conv_shared_x(self, base: str, x, g, **kw):
         """conv over the virtual cat(x broadcast, g): one launch for a single object, otherwise the image
         part once + the per-object part with it as the fused residual"""
+        amp = self._amp_of(base)
         if g.shape[0] < 2 or x.shape[0] != 1 or base not in self.split:
-            return ops.conv2d(self.convs[base], x, g, **kw)
+            return ops.conv2d(self.convs[base], x, g, amp=amp, **kw)
         wx, wg = self.split[base]
-        shared = ops.conv2d(wx, x, **kw)
-        return ops.conv2d(wg, g, residual=shared, **kw)
+        shared = ops.conv2d(wx, x, amp=amp, **kw)
+        return ops.conv2d(wg, g, residual=shared, amp=amp, **kw)
 
     def _bn_after(self, conv: str):
         """the BatchNorm that follows `conv` in the ResNets: convN -> bnN, downsample.0 -> downsample.1"""
@@ -178,18 +193,18 @@ class CompiledGraph:
     # ---------------------------------------------------------------- building blocks
     def _bottleneck(self, pre: str, x, stride: int):
         c = self.convs
-        y = ops.conv2d(c[pre + '.conv1'], x, act=ACT_RELU)
-        y = ops.conv2d(c[pre + '.conv2'], y, stride=stride, pad=1, act=ACT_RELU)
+        y = self._conv(pre + '.conv1', x, act=ACT_RELU)
+        y = self._conv(pre + '.conv2', y, stride=stride, pad=1, act=ACT_RELU)
         if (pre + '.downsample.0') in c:
-            x = ops.conv2d(c[pre + '.downsample.0'], x, stride=stride)
-        return ops.conv2d(c[pre + '.conv3'], y, residual=x, act=ACT_RELU)
+            x = self._conv(pre + '.downsample.0', x, stride=stride)
+        return self._conv(pre + '.conv3', y, residual=x, act=ACT_RELU)
 
     def _basic(self, pre: str, x, stride: int):
         c = self.convs
-        y = ops.conv2d(c[pre + '.conv1'], x, stride=stride, pad=1, act=ACT_RELU)
+        y = self._conv(pre + '.conv1', x, stride=stride, pad=1, act=ACT_RELU)
         if (pre + '.downsample.0') in c:
-            x = ops.conv2d(c[pre + '.downsample.0'], x, stride=stride)
-        return ops.conv2d(c[pre + '.conv2'], y, pad=1, residual=x, act=ACT_RELU)
+            x = self._conv(pre + '.downsample.0', x, stride=stride)
+        return self._conv(pre + '.conv2', y, pad=1, residual=x, act=ACT_RELU)
 
     def _stage(self, pre: str, x, blocks: int, stride: int, block_fn):
         for i in range(blocks):
@@ -203,9 +218,9 @@ class CompiledGraph:
             t = self._conv_shared_x(pre + '.conv1', g0, g1, pad=1, relu_in=True)
             skip = self._conv_shared_x(pre + '.downsample', g0, g1)
         else:
-            t = ops.conv2d(c[pre + '.conv1'], g0, pad=1, relu_in=True)
-            skip = ops.conv2d(c[pre + '.downsample'], g0) if (pre + '.downsample') in c else g0
-        return ops.conv2d(c[pre + '.conv2'], t, pad=1, relu_in=True, residual=skip)
+            t = self._conv(pre + '.conv1', g0, pad=1, relu_in=True)
+            skip = self._conv(pre + '.downsample', g0) if (pre + '.downsample') in c else g0
+        return self._conv(pre + '.conv2', t, pad=1, relu_in=True, residual=skip)
 
     def _fusion(self, pre: str, x, g):
         """x [1,Cx,h,w] image feature (broadcast over objects), g [no,Cg,h,w]"""
@@ -216,25 +231,25 @@ class CompiledGraph:
         return self._res_block(pre + '.block2', g)
 
     def _gru(self, conv: str, g, h):
-        return ops.gru_update(ops.conv2d(self.convs[conv], g, h, pad=1), h)
+        return ops.gru_update(self._conv(conv, g, h, pad=1), h)
 
     # ---------------------------------------------------------------- stages
     def encode_image(self, image):
         c = self.convs
         pe = 'pixel_encoder'
-        x = ops.conv2d(c[pe + '.conv1'], image, stride=2, pad=3, act=ACT_RELU)
+        x = self._conv(pe + '.conv1', image, stride=2, pad=3, act=ACT_RELU)
         x = ops.maxpool3x3s2(x)
         f4 = self._stage(pe + '.res2', x, 3, 1, self._bottleneck)
         f8 = self._stage(pe + '.layer2', f4, 4, 2, self._bottleneck)
         f16 = self._stage(pe + '.layer3', f8, 6, 2, self._bottleneck)
-        both = ops.conv2d(c[pe + '.proj12'], f16)  # batch 1: the two channel ranges are contiguous tensors
+        both = self._conv(pe + '.proj12', f16)  # batch 1: the two channel ranges are contiguous tensors
         return (both[:, :self.proj_split], f8, f4), both[:, self.proj_split:]
 
     def transform_key(self, feat, need_s: bool, need_e: bool):
         c = self.convs
-        shrinkage = ops.conv2d(c['key_proj.d_proj'], feat, pad=1, act=ACT_SQUARE_PLUS_ONE) if need_s else None
-        selection = ops.conv2d(c['key_proj.e_proj'], feat, pad=1, act=ACT_SIGMOID) if need_e else None
-        return ops.conv2d(c['key_proj.key_proj'], feat, pad=1), shrinkage, selection
+        shrinkage = self._conv('key_proj.d_proj', feat, pad=1, act=ACT_SQUARE_PLUS_ONE) if need_s else None
+        selection = self._conv('key_proj.e_proj', feat, pad=1, act=ACT_SIGMOID) if need_e else None
+        return self._conv('key_proj.key_proj', feat, pad=1), shrinkage, selection
 
     def encode_mask(self, image, f16, sensory, masks, deep_update: bool):
         """image [1,3,H,W]; masks [no,1,H,W]; sensory [no,C,h,w] -> value [no,C,h,w], sensory'"""
@@ -256,22 +271,22 @@ class CompiledGraph:
         c = self.convs
         md = 'mask_decoder'
         f16, f8, f4 = ms_features
-        d8 = ops.conv2d(c[md + '.decoder_feat_proc.transforms.0'], f8)
-        d4 = ops.conv2d(c[md + '.decoder_feat_proc.transforms.1'], f4)
-        p16 = ops.conv2d(c[md + '.sensory_compress'], sensory, last_mask16, residual=readout)
+        d8 = self._conv(md + '.decoder_feat_proc.transforms.0', f8)
+        d4 = self._conv(md + '.decoder_feat_proc.transforms.1', f4)
+        p16 = self._conv(md + '.sensory_compress', sensory, last_mask16, residual=readout)
         p16 = self._fusion(md + '.fuser', f16, p16)
         p8 = self._res_block(md + '.up_16_8.out_conv', ops.upsample2x_add(p16, d8))
         p4 = self._res_block(md + '.up_8_4.out_conv', ops.upsample2x_add(p8, d4))
-        logits = ops.conv2d(c[md + '.pred'], p4, pad=1, relu_in=True)
+        logits = self._conv(md + '.pred', p4, pad=1, relu_in=True)
         return p16, p8, p4, logits
 
     def sensory_update(self, p16, p8, p4, logits, sensory):
         """the decoder's GRU update of the sensory memory (modules.py:121-151): needed by the NEXT frame only"""
         c = self.convs
         su = 'mask_decoder.sensory_update'
-        g = ops.conv2d(c[su + '.g16_conv'], p16)
-        g = ops.conv2d(c[su + '.g8_conv'], ops.area_downsample(p8, 2), residual=g)
-        g = ops.conv2d(c[su + '.g4_conv'], ops.area_downsample(p4, 4), ops.area_downsample(logits, 4), residual=g)
+        g = self._conv(su + '.g16_conv', p16)
+        g = self._conv(su + '.g8_conv', ops.area_downsample(p8, 2), residual=g)
+        g = self._conv(su + '.g4_conv', ops.area_downsample(p4, 4), ops.area_downsample(logits, 4), residual=g)
         return self._gru(su + '.transform', g, sensory)
 
     def decode(self, ms_features, readout, sensory, last_mask16, update_sensory: bool):

@@ -21,6 +21,10 @@ class DEVA(nn.Module):
         self.pix_feat_dim = config['pix_feat_dim']
         self.key_dim = config['key_dim']
         self.value_dim = config['value_dim']
+        # --amp (eval_args.py:17; the reference's drivers wrap the frame loop in fp16 autocast, eval_vos.py:137): the
+        # value encoder and the mask decoder run their convolutions on fp16 operands with fp32 accumulation; key encoder,
+        # key projection, memory read, aggregate and the mask-logit head stay fp32 (deva/model/_graph.py:AMP_SCOPES)
+        self.amp = bool(config.get('amp', False))
         for name, module in build_parameter_tree(self.pix_feat_dim, self.key_dim, self.value_dim).items():
             self.add_module(name, module)
         for p in self.parameters():
@@ -44,7 +48,7 @@ class DEVA(nn.Module):
     def graph(self) -> CompiledGraph:
         if self._graph is None:
             device = next(self.parameters()).device
-            self._graph = CompiledGraph(self.state_dict(), device)
+            self._graph = CompiledGraph(self.state_dict(), device, amp=self.amp)
         return self._graph
 
     # ------------------------------------------------------------------ reference API
