@@ -74,11 +74,40 @@ def conv_source_sha1():
     import hashlib
     h = hashlib.sha1()
     d = os.path.join(ROOT, 'tracking-anything-with-deva_amd', 'csrc')
-    for name in ('conv_args.h', 'conv_igemm.hip', 'conv_mfma.hip', 'conv_cout1.hip', 'common.h'):
+    for name in ('conv_args.h', 'conv_epilogue.h', 'conv_igemm.hip', 'conv_mfma.hip', 'conv_cout1.hip', 'common.h'):
         with open(os.path.join(d, name), 'rb') as f:
             h.update(f.read())
     return h.hexdigest()
 PEAK_HBM_GBPS = 8000.0
+
+
+def mfma_probe(device, iters=6000, reps=4):
+    """what the fp32 matrix pipes sustain on THIS box (include/deva_hip.h: deva_probe_mfma_f32): a register-only
+    v_mfma_f32_32x32x2_f32 loop, 4 waves per SIMD on every CU, timed with events after a warm-up; random operands (the
+    switching activity of real data) and zeros.  The chip clocks to its power budget under dense MFMA work
+    (MI355X_MICROARCH.md, DVFS give-back), so this -- not the data-sheet 157.3 -- is what a perfect kernel reaches."""
+    from deva.hip import lib
+    L = lib()
+    out = {}
+    sink = torch.empty(1 << 16, device=device)
+    for name, ops_ in (('random_operands', torch.rand(1 << 16, device=device) * 2 - 1), ('zero_operands', torch.zeros(1 << 16, device=device))):
+        st = torch.cuda.current_stream().cuda_stream
+        flop = 0
+        for _ in range(3):  # ~40 ms of warm-up: the clock settles within milliseconds
+            flop = L.deva_probe_mfma_f32(ops_.data_ptr(), ops_.numel(), sink.data_ptr(), iters, st)
+        if flop <= 0:
+            raise RuntimeError('deva_probe_mfma_f32 failed')
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            L.deva_probe_mfma_f32(ops_.data_ptr(), ops_.numel(), sink.data_ptr(), iters, st)
+        b.record()
+        torch.cuda.synchronize()
+        out[name + '_tflops'] = flop * reps / (a.elapsed_time(b) * 1e-3) / 1e12
+    out['frac_of_peak'] = out['random_operands_tflops'] / PEAK_FP32_MATRIX_TFLOPS
+    out['method'] = (f'deva_probe_mfma_f32: {reps} launches of {iters} x 16 back-to-back v_mfma_f32_32x32x2_f32 per wave, 4 waves per '
+                     'SIMD, no memory traffic in the loop, events on the launch stream after 3 warm-up launches')
+    return out
 
 
 def build_network(device, amp=False):
@@ -906,6 +935,13 @@ def main():
             'ms_per_frame_of_the_instrumented_replay': replay_ms,
             'algorithmic_bytes_per_frame': alg_bytes / n_replay,
         }
+        try:
+            probe = mfma_probe(device)
+            result['roofline']['sustained_mfma_probe'] = probe
+            result['roofline']['frac_of_sustained_probe'] = ach / probe['random_operands_tflops']
+        except Exception as exc:  # noqa: BLE001
+            result['roofline']['sustained_mfma_probe'] = {'error': f'{type(exc).__name__}: {exc}'[:300]}
+            torch.cuda.synchronize()
         # HBM traffic of these kernels per frame, from the committed rocprofv3 --pmc passes over this same
         # command (tools/pmc_bench.sh; FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes)
         for pmc_dir in ('pmc_r04', 'pmc_r03'):

@@ -27,10 +27,17 @@
 extern "C" {
 #endif
 
-#define DEVA_HIP_ABI_VERSION 5
+#define DEVA_HIP_ABI_VERSION 6
 
 int deva_hip_version(void);
 const char* deva_hip_last_error(void);
+
+/* Diagnostic (no counterpart in the reference): one launch of a register-only v_mfma_f32_32x32x2_f32 loop, 4 waves per
+ * SIMD on every CU, `iters` x 16 MFMAs per wave.  Returns the flop of the launch (< 0 on error); the caller times it
+ * with events on `stream`.  bench.py reports the rate beside the convolution roofline: under dense MFMA work the chip
+ * clocks to its power budget, so the sustained rate sits below the data-sheet 157.3 TFLOP/s.  `operands`: >= 1024
+ * floats (their values set the switching activity: random vs zeros), `sink`: as many writable floats. */
+int64_t deva_probe_mfma_f32(const float* operands, int64_t operand_elems, float* sink, int iters, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Convolution as implicit GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32), fused prologue/epilogue.

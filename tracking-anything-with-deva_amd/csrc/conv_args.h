@@ -48,6 +48,7 @@ struct ConvArgs {
   float* out;
   int vec_ok;        // inputs are guard-banded + 'same' stride-1 geometry: 4-pixel vector gathers allowed
   int tiles_n, tiles_m;
+  int group_m;       // cout tiles per tile-order group (conv_epilogue.h: conv_tile_coords); <= 0: all of them
   int64_t ws_elems;
   int splits;        // split-K factor (gridDim.y); > 1 writes raw partial sums to ws
   int per_split;     // K steps per split
@@ -55,6 +56,18 @@ struct ConvArgs {
   int64_t in0_span, in1_span;  // elements from the first to one past the last element of each input
   const void* w16;   // conv_f16.hip: fp16 weights (DEVA_KLAYOUT_H8) or null
 };
+
+// cout tiles per tile-order group (conv_epilogue.h: conv_tile_coords).  With C workgroups of an XCD (resident at a time,
+// ~48, or all the XCD ever gets on a small grid) covering g cout tiles x C/g pixel tiles, that XCD's L2 pulls g weight
+// tiles + C/g activation tiles; a weight tile is taps * BM / (BN * stride^2) times the bytes of an activation tile, so
+// g ~ sqrt(C / that ratio).
+inline int conv_group_m(int taps, int stride, int bm, int bn, int64_t tiles) {
+  const float ratio = (float)taps * bm / ((float)bn * stride * stride);
+  const float c = (float)(tiles >= 8 * 48 ? 48 : (tiles + 7) / 8);
+  int g = 1;
+  while ((g + 1) * (g + 1) * ratio <= c * 1.5f) ++g;  // largest g with g^2 <= 1.5 C / ratio
+  return g;
+}
 
 // conv_igemm.hip: out = act(sum_s ws[s] + bias + residual) for a split-K launch (p.splits > 1)
 int launch_splitk_reduce(const ConvArgs& p, hipStream_t st);

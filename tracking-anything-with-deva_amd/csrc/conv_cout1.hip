@@ -105,7 +105,15 @@ __global__ __launch_bounds__(256) void conv3x3_cout1_rows_kernel(const Cout1Args
   const int lane = threadIdx.x & 63;
   const int cg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // channel group = wave
   const int strips = p.n_total >> 2;
-  const int sidx = blockIdx.x * 64 + lane;
+  // workgroup b runs on XCD b % 8: give every XCD a contiguous range of rows, so that the three workgroups that read
+  // an input row (as their row above / own row / row below) meet in one L2 (measured: L2 fills 366 -> ~1.3x input MB)
+  int blk;
+  {
+    const int nb = gridDim.x, bi = blockIdx.x;
+    const int q = nb >> 3, r = nb & 7, xcd = bi & 7;
+    blk = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bi >> 3);
+  }
+  const int sidx = blk * 64 + lane;
   const bool s_ok = sidx < strips;
   const int n = (s_ok ? sidx : 0) * 4;
   const int b = n / p.OHW;

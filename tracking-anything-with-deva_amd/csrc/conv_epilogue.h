@@ -9,12 +9,24 @@ namespace deva {
 
 typedef float conv_f32x16 __attribute__((ext_vector_type(16)));
 
-// logical tile of workgroup b: cout tiles fastest, XCD x gets a contiguous range of logical tiles (workgroup b runs on
-// XCD b % 8), so the workgroups sharing one pixel tile and neighbouring pixel tiles meet in one L2
-__device__ __forceinline__ int conv_logical_tile() {
+// Workgroup b -> (cout tile, pixel tile).  Workgroup b runs on XCD b % 8; XCD x gets a contiguous range of LOGICAL tiles,
+// and logical tiles are ordered in groups of `group_m` cout tiles, cout fastest inside a group, pixel tiles next, groups
+// last.  The ~32-64 workgroups resident on one XCD then cover group_m cout tiles x ~(32..64)/group_m neighbouring pixel
+// tiles, and that rectangle is what streams through the XCD's 4 MB L2 per K step: group_m weight tiles + the pixel tiles'
+// activations.  A 3x3 weight tile is ~9x the bytes of a pixel tile's activations, so few cout tiles per group there
+// (measured on the 1024->1536 GRU convolution: L2 fills 1.36 GB -> see profiles/r04b), all cout tiles for 1x1.
+__device__ __forceinline__ void conv_tile_coords(const ConvArgs& p, int& tile_m, int& tile_n) {
   const int nb = gridDim.x, b = blockIdx.x;
   const int q = nb >> 3, r = nb & 7, xcd = b & 7;
-  return ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  const int logical = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  const int g = (p.group_m > 0 && p.group_m < p.tiles_m) ? p.group_m : p.tiles_m;
+  const int per_group = g * p.tiles_n;
+  const int grp = logical / per_group;
+  const int in_grp = logical - grp * per_group;
+  const int m_first = grp * g;
+  const int gsz = min(g, p.tiles_m - m_first);
+  tile_n = in_grp / gsz;
+  tile_m = m_first + (in_grp - tile_n * gsz);
 }
 
 template <int TM, int TN>

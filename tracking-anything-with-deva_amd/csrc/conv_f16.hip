@@ -67,9 +67,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
   const int l31 = lane & 31;
   const int half = lane >> 5;
 
-  const int logical = conv_logical_tile();
-  const int tile_n = logical / p.tiles_m;
-  const int tile_m = logical - tile_n * p.tiles_m;
+  int tile_m, tile_n;
+  conv_tile_coords(p, tile_m, tile_n);
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
 
@@ -315,6 +314,7 @@ int launch_tile_f16(const ConvArgs& a, int kind, hipStream_t st) {
   p.per_split = ksteps_total;
   p.splits = 1;
   const int64_t blocks = (int64_t)p.tiles_m * p.tiles_n;
+  p.group_m = conv_group_m(a.KH * a.KW, a.stride, BM, BN, blocks);
   if (a.ws && blocks < 192 && ksteps_total >= 12) {  // few tiles, long K: deterministic split-K like the fp32 kernels
     int64_t sp = ceil_div(512, blocks);
     if (sp > ksteps_total / 6) sp = ksteps_total / 6;

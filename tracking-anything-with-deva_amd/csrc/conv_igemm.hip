@@ -698,6 +698,7 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
   a.out = d->out;
   a.tiles_n = 0;
   a.tiles_m = 0;
+  a.group_m = 0;
   // 4-pixel vector gathers: stride-1 'same' geometry, quads never straddle images, and the caller
   // vouches for readable guard bands around both inputs
   a.vec_ok = (d->stride == 1 && a.OH == a.H && a.OW == a.W && a.OHW % 4 == 0 && a.OW >= 4 &&

@@ -69,8 +69,13 @@ __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, int voff, i
 // sums meet in LDS in a fixed order (k = 1, 2, ...) before group 0 runs the epilogue.  For layers with few output
 // tiles (batch-1 key encoder at 30x54) this is the split-K that fills the SIMDs without partial sums in HBM and
 // without a reduction launch.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int KIND, int MINW, int WK>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KIND, int MINW, int WK, int RELU>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (KIND <= 1 || MINW < 2) ? MINW : 2) void conv_mfma_kernel(const ConvArgs p) {
+  // RELU: 0 = the input is taken as it is, 2 = ReLU on every input element, 1 = p.relu_in decides at run time (one
+  // VALU instruction per loaded element either way).  The 3x3 row kind is built as 0 and 2 (36 of the 97 VALU
+  // instructions of its loop; worth 0.3-0.7 % on the GRU / fuser layers, tools/convlab --rounds 7); the 1x1 kind keeps
+  // the run-time flag -- its loop came out 4 % slower without the instruction (register allocation).
+  const bool relu_in = RELU == 2 ? true : (RELU == 1 ? (p.relu_in != 0) : false);
   // (the scalar-gather kinds carry 64-bit pointers and per-element validity: two waves per SIMD, no spills)
   constexpr int THREADS = 64 * WAVES_M * WAVES_N;  // threads of one K-slice group
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -119,9 +124,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (KIND <= 1 || MINW < 2
     __syncthreads();
   }
 
-  const int logical = conv_logical_tile();
-  const int tile_n = logical / p.tiles_m;
-  const int tile_m = logical - tile_n * p.tiles_m;
+  int tile_m, tile_n;
+  conv_tile_coords(p, tile_m, tile_n);
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
 
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (KIND <= 1 || MINW < 2
     for (int i = 0; i < A_V4; ++i) *reinterpret_cast<f32x4*>(a + i * THREADS * 4) = ra[SET][i];
     if (KIND == 0) {
       f32x4* rv = rbv[ROW ? 0 : SET];
-      if (p.relu_in) {
+      if (relu_in) {
 #pragma unroll
         for (int i = 0; i < B_V4; ++i) relu4(rv[i]);
       }
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (KIND <= 1 || MINW < 2
     } else if (KIND == 1) {
       if (WITH_ROWS) {
         float* bt = sB + GB * B_FLOATS;
-        if (p.relu_in) {
+        if (relu_in) {
 #pragma unroll
           for (int i = 0; i < B_V4; ++i) relu4(rbv[0][i]);
           rh = __builtin_amdgcn_fmed3f(rh, 0.0f, __builtin_inff());
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (KIND <= 1 || MINW < 2
       for (int i = 0; i < B_PT; ++i) {
         const int r = bk_group + i * KG;
         float v = rb[i];
-        if (p.relu_in) v = __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff());
+        if (relu_in) v = __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff());
         b[(r >> 1) * BNP * 2 + (r & 1)] = (ok_b & (1u << i)) ? v : 0.0f;
       }
     }
@@ -550,6 +554,7 @@ int launch_tile_q4(const ConvArgs& a, hipStream_t st) {
   p.per_split = ksteps_total;
   const int blocks_eff_scale = WK;  // every workgroup already holds WK slice groups
   const int64_t blocks = (int64_t)p.tiles_m * p.tiles_n;
+  p.group_m = conv_group_m(a.KH * a.KW, a.stride, BM, BN, blocks);
   p.splits = 1;
   int64_t target_blocks = 512;
   // measured (tools/convlab sweep, profiles/r04a): from ~190 tiles up the split (+ its reduction pass) loses
@@ -560,6 +565,11 @@ int launch_tile_q4(const ConvArgs& a, hipStream_t st) {
       const char* e = getenv("DEVA_CONV_SPLIT_TARGET");  // blocks to aim for; 0 = no split-K at all
       return e ? atoi(e) : -1;
     }();
+    static const int forced_group = [] {
+      const char* e = getenv("DEVA_CONV_GROUP_M");  // cout tiles per tile-order group; 0 = all
+      return e ? atoi(e) : -1;
+    }();
+    if (forced_group >= 0) p.group_m = forced_group;
     if (forced == 0) want_split = false;
     if (forced > 0) {
       target_blocks = forced;
@@ -587,15 +597,18 @@ int launch_tile_q4(const ConvArgs& a, hipStream_t st) {
     if (kind >= 2) return launch_tile_q4<BM, BN, WAVES_M, WAVES_N, MINW, 1>(a, st);  // scalar kinds: no K-slice build at 1024 threads
   }
   switch (kind) {
-    case 0: hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, 0, MINW, WK>), grid, block, 0, st, p); break;
+    case 0: hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, 0, MINW, WK, 1>), grid, block, 0, st, p); break;
     case 1:
-      if constexpr (BN / WAVES_N == 32) hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, 1, MINW, WK>), grid, block, 0, st, p);
+      if constexpr (BN / WAVES_N == 32) {
+        if (p.relu_in) hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, 1, MINW, WK, 2>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, 1, MINW, WK, 0>), grid, block, 0, st, p);
+      }
       break;
     case 2:
-      if constexpr (!(BM == 128 && WK > 1)) hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, 2, MINW, WK>), grid, block, 0, st, p);
+      if constexpr (!(BM == 128 && WK > 1)) hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, 2, MINW, WK, 1>), grid, block, 0, st, p);
       break;
     default:
-      if constexpr (!(BM == 128 && WK > 1)) hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, 3, MINW, WK>), grid, block, 0, st, p);
+      if constexpr (!(BM == 128 && WK > 1)) hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, 3, MINW, WK, 1>), grid, block, 0, st, p);
       break;
   }
   if (p.splits > 1) return launch_splitk_reduce(p, st);

@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdeva_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQUARE_PLUS_ONE = 0, 1, 2, 3
 KLAYOUT_TAP_MAJOR, KLAYOUT_CHUNK32 = 0, 1
@@ -71,6 +71,7 @@ SIGNATURES = {
     'deva_affinity_read_scratch': (c_int64, [c_int, c_int, c_int]),
     'deva_affinity_prefilter_enabled': (c_int, [c_int, c_int, c_int]),
     'deva_affinity_force_prefilter': (c_int, [c_int]),
+    'deva_probe_mfma_f32': (c_int64, [c_void_p, c_int64, c_void_p, c_int, c_void_p]),
     'deva_affinity_read_flag': (c_int, [c_void_p, c_void_p]),
     'deva_affinity_read_stats': (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_int64), c_void_p]),
     'deva_affinity_merge': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -175,8 +175,9 @@ class CompiledGraph:
         if g.shape[0] < 2 or x.shape[0] != 1 or base not in self.split:
             return ops.conv2d(self.convs[base], x, g, amp=amp, **kw)
         wx, wg = self.split[base]
+        act = kw.pop('act', 0)  # the activation belongs to the sum of the two parts
         shared = ops.conv2d(wx, x, amp=amp, **kw)
-        return ops.conv2d(wg, g, residual=shared, amp=amp, **kw)
+        return ops.conv2d(wg, g, residual=shared, amp=amp, act=act, **kw)
 
     def _bn_after(self, conv: str):
         """the BatchNorm that follows `conv` in the ResNets: convN -> bnN, downsample.0 -> downsample.1"""
@@ -212,15 +213,16 @@ class CompiledGraph:
         return x
 
     def _res_block(self, pre: str, g0, g1=None):
-        """relu -> 3x3 -> relu -> 3x3, plus (1x1-projected) input; input = virtual cat(g0, g1)"""
+        """relu -> 3x3 -> relu -> 3x3, plus (1x1-projected) input; input = virtual cat(g0, g1).  The inner ReLU is
+        conv1's output stage (its result feeds conv2 only), so conv2 reads its input as it is."""
         c = self.convs
         if g1 is not None:
-            t = self._conv_shared_x(pre + '.conv1', g0, g1, pad=1, relu_in=True)
+            t = self._conv_shared_x(pre + '.conv1', g0, g1, pad=1, relu_in=True, act=ACT_RELU)
             skip = self._conv_shared_x(pre + '.downsample', g0, g1)
         else:
-            t = self._conv(pre + '.conv1', g0, pad=1, relu_in=True)
+            t = self._conv(pre + '.conv1', g0, pad=1, relu_in=True, act=ACT_RELU)
             skip = self._conv(pre + '.downsample', g0) if (pre + '.downsample') in c else g0
-        return self._conv(pre + '.conv2', t, pad=1, relu_in=True, residual=skip)
+        return self._conv(pre + '.conv2', t, pad=1, residual=skip)
 
     def _fusion(self, pre: str, x, g):
         """x [1,Cx,h,w] image feature (broadcast over objects), g [no,Cg,h,w]"""
