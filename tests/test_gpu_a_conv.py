@@ -48,6 +48,15 @@ CASES += [
 ]
 
 
+# the output stage through LDS (conv_epilogue.h: conv_store_tile_vec; rows of 4k pixels, aligned tensors): ragged cout,
+# pixel counts that end inside a tile, broadcast / per-image residual, every activation
+CASES += [
+    ('vecout_cout72_bcast_sigmoid', 64, 0, 72, 1, 1, 0, 3, 6, 10, False, False, 'bcast', ops.ACT_SIGMOID, True, False),
+    ('vecout_cout200_res_relu', 128, 0, 200, 3, 1, 1, 2, 20, 36, False, True, 'full', ops.ACT_RELU, True, False),
+    ('vecout_cout136_sq1', 96, 32, 136, 3, 1, 1, 1, 34, 44, True, False, 'none', ops.ACT_SQUARE_PLUS_ONE, True, False),
+]
+
+
 # single output channel on a large guard-banded map: the row-reusing VALU kernel (conv_cout1.hip); the
 # unguarded variants of the same cases run on the MFMA tile
 CASES += [

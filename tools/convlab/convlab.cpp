@@ -158,7 +158,7 @@ int main(int argc, char** argv) {
   }
   std::vector<Layer> layers(std::begin(kLayers), std::end(kLayers));
   static std::vector<std::string> custom_names;
-  if (!shapes.empty()) {  // --shapes "c0,c1,cout,k,stride,batch,oh,ow,relu,res,act;..."
+  if (!shapes.empty()) {  // --shapes "c0,c1,cout,k,stride,batch,oh,ow,relu,res,act[,calls];..."
     layers.clear();
     custom_names.reserve(64);
     for (size_t p = 0; p < shapes.size();) {
@@ -166,10 +166,11 @@ int main(int argc, char** argv) {
       if (q == std::string::npos) q = shapes.size();
       const std::string one = shapes.substr(p, q - p);
       int v[11] = {0};
-      if (sscanf(one.c_str(), "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7, v + 8, v + 9,
-                 v + 10) >= 8) {
+      float calls = 1.0f;  // optional 12th field: calls per frame
+      if (sscanf(one.c_str(), "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%f", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7, v + 8, v + 9,
+                 v + 10, &calls) >= 8) {
         custom_names.push_back(one);
-        layers.push_back(Layer{custom_names.back().c_str(), v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], 1.0, 1});
+        layers.push_back(Layer{custom_names.back().c_str(), v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], calls, 1});
       }
       p = q + 1;
     }

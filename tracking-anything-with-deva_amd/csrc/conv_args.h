@@ -47,6 +47,7 @@ struct ConvArgs {
   int act;
   float* out;
   int vec_ok;        // inputs are guard-banded + 'same' stride-1 geometry: 4-pixel vector gathers allowed
+  int vec_out;       // output and residual rows are 16-byte aligned, OHW % 4 == 0: output stage through LDS
   int tiles_n, tiles_m;
   int group_m;       // cout tiles per tile-order group (conv_epilogue.h: conv_tile_coords); <= 0: all of them
   int64_t ws_elems;

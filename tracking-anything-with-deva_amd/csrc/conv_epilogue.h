@@ -29,6 +29,80 @@ __device__ __forceinline__ void conv_tile_coords(const ConvArgs& p, int& tile_m,
   tile_m = m_first + (in_grp - tile_n * gsz);
 }
 
+typedef float conv_f32x4 __attribute__((ext_vector_type(4)));
+
+// Output stage through LDS (p.vec_out: 16-byte aligned rows, OHW % 4 == 0; not for split-K partial sums): a 32x32
+// accumulator block goes to the wave's own 4 KB of LDS as [row][pixel] and comes back as 4 consecutive pixels per lane (8 lanes = one 128-byte row segment),
+// so the residual is read and the result written with 16-byte accesses -- a quarter of the memory instructions of the
+// one-pixel-per-lane form below, same arithmetic in the same order.  `scr`: 1024 floats of LDS nobody else touches
+// (the caller has put a barrier between the last tile reads and this call).
+template <int TM, int TN>
+__device__ __forceinline__ void conv_store_tile_vec(const ConvArgs& p, conv_f32x16 (&acc)[TM][TN], int m0w, int n0w, int lane,
+                                                    float* scr) {
+  const int l31 = lane & 31, half = lane >> 5;
+  const int rrow = lane >> 3, rcol = (lane & 7) * 4;
+  // every residual vector and bias value of the wave's tile first (independent of the accumulators: all in flight at once)
+  conv_f32x4 rv[TM][TN][4];
+  float bv[TM][4];
+  int64_t obase[TN];
+  bool n_ok[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0w + j * 32 + rcol;
+    n_ok[j] = n < p.n_total;
+    const int nn = n_ok[j] ? n : 0;
+    const int b = nn / p.OHW;
+    const int pix = nn - b * p.OHW;
+    obase[j] = (int64_t)b * p.cout * p.OHW + pix;
+    const int64_t rbase = (int64_t)b * p.res_bs + pix;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = m0w + i * 32 + q * 8 + rrow;
+        rv[i][j][q] = (p.res && n_ok[j] && m < p.cout) ? *reinterpret_cast<const conv_f32x4*>(p.res + rbase + (int64_t)m * p.OHW)
+                                                                 : conv_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = m0w + i * 32 + q * 8 + rrow;
+      bv[i][q] = (p.bias && m < p.cout) ? p.bias[m] : 0.0f;
+    }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[i][j][r];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = q * 8 + rrow;
+        const int m = m0w + i * 32 + row;
+        conv_f32x4 v = *reinterpret_cast<const conv_f32x4*>(scr + row * 32 + rcol);
+        if (!n_ok[j] || m >= p.cout) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float x = v[c];
+          if (p.bias) x += bv[i][q];
+          if (p.res) x += rv[i][j][q][c];
+          if (p.act == DEVA_ACT_RELU) {
+            x = fmaxf(x, 0.0f);
+          } else if (p.act == DEVA_ACT_SIGMOID) {
+            x = sigmoidf_(x);
+          } else if (p.act == DEVA_ACT_SQUARE_PLUS_ONE) {
+            x = x * x + 1.0f;
+          }
+          v[c] = x;
+        }
+        *reinterpret_cast<conv_f32x4*>(p.out + obase[j] + (int64_t)m * p.OHW) = v;
+      }
+    }
+  }
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void conv_store_tile(const ConvArgs& p, conv_f32x16 (&acc)[TM][TN], int m0, int wm0, int n0, int wn0,
                                                 int l31, int half) {

@@ -302,6 +302,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
     if (s < ksteps) step(s, I0{}, I0{}, I0{});
   }
 
+  if (p.vec_out && p.splits == 1) {  // (split-K partial sums: the direct stores measured 3-4 % faster on the layers that split)
+    static_assert((THREADS / 64) * 4096 <= (2 * A_HALFS + 2 * B_HALFS) * 2, "one 4 KB output-stage scratch per wave fits the dead tile buffers");
+    __syncthreads();  // every wave is done with the tiles
+    conv_store_tile_vec<TM, TN>(p, acc, m0 + wm0, n0 + wn0, lane, reinterpret_cast<float*>(smem) + wave * 1024);
+    return;
+  }
   conv_store_tile<TM, TN>(p, acc, m0, wm0, n0, wn0, l31, half);
 }
 

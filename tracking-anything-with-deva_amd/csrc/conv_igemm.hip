@@ -699,6 +699,10 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
   a.tiles_n = 0;
   a.tiles_m = 0;
   a.group_m = 0;
+  {
+    const auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    a.vec_out = a.OHW % 4 == 0 && al16(d->out) && (!d->residual || (al16(d->residual) && d->residual_batch_stride % 4 == 0));
+  }
   // 4-pixel vector gathers: stride-1 'same' geometry, quads never straddle images, and the caller
   // vouches for readable guard bands around both inputs
   a.vec_ok = (d->stride == 1 && a.OH == a.H && a.OW == a.W && a.OHW % 4 == 0 && a.OW >= 4 &&
