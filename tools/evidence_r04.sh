@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round-4 evidence on the GPU box (sections: build tests alltests bench trace pmc):  tools/evidence_r04.sh bench trace pmc
+# Round-4 evidence on the GPU box (sections: tests alltests pmc bench trace trace1080):  tools/evidence_r04.sh pmc bench trace
 # Everything lands in gpurun_out/r04/; the summaries are copied into profiles/r04*/ by hand (tracked).
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/r04
 mkdir -p $OUT
-SECTIONS="${@:-bench trace pmc}"
+SECTIONS="${@:-pmc bench trace}"
 has() { [[ " $SECTIONS " == *" $1 "* ]]; }
 python __graft_entry__.py > $OUT/build.log 2>&1; echo "build exit $?"
 CMD="python bench.py --steps 20 --warmup 3 --no_cpu_baseline --no_extra --no_affinity"
@@ -22,6 +22,16 @@ if has alltests; then
   for f in test_gpu_a_conv test_gpu_b_pointwise test_gpu_c_bank test_gpu_d_affinity test_gpu_f_memory_events test_gpu_e_network test_gpu_i_drivers test_gpu_g_fullsize; do
     [ -f tests/$f.py ] && run_test $f ${TEST_TIMEOUT:-1500}
   done
+fi
+if has pmc; then
+  rm -rf gpurun_out/pmc; bash tools/pmc_bench.sh
+  cp gpurun_out/pmc/conv_traffic.json $OUT/conv_traffic.json 2>/dev/null
+  mkdir -p profiles/pmc_r04 && cp gpurun_out/pmc/conv_traffic.json profiles/pmc_r04/conv_traffic.json   # what bench.py reads (same build: sha checked)
+  python - <<'PY'
+import json
+d = json.load(open('gpurun_out/r04/conv_traffic.json'))
+print({k: v for k, v in d.items() if k not in ('per_dispatch_averages',)})
+PY
 fi
 if has bench; then
   DEVA_BENCH_LAYERS=$OUT/conv_layers_480p5.json timeout -k 10 ${BENCH_TIMEOUT:-900} python bench.py ${BENCH_ARGS:---steps 40 --warmup 5} > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"
@@ -46,12 +56,12 @@ if has trace; then
   head -12 $OUT/kernel_stats.md
   find $OUT/trace -name "*.csv" -size +20M -delete   # the raw trace stays on the box
 fi
-if has pmc; then
-  rm -rf gpurun_out/pmc; bash tools/pmc_bench.sh
-  cp gpurun_out/pmc/conv_traffic.json $OUT/conv_traffic.json 2>/dev/null
-  python - <<'PY'
-import json
-d = json.load(open('gpurun_out/r04/conv_traffic.json'))
-print({k: v for k, v in d.items() if k not in ('per_dispatch_averages',)})
-PY
+if has trace1080; then
+  # the 1080p / 1-object frame loop (working memory only): per-layer table + kernel trace
+  rm -rf $OUT/trace1080
+  DEVA_BENCH_LAYERS=$OUT/conv_layers_1080p1.json timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace1080 -o t -- \
+    python bench.py --height 1080 --width 1920 --objects 1 --steps 12 --warmup 3 --no_cpu_baseline --no_extra --no_affinity > $OUT/bench_1080p1.json 2> $OUT/trace1080.log; echo "trace1080 exit $?"
+  python tools/kernel_stats_md.py $OUT/trace1080 "rocprofv3 --kernel-trace -- python bench.py --height 1080 --width 1920 --objects 1 --steps 12 --warmup 3 --no_cpu_baseline --no_extra --no_affinity" "1080p / 1-object loop (working memory only)" $OUT/bench_1080p1.json > $OUT/kernel_stats_1080p1.md
+  head -8 $OUT/kernel_stats_1080p1.md
+  find $OUT/trace1080 -name "*.csv" -size +20M -delete
 fi
