@@ -56,6 +56,13 @@ CASES += [
     ('vecout_cout136_sq1', 96, 32, 136, 3, 1, 1, 1, 34, 44, True, False, 'none', ops.ACT_SQUARE_PLUS_ONE, True, False),
 ]
 
+# the grouped tile order (conv_epilogue.h: conv_tile_coords) with a last group that is not full: 3 cout tiles of 128 in
+# groups of 2 (3x3, 192 tiles), 5 cout tiles of 64 in groups of 3 (1x1, 80 tiles) -- a tile visited twice or never shows
+CASES += [
+    ('tile_groups_3x3_3of2', 32, 0, 384, 3, 1, 1, 2, 64, 64, False, False, 'none', ops.ACT_NONE, True, False),
+    ('tile_groups_1x1_5of3', 64, 0, 320, 1, 1, 0, 1, 32, 32, False, False, 'full', ops.ACT_RELU, True, False),
+]
+
 
 # single output channel on a large guard-banded map: the row-reusing VALU kernel (conv_cout1.hip); the
 # unguarded variants of the same cases run on the MFMA tile

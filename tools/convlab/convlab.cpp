@@ -170,6 +170,7 @@ int main(int argc, char** argv) {
       if (sscanf(one.c_str(), "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%f", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7, v + 8, v + 9,
                  v + 10, &calls) >= 8) {
         custom_names.push_back(one);
+        std::replace(custom_names.back().begin(), custom_names.back().end(), ',', '_');  // (the CSV output is comma-separated)
         layers.push_back(Layer{custom_names.back().c_str(), v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], calls, 1});
       }
       p = q + 1;
