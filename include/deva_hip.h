@@ -238,6 +238,16 @@ int64_t deva_affinity_workspace(int hw, int k, int splits);
 /* splits the library would pick for a bank/query size (>= 1) */
 int deva_affinity_default_splits(int n_total, int hw);
 
+/* The same read for 32 < k <= 64 (eval_args.py:40 leaves --top_k free; the list kernels behind deva_affinity_topk /
+ * deva_affinity_read hand over at most 32 entries per range): ONE kernel, lane = query, the bank streamed through
+ * wave-uniform rows, scores by the same natural-order fp32 FMA chains (bit-identical to the other kernels, hence the same
+ * selection wherever both apply), each query's k best kept in LDS, then exp / normalise / usage like
+ * deva_affinity_finalize.  VALU-bound (~4 ms at 10 000 x 8 160): a correct path for a rare setting.  deva_affinity_read
+ * routes k > 32 here (idx / weight outputs only: no hand-over format, so no token-sharded bank).  Also accepts k <= 32
+ * (tests hold it against the list kernels bit for bit). */
+int deva_affinity_dense(const float* key_long, const float* shr_long, int n_long, const float* key_work,
+                        const float* shr_work, int n_work, const float* qk, const float* qe, int hw, int k,
+                        int32_t* idx, float* weight, uint64_t* usage_fix, void* stream);
 /* The whole read in one call, with the fp16 pre-filter where it pays (banks of >= 4 096 tokens AND >= 8 000 000
  * (token, query) scores: PF_MIN_TOKENS / PF_MIN_SCORES of csrc/affinity.hip; deva_affinity_prefilter_enabled tells):
  *   every (token, query) score is first bounded from both sides with v_mfma_f32_32x32x16_f16 on fp16 copies of the

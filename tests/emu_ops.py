@@ -144,6 +144,8 @@ def affinity_topk(key_long, shr_long, n_long, key_work, shr_work, n_work, qk, qe
     ms = _bank(shr_long, n_long, shr_work, n_work)          # [N]
     if mk.shape[0] < k:
         raise real.DevaHipError('selected index k out of range')
+    if not 1 <= k <= 64:
+        raise real.DevaHipError(f'k={k} unsupported (1..64)')
     a_sq = mk.pow(2) @ qe
     two_ab = 2 * (mk @ (qk * qe))
     b_sq = (qe * qk.pow(2)).sum(0, keepdim=True)
@@ -155,6 +157,10 @@ def affinity_topk(key_long, shr_long, n_long, key_work, shr_work, n_work, qk, qe
     if usage_fix is not None:
         usage_fix.index_add_(0, idx.reshape(-1), (w.reshape(-1).double() * TWO40).long())
     return idx.int(), w
+
+
+def affinity_dense(key_long, shr_long, n_long, key_work, shr_work, n_work, qk, qe, k, usage_fix=None):
+    return affinity_topk(key_long, shr_long, n_long, key_work, shr_work, n_work, qk, qe, k, usage_fix)
 
 
 def usage_update(usage_fix, offset, use, life, n):

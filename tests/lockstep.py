@@ -11,9 +11,9 @@ from oracle import deva_oracle as O
 from workload import synth
 
 
-def run(network, P, H, W, no, frames, device, stage_tol=2e-4, logits_tol=1e-3, prob_tol=1e-3):
+def run(network, P, H, W, no, frames, device, stage_tol=2e-4, logits_tol=1e-3, prob_tol=1e-3, **config):
     from deva.inference.memory_manager import MemoryManager
-    cfg = synth.base_config(mem_every=2)
+    cfg = synth.base_config(**dict({'mem_every': 2}, **config))
     d = device
     stream = synth.FrameStream(H, W, seed=4)
     objs = list(range(1, no + 1))

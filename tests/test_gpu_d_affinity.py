@@ -109,6 +109,49 @@ def test_larger_shapes_against_cpu(n, hw, scale, k):
                 'result depends on the split count'
 
 
+@pytest.mark.parametrize('n,hw,scale,k', [(5000, 1620, 4.0, 48), (2000, 257, 1.0, 64), (80, 40, 1.0, 64), (999, 129, 0.2, 33)])
+def test_top_k_above_32_runs_on_the_dense_kernel(n, hw, scale, k):
+    """eval_args.py:40 leaves --top_k free; 33..64 are served by deva_affinity_dense behind the same entry point"""
+    mk, ms, qk, qe = synth.affinity_inputs(n, hw, seed=n + hw + k, key_scale=scale)
+    from oracle import deva_oracle as O
+    sim = O.get_similarity(mk, ms, qk, qe)
+    base = None
+    for n_long in (0, n // 3):
+        idx, w, usage = _run(mk, ms, qk, qe, k, n_long)
+        assert tuple(idx.shape) == (hw, k)
+        _compare(f'dense n{n}hw{hw}k{k}/long{n_long}', idx, w, usage, sim, k)
+        if base is None:
+            base = (idx, w)
+        else:
+            assert torch.equal(idx, base[0]) and torch.equal(torch.nan_to_num(w, nan=-1.0), torch.nan_to_num(base[1], nan=-1.0)), \
+                'result depends on where the bank is split into long-term and working segment'
+    with pytest.raises(Exception, match='unsupported'):
+        _run(mk, ms, qk, qe, 65)
+
+
+def _run_dense(mk, ms, qk, qe, k, n_long=0):
+    n = mk.shape[1]
+    rows, shr = mk.t().contiguous(), ms.reshape(-1).contiguous()
+    kl, sl = (to_dev(rows[:n_long]), to_dev(shr[:n_long])) if n_long else (None, None)
+    kw, sw = to_dev(rows[n_long:].contiguous()), to_dev(shr[n_long:].contiguous())
+    fix = torch.zeros(n, dtype=torch.int64, device=dev())
+    idx, w = ops.affinity_dense(kl, sl, n_long, kw, sw, n - n_long, to_dev(qk), to_dev(qe), k, fix)
+    torch.cuda.synchronize()
+    return idx.cpu(), w.cpu(), (fix.cpu().double() / 2**40).float()
+
+
+@pytest.mark.parametrize('n,hw,k,n_long', [(4096, 2000, 30, 0), (5000, 333, 32, 1200), (70, 65, 30, 7), (700, 64, 1, 0),
+                                            (9000, 1000, 30, 4000)])
+def test_dense_kernel_is_bit_identical_to_the_list_kernels(n, hw, k, n_long):
+    """same fp32 FMA chains, same (score, index) order, same exp / sequential sum: where both kernels apply the dense one
+    must reproduce the list kernels' indices, weights and usage counters bit for bit (the last shape takes the fp16
+    pre-filter + exact re-scoring on the other side)"""
+    if os.environ.get('DEVA_TEST_DRYRUN') == '1':
+        pytest.skip('kernel-path property: nothing to compare on the emulated ops')
+    mk, ms, qk, qe = synth.affinity_inputs(n, hw, seed=3 * n + hw, key_scale=1.5)
+    _assert_identical(f'dense vs lists n{n}hw{hw}k{k}', _run(mk, ms, qk, qe, k, n_long), _run_dense(mk, ms, qk, qe, k, n_long))
+
+
 def _both_paths(mk, ms, qk, qe, k, n_long=0):
     """the same read through the fp32 kernels (pre-filter off) and through the automatic choice"""
     from deva.hip import lib

@@ -230,6 +230,15 @@ def test_480p_lockstep_teacher_forced(network, recipe_state_dict):
     print('lockstep 480p worst relative errors:', json.dumps({k: float(f'{v:.2e}') for k, v in worst.items()}))
 
 
+def test_top_k_48_lockstep_teacher_forced(network, recipe_state_dict):
+    """--top_k above 32 end to end (dense read kernel -> 48-term read-out -> decoder), teacher-forced against the oracle
+    with the same top_k; 192x256 so that the bank (768 tokens per memory frame) is much larger than k"""
+    import lockstep
+    P, _ = recipe_state_dict
+    worst = lockstep.run(network, P, 192, 256, 2, 5, dev(), top_k=48)
+    print('top_k=48 teacher-forced lock-step, worst relative stage errors:', {k: f'{v:.2e}' for k, v in worst.items()})
+
+
 def test_amp_lockstep_teacher_forced(recipe_state_dict):
     """--amp: fp16 operands / fp32 accumulation in the value encoder and the mask decoder (csrc/conv_f16.hip), every
     stage of every frame teacher-forced against the oracle's amp restatement (the same convolutions see their inputs

@@ -395,7 +395,7 @@ def test_soft_annotation_on_engaged_memory_and_top_k_validation(emu, recipe_stat
     assert (prob[3, 60:90, 10:40] > 0.5).all() and (prob[1:3, 60:90, 10:40] < 0.5).all()
     assert core.step(stream.next()).shape[0] == 4
     with pytest.raises(ValueError, match='top_k'):
-        MemoryManager(synth.base_config(top_k=50))
+        MemoryManager(synth.base_config(top_k=65))
     with pytest.raises(ValueError, match='top_k'):
         core.memory.update_config(synth.base_config(top_k=0, mem_every=2))
 

@@ -2228,6 +2228,7 @@ extern "C" int deva_readout_sparse(const int32_t* idx, const float* weight, int 
                                    int n_long, const float* val_work, int cv, float* out, int tok_lo, int tok_hi,
                                    const int32_t* map_long, const int32_t* map_work, void* stream) {
   DEVA_REQUIRE(idx && weight && out && hw > 0 && k > 0 && cv > 0, "deva_readout_sparse: bad args");
+  DEVA_REQUIRE(k <= 64, "deva_readout_sparse: k=%d unsupported (one term per lane: 1..64)", k);
   DEVA_REQUIRE(cv % 4 == 0, "deva_readout_sparse: value dim must be a multiple of 4");
   DEVA_REQUIRE(n_long == 0 || val_long, "deva_readout_sparse: null long-term values");
   const float* vl = val_long ? val_long : val_work;
@@ -2295,6 +2296,138 @@ static PfLayout pf_layout(int n_total, int hw, int k) {
   return L;
 }
 
+// ------------------------------------------------------------------ dense read (32 < k <= 64)
+// The list kernels above size their per-range hand-over for k <= K_MAX = 32.  For the rare larger top_k
+// (eval_args.py:40 leaves it free) the read runs on this one kernel: lane = query (64 queries per one-wave workgroup,
+// query operands in registers), the bank streams through wave-uniform rows, every score is the same natural-order fp32
+// FMA chain as in affinity_pf_rescore_kernel (bit-identical scores, hence the same selection as the list kernels for any
+// k both can serve), and each lane keeps its k best (score, ~token) keys in LDS -- unsorted, smallest tracked, replaced
+// on insert (~k ln(N/k) inserts per query).  Finish per query exactly like affinity_finalize_kernel.  VALU-bound:
+// 192 instructions per (token, query); ~4 ms at N = 10 000 x 8 160 queries -- a correct path, not a fast one.
+constexpr int DK_MAX = 64;
+
+struct DenseArgs {
+  PfBank bank;
+  const float* qk;
+  const float* qe;
+  int hw, k;
+  int32_t* idx;
+  float* weight;
+  unsigned long long* usage_fix;
+};
+
+__global__ __launch_bounds__(64) void affinity_dense_kernel(const DenseArgs p) {
+  __shared__ uint64_t s_list[DK_MAX][64];  // [entry][query lane]
+  __shared__ uint64_t s_sort[64];
+  const int lane = threadIdx.x;
+  const int q0 = blockIdx.x * 64;
+  const int qq = min(q0 + lane, p.hw - 1);
+  const int k = p.k, n = p.bank.n_total;
+  float qe[CK], qp[CK];
+  float bs[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // bsq in ATen's summation order (see affinity_topk_kernel)
+#pragma unroll
+  for (int c = 0; c < CK; ++c) {
+    const float ev = p.qe[(int64_t)c * p.hw + qq], kv = p.qk[(int64_t)c * p.hw + qq];
+    qe[c] = ev;
+    qp[c] = kv * ev;
+    bs[c >> 4] += ev * (kv * kv);
+  }
+  const float bsq = ((bs[0] + bs[1]) + bs[2]) + bs[3];
+
+  uint64_t kmin = ~0ull;
+  int pmin = 0;
+  for (int t = 0; t < n; ++t) {  // t is wave-uniform: the row and its shrinkage are scalar loads
+    float ms;
+    const float* row = pf_row(p.bank, t, &ms);
+    float accA = 0.0f, accB = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CK; ++c) {
+      const float a = row[c];
+      accA = __builtin_fmaf(a * a, qe[c], accA);
+      accB = __builtin_fmaf(a, qp[c], accB);
+    }
+    const float v = (((accB + accB) - accA) - bsq) * (ms * 0.125f);
+    const uint64_t key = ((uint64_t)orderable(v) << 32) | (uint64_t)(~(uint32_t)t);
+    if (t < k) {  // (uniform) the first k tokens fill the list
+      s_list[t][lane] = key;
+      if (key < kmin) {
+        kmin = key;
+        pmin = t;
+      }
+    } else if (key > kmin) {
+      s_list[pmin][lane] = key;
+      kmin = ~0ull;
+      for (int e = 0; e < k; ++e) {
+        const uint64_t o = s_list[e][lane];
+        if (o < kmin) {
+          kmin = o;
+          pmin = e;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- per query of the tile: sort the k keys by rank counting, exp / normalise / usage (affinity_finalize_kernel's tail)
+  const bool live = lane < k;
+  for (int j = 0; j < 64 && q0 + j < p.hw; ++j) {
+    const int q = q0 + j;
+    const uint64_t cand = live ? s_list[live ? lane : 0][j] : 0ull;
+    int rank = 0;
+    for (int r = 0; r < k; ++r) {
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cand, r);
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cand >> 32), r);
+      rank += ((((uint64_t)hi << 32) | lo) > cand) ? 1 : 0;
+    }
+    __syncthreads();  // (one wave: orders the LDS traffic of consecutive queries)
+    if (live) s_sort[rank] = cand;
+    __syncthreads();
+    const uint64_t mine = live ? s_sort[lane] : 0ull;  // lane r holds the r-th best
+    const float score = from_orderable((uint32_t)(mine >> 32));
+    const uint32_t token = ~(uint32_t)mine;
+    const float ex = live ? expf(score) : 0.0f;
+    float sum = 0.0f;
+    for (int r = 0; r < k; ++r)  // sequential, like torch.sum over the sorted top-k
+      sum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ex), r));
+    const float w = ex / sum;
+    if (live) {
+      p.idx[(int64_t)q * k + lane] = (int32_t)token;
+      p.weight[(int64_t)q * k + lane] = w;
+      if (p.usage_fix && w == w) atomicAdd(&p.usage_fix[token], (unsigned long long)(w * 1099511627776.0f));
+    }
+  }
+}
+
+extern "C" int deva_affinity_dense(const float* key_long, const float* shr_long, int n_long, const float* key_work,
+                                   const float* shr_work, int n_work, const float* qk, const float* qe, int hw, int k,
+                                   int32_t* idx, float* weight, uint64_t* usage_fix, void* stream) {
+  DEVA_REQUIRE(qk && qe && idx && weight && hw > 0, "deva_affinity_dense: bad args");
+  DEVA_REQUIRE(n_long >= 0 && n_work >= 0, "deva_affinity_dense: negative bank size");
+  DEVA_REQUIRE(n_long == 0 || (key_long && shr_long), "deva_affinity_dense: null long-term segment");
+  DEVA_REQUIRE(n_work == 0 || (key_work && shr_work), "deva_affinity_dense: null working segment");
+  DEVA_REQUIRE(k >= 1 && k <= DK_MAX, "deva_affinity_dense: k=%d unsupported (1..%d)", k, DK_MAX);
+  const int64_t n_total = (int64_t)n_long + n_work;
+  DEVA_REQUIRE(n_total >= k, "deva_affinity_dense: selected index k out of range (bank has %lld tokens, k=%d)",
+               (long long)n_total, k);
+  DEVA_REQUIRE(n_total < (1ll << 31) - 64, "deva_affinity_dense: bank too large");
+  DenseArgs a;
+  a.bank.key_long = key_long ? key_long : key_work;
+  a.bank.shr_long = shr_long ? shr_long : shr_work;
+  a.bank.n_long = n_long;
+  a.bank.key_work = key_work ? key_work : key_long;
+  a.bank.shr_work = shr_work ? shr_work : shr_long;
+  a.bank.n_total = (int)n_total;
+  a.qk = qk;
+  a.qe = qe;
+  a.hw = hw;
+  a.k = k;
+  a.idx = idx;
+  a.weight = weight;
+  a.usage_fix = (unsigned long long*)usage_fix;
+  hipLaunchKernelGGL(affinity_dense_kernel, dim3((unsigned)ceil_div(hw, 64)), dim3(64), 0, (hipStream_t)stream, a);
+  return check_launch("deva_affinity_dense");
+}
+
 extern "C" int deva_affinity_prefilter_enabled(int n_total, int hw, int k) {
   if (g_prefilter < 0) {
     const char* e = getenv("DEVA_AFFINITY_PREFILTER");
@@ -2310,6 +2443,7 @@ extern "C" int deva_affinity_force_prefilter(int mode) {
 }
 
 extern "C" int64_t deva_affinity_read_scratch(int n_total, int hw, int k) {
+  if (k > K_MAX) return 64;  // the dense kernel (32 < k <= 64) needs no scratch; a token size keeps callers uniform
   return pf_layout(n_total, hw, k).bytes / 8;
 }
 
@@ -2323,7 +2457,13 @@ extern "C" int deva_affinity_read(const float* key_long, const float* shr_long, 
   DEVA_REQUIRE(n_long >= 0 && n_work >= 0, "deva_affinity_read: negative bank size");
   DEVA_REQUIRE(n_long == 0 || (key_long && shr_long), "deva_affinity_read: null long-term segment");
   DEVA_REQUIRE(n_work == 0 || (key_work && shr_work), "deva_affinity_read: null working segment");
-  DEVA_REQUIRE(k >= 1 && k <= K_MAX, "deva_affinity_read: k=%d unsupported (1..%d)", k, K_MAX);
+  if (k > K_MAX) {  // beyond the list kernels: one dense kernel, no hand-over format (a token-sharded bank cannot use it)
+    DEVA_REQUIRE(idx && weight, "deva_affinity_read: k=%d > %d is served by the dense kernel, which has no hand-over format "
+                 "(out_keys / out_counts)", k, K_MAX);
+    return deva_affinity_dense(key_long, shr_long, n_long, key_work, shr_work, n_work, qk, qe, hw, k, idx, weight, usage_fix,
+                               stream);
+  }
+  DEVA_REQUIRE(k >= 1, "deva_affinity_read: k=%d unsupported", k);
   const int64_t n_total = (int64_t)n_long + n_work;
   DEVA_REQUIRE(n_total >= k, "deva_affinity_read: selected index k out of range (bank has %lld tokens, k=%d)",
                (long long)n_total, k);

@@ -69,6 +69,8 @@ SIGNATURES = {
     'deva_affinity_read': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     'deva_affinity_read_scratch': (c_int64, [c_int, c_int, c_int]),
+    'deva_affinity_dense': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                            c_void_p, c_void_p, c_void_p, c_void_p]),
     'deva_affinity_prefilter_enabled': (c_int, [c_int, c_int, c_int]),
     'deva_affinity_force_prefilter': (c_int, [c_int]),
     'deva_probe_mfma_f32': (c_int64, [c_void_p, c_int64, c_void_p, c_int, c_void_p]),

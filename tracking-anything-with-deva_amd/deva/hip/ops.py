@@ -15,7 +15,7 @@ from . import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQUARE_PLUS_ONE, KLAYOUT_CHU
 
 __all__ = ['PackedConv', 'pack_conv', 'conv2d', 'maxpool3x3s2', 'upsample2x_add', 'area_downsample',
            'aggregate', 'softmax_channels', 'upsample4x_softmax', 'cbam', 'gru_update',
-           'affinity_topk', 'affinity_candidates', 'affinity_merge', 'usage_update', 'readout_sparse', 'bank_append', 'bank_gather_rows',
+           'affinity_topk', 'affinity_dense', 'affinity_candidates', 'affinity_merge', 'usage_update', 'readout_sparse', 'bank_append', 'bank_gather_rows',
            'bank_export', 'rank', 'rank_select', 'evict_select', 'similarity_dense', 'softmax_columns',
            'label_histogram', 'merge_paint', 'lut_remap', 'index_mask', 'input_head',
            'ACT_NONE', 'ACT_RELU', 'ACT_SIGMOID', 'ACT_SQUARE_PLUS_ONE']
@@ -386,6 +386,22 @@ def affinity_topk(key_long, shr_long, n_long: int, key_work, shr_work, n_work: i
           'deva_affinity_topk')
     check(L.deva_affinity_finalize(_p(part, torch.int64), hw, k, splits, _p(idx, torch.int32), _p(weight),
                                    _p(usage_fix, torch.int64), _stream()), 'deva_affinity_finalize')
+    return idx, weight
+
+
+def affinity_dense(key_long, shr_long, n_long: int, key_work, shr_work, n_work: int, qk: torch.Tensor, qe: torch.Tensor,
+                   k: int, usage_fix: Optional[torch.Tensor] = None):
+    """The read on the dense kernel (deva_affinity_dense: 1 <= k <= 64; what `affinity_topk` runs for k > 32).  Same
+    arguments and results as `affinity_topk`; for k <= 32 bit-identical to it (tests)."""
+    hw = qk.shape[1]
+    if qk.shape[0] != 64 or tuple(qe.shape) != tuple(qk.shape):
+        raise DevaHipError('affinity_dense: queries must be [64, hw]')
+    idx = torch.empty((hw, k), dtype=torch.int32, device=qk.device)
+    weight = torch.empty((hw, k), dtype=torch.float32, device=qk.device)
+    check(lib().deva_affinity_dense(_p(key_long) if n_long else None, _p(shr_long) if n_long else None, n_long,
+                                    _p(key_work) if n_work else None, _p(shr_work) if n_work else None, n_work,
+                                    _p(qk), _p(qe), hw, k, _p(idx, torch.int32), _p(weight), _p(usage_fix, torch.int64),
+                                    _stream()), 'deva_affinity_dense')
     return idx, weight
 
 

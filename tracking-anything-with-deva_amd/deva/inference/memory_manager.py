@@ -40,7 +40,10 @@ class MemoryManager:
     Manages all three memory stores and the transition between working/long-term memory
     """
 
-    MAX_TOP_K = 32  # the fused affinity kernel keeps one candidate per lane pair: 1 <= top_k <= 32
+    # 1..32: the list kernels (fp16 pre-filter / fused fp32 kernels); 33..64: the dense kernel behind deva_affinity_read
+    # (correct, ~4 ms per read at 1080p / 10k tokens); the read-out gathers one term per lane: 64 at most
+    MAX_TOP_K = 64
+    MAX_TOP_K_SHARDED_BANK = 32  # the hand-over format of a token-sharded bank holds <= 32 entries per range
 
     @classmethod
     def _checked_top_k(cls, top_k) -> int:
@@ -154,6 +157,9 @@ class MemoryManager:
         if not dist.is_initialized():
             raise RuntimeError('shard_bank: torch.distributed is not initialised')
         self._shard_group = group if group is not None else dist.group.WORLD
+        if self.top_k > self.MAX_TOP_K_SHARDED_BANK:
+            raise ValueError(f'shard_bank: top_k={self.top_k} > {self.MAX_TOP_K_SHARDED_BANK} is served by the dense read kernel, '
+                             'which has no per-shard hand-over; use shard_queries or a smaller top_k')
         if dist.get_world_size(self._shard_group) > 32:
             # deva_affinity_merge takes at most 32 candidate lists (MAX_SPLITS, include/deva_hip.h)
             raise ValueError('shard_bank: at most 32 ranks per group (one candidate list per rank is merged)')
