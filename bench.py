@@ -20,9 +20,11 @@ Extra objects on the JSON line:
                 deva_conv2d call WITHOUT any synchronisation, in a pass that replays the same number of
                 frames right after the timed region (event overhead never touches `value`); the stream
                 stays busy back to back, so an event pair brackets exactly the kernel(s) of its launch
-                at the clocks of the real frame loop.  peak = 157.3 TFLOP/s fp32 matrix.  `traffic` =
+                at the clocks of the real frame loop.  peak = 157.3 TFLOP/s fp32 matrix (data sheet);
+                `sustained_mfma_probe` = what a register-only fp32 MFMA loop reaches on this box, timed right
+                here (the chip clocks to its power budget: ~0.78 of the data sheet).  `traffic` =
                 HBM bytes per frame of those kernels from the committed rocprofv3 --pmc passes over
-                this same command (profiles/pmc_r03/conv_traffic.json; bench.py cannot collect PMC
+                this same command (profiles/pmc_r04/conv_traffic.json, tools/pmc_bench.sh; bench.py cannot collect PMC
                 counters itself), next to the algorithmic bytes per frame computed here.
   affinity      the north-star read (similarity -> exact top-k -> softmax -> usage): event-timed at the
                 BASELINE shape (N=10 000 bank, 1080p queries) through deva_affinity_read (fp16 MFMA
