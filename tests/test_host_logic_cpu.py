@@ -458,3 +458,40 @@ def test_read_memory_matches_reference(emu, golden_dir, recipe_state_dict):
     out = net.read_memory(**g['args'])
     assert out.shape == g['out'].shape
     assert (out - g['out']).abs().max().item() <= 1e-4 * max(1.0, g['out'].abs().max().item())
+
+
+def test_conv_tile_order_is_a_permutation():
+    """csrc/conv_epilogue.h: conv_tile_coords + csrc/conv_args.h: conv_group_m, restated line by line: for every grid
+    the workgroup -> (cout tile, pixel tile) map must hit every tile exactly once, whatever the group size leaves over"""
+    def group_m(taps, stride, bm, bn, tiles):
+        ratio = taps * bm / (bn * stride * stride)
+        c = 48.0 if tiles >= 8 * 48 else float((tiles + 7) // 8)
+        g = 1
+        while (g + 1) * (g + 1) * ratio <= c * 1.5:
+            g += 1
+        return g
+
+    def coords(b, nb, tiles_m, tiles_n, group):
+        q, r, xcd = nb >> 3, nb & 7, b & 7
+        logical = (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + (b >> 3)
+        g = group if 0 < group < tiles_m else tiles_m
+        per_group = g * tiles_n
+        grp, in_grp = divmod(logical, per_group)
+        m_first = grp * g
+        gsz = min(g, tiles_m - m_first)
+        tile_n = in_grp // gsz
+        return m_first + (in_grp - tile_n * gsz), tile_n
+
+    seen_groups = set()
+    for tiles_m in (1, 2, 3, 4, 5, 7, 8, 12):
+        for tiles_n in (1, 2, 13, 26, 64, 203, 1013):
+            for taps, stride in ((1, 1), (9, 1), (9, 2), (49, 2)):
+                for bm, bn in ((128, 128), (64, 64), (32, 128)):
+                    nb = tiles_m * tiles_n
+                    g = group_m(taps, stride, bm, bn, nb)
+                    seen_groups.add(min(g, tiles_m))
+                    got = sorted(coords(b, nb, tiles_m, tiles_n, g) for b in range(nb))
+                    assert got == [(m, n) for m in range(tiles_m) for n in range(tiles_n)], (tiles_m, tiles_n, g)
+    assert {1, 2, 3, 5, 8} <= seen_groups  # partial last groups (3 of 2, 5 of 3, ...) were among the cases
+    # the two sizes the comments quote: 3x3 on 128x128 tiles -> 2 cout tiles per group, 1x1 -> 8
+    assert group_m(9, 1, 128, 128, 768) == 2 and group_m(1, 1, 128, 128, 2026) == 8

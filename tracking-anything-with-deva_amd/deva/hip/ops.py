@@ -36,7 +36,9 @@ def _stream(device=None) -> int:
     builds a Stream object through four Python layers (6 us, twice per kernel launch = 1 ms of a 3.5-ms frame at
     480p / 1 object); the C entry points behind it return the same handle in 0.3 us."""
     if _RAW_STREAM is not None and _RAW_DEVICE is not None:
-        index = getattr(device, 'index', None)
+        if device is not None and not isinstance(device, torch.device):
+            device = torch.device(device)  # 'cuda:1', 1
+        index = None if device is None else device.index
         return _RAW_STREAM(_RAW_DEVICE() if index is None else index)
     return torch.cuda.current_stream(device).cuda_stream
 
