@@ -116,3 +116,26 @@ def test_conv_pack_matches_python_packing(library):
                                 ctypes.byref(cpad)) == n
         assert torch.equal(out.view_as(pc.weight), pc.weight), (cout, cin, k)
         assert bool(pc.k_layout & hip.KLAYOUT_Q4) == (cout > 1)
+
+
+def test_conv_pack_f16_matches_python_packing(library):
+    """deva_conv_pack_f16 (host function, the --amp weights) and ops.pack_f16 produce the same bytes: fp16 octets
+    Wh[K/8][cout_pad][8], 64-channel slabs for 3x3, round-to-nearest-even; layers with cin % 64 != 0 are refused by both"""
+    import torch
+    from deva import hip
+    from deva.hip import ops
+    L = hip.lib()
+    g = torch.Generator().manual_seed(5)
+    for cout, cin, k in ((64, 64, 1), (72, 128, 3), (1536, 64, 3), (40, 192, 1)):
+        w = torch.randn(cout, cin, k, k, generator=g) * 3.0
+        w.view(-1)[::7] *= 1e-6   # some values in the fp16 subnormal range, some ties of the rounding
+        ref = ops.pack_f16(w)
+        cpad = ctypes.c_int(-1)
+        n = L.deva_conv_pack_f16(w.contiguous().data_ptr(), None, cout, cin, k, k, ctypes.byref(cpad))
+        assert n == ref.numel() and cpad.value == (cout + 31) // 32 * 32, (cout, cin, k)
+        out = torch.zeros(n, dtype=torch.int16)
+        assert L.deva_conv_pack_f16(w.contiguous().data_ptr(), out.data_ptr(), cout, cin, k, k, ctypes.byref(cpad)) == n
+        assert torch.equal(out, ref.view(torch.int16)), (cout, cin, k)
+    w = torch.randn(64, 96, 3, 3, generator=g)  # 96 % 64 != 0: not an amp layer
+    assert ops.pack_f16(w) is None
+    assert L.deva_conv_pack_f16(w.contiguous().data_ptr(), None, 64, 96, 3, 3, ctypes.byref(ctypes.c_int(0))) == -1
