@@ -59,7 +59,7 @@ def _batched(t: torch.Tensor, name: str) -> Tuple[int, int]:
     """pointer and batch stride of an NCHW tensor whose per-item [C,H,W] block is contiguous"""
     if not t.is_cuda or t.dtype != torch.float32:
         raise DevaHipError(f'{name} must be an fp32 HIP tensor')
-    if t.dim() != 4 or not t[0].is_contiguous():
+    if t.dim() != 4 or not (t.is_contiguous() or t[0].is_contiguous()):  # (the first test avoids building a view)
         raise DevaHipError(f'{name} must be [B,C,H,W] with contiguous items')
     return t.data_ptr(), (t.stride(0) if t.shape[0] > 1 else 0)
 
@@ -149,13 +149,18 @@ def _alloc(shape, device) -> torch.Tensor:
     for s_ in shape:
         n *= int(s_)
     flat = torch.empty(n + 2 * GUARD, dtype=torch.float32, device=device)
-    return flat[GUARD:GUARD + n].view(*shape)
+    out = flat[GUARD:GUARD + n].view(*shape)
+    out._deva_guard = GUARD  # what _guard_elems would compute for this very object (views and slices of it recompute)
+    return out
 
 
 def _guard_elems(t: Optional[torch.Tensor]) -> int:
     """readable floats before the first / after the last element of t inside its storage"""
     if t is None:
         return 1 << 30
+    known = getattr(t, '_deva_guard', None)  # set by _alloc on the tensor object it returns: 3 us less per operand
+    if known is not None:
+        return known
     first = t.storage_offset()
     last = first + sum((int(n) - 1) * int(st) for n, st in zip(t.shape, t.stride()))
     total = t.untyped_storage().nbytes() // 4
