@@ -396,6 +396,9 @@ def test_soft_annotation_on_engaged_memory_and_top_k_validation(emu, recipe_stat
     assert core.step(stream.next()).shape[0] == 4
     with pytest.raises(ValueError, match='top_k'):
         MemoryManager(synth.base_config(top_k=65))
+    assert MemoryManager(synth.base_config(top_k=64)).top_k == 64  # 33..64: the dense read kernel
+    with pytest.raises(ValueError, match='shard_bank: top_k=48'):  # ... which has no per-shard hand-over format
+        MemoryManager(synth.base_config(top_k=48)).shard_bank()
     with pytest.raises(ValueError, match='top_k'):
         core.memory.update_config(synth.base_config(top_k=0, mem_every=2))
 

@@ -154,12 +154,12 @@ class MemoryManager:
         half the bytes of the all-reduce every-rank-decodes needs) and nobody else receives them.  The configuration
         for a bank that outgrows one GPU: every rank stores and scores 1/world of it, one rank decodes."""
         import torch.distributed as dist
-        if not dist.is_initialized():
-            raise RuntimeError('shard_bank: torch.distributed is not initialised')
-        self._shard_group = group if group is not None else dist.group.WORLD
         if self.top_k > self.MAX_TOP_K_SHARDED_BANK:
             raise ValueError(f'shard_bank: top_k={self.top_k} > {self.MAX_TOP_K_SHARDED_BANK} is served by the dense read kernel, '
                              'which has no per-shard hand-over; use shard_queries or a smaller top_k')
+        if not dist.is_initialized():
+            raise RuntimeError('shard_bank: torch.distributed is not initialised')
+        self._shard_group = group if group is not None else dist.group.WORLD
         if dist.get_world_size(self._shard_group) > 32:
             # deva_affinity_merge takes at most 32 candidate lists (MAX_SPLITS, include/deva_hip.h)
             raise ValueError('shard_bank: at most 32 ranks per group (one candidate list per rank is merged)')
