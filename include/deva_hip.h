@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DEVA_HIP_ABI_VERSION 6
+#define DEVA_HIP_ABI_VERSION 7
 
 int deva_hip_version(void);
 const char* deva_hip_last_error(void);
@@ -106,12 +106,29 @@ typedef struct deva_conv_desc {
    * fp32 kernels on `weight` as if amp were 0. */
   const void* weight_f16;
   int32_t amp;
+  /* amp == 2: fp32-ACCURATE convolution on the f16 matrix pipes (the arithmetic of the reference's fp32 nn.Conv2d,
+   * big_modules.py:54-212, modules.py:81-169, to fp32 round-off; opt-in, csrc/conv_f16.hip).  weight_f16 then points to
+   * the hi / lo fp16 planes packed by deva_conv_pack_split (layout: element (k, plane, m) at
+   * (((k/8)*2 + plane)*cout_pad + m)*8 + k%8, K tap-major for 1x1, 32-channel slabs otherwise) of the weights scaled
+   * by 2^split_scale_log2; every activation is split into hi = fp16(x), lo = fp16(x - hi) while it is staged, each
+   * K-block runs hi.hi + hi.lo + lo.hi with fp32 accumulation, and the accumulators are scaled back exactly.
+   * split_flag: one device int the caller has zeroed; the kernel sets it when an input lay beyond the fp16 range
+   * (|x| > 65504 or non-finite), and the fp32 kernels -- launched behind the split kernel on the same stream, gated on
+   * that int -- then produce the output.  Shapes the split kernels do not cover (stride 2, channel counts that are not
+   * multiples of 32, single-channel heads, unguarded inputs) run the fp32 kernels on `weight` directly. */
+  int32_t split_scale_log2;
+  int32_t* split_flag;
 } deva_conv_desc;
 
 int deva_conv2d(const deva_conv_desc* desc, void* stream);
 /* fp16 weights of the amp path (HOST pointers, model load): -> number of uint16 elements (out == NULL: size query),
  * -1 when the layer is not eligible (cin % 64 != 0) or on bad arguments */
 int64_t deva_conv_pack_f16(const float* w_oihw, uint16_t* out, int cout, int cin, int kh, int kw, int* cout_pad);
+/* hi / lo fp16 planes of the split path (HOST pointers, model load): -> number of uint16 elements (out == NULL: size
+ * query; *scale_log2 is set either way), -1 when the layer is not eligible (cin % 32 != 0), holds a non-finite weight,
+ * or on bad arguments.  *scale_log2 = e with max|w| * 2^e in [2^13, 2^14): pass it as deva_conv_desc.split_scale_log2. */
+int64_t deva_conv_pack_split(const float* w_oihw, uint16_t* out, int cout, int cin, int kh, int kw, int* cout_pad,
+                             int* scale_log2);
 
 /* Host-side packing of one convolution's weights (HOST pointers; model load, not the frame path):
  * w_oihw [cout][cin][kh][kw] (BatchNorm already folded) -> out in the layout named by *k_layout / *cout_pad

@@ -20,8 +20,8 @@ def require_hip(device, what):  # the emulation runs on the CPU
     return None
 
 
-def pack_conv(weight, bias=None, bn=None, device=None, amp=False):
-    return _real_pack_conv(weight, bias, bn, None, amp)
+def pack_conv(weight, bias=None, bn=None, device=None, amp=False, split=False):
+    return _real_pack_conv(weight, bias, bn, None, amp, split)
 
 
 def _unpack(pc: PackedConv):
@@ -55,7 +55,31 @@ def amp_takes(pc, x0, x1, stride, pad):
             ((pc.kh == 1 and pad == 0) or (pc.kh == 3 and pad == 1)) and (h * w) % 4 == 0 and w >= 4)
 
 
-def conv2d(pc, x0, x1=None, *, stride=1, pad=0, relu_in=False, residual=None, act=real.ACT_NONE, out=None, amp=False):
+def split_takes(pc, x0, x1, stride, pad):
+    """the shapes the hi/lo split kernels take (csrc/conv_f16.hip: launch_conv_f16 with prec 2 + the vector-gather
+    geometry of deva_conv2d); everything else runs the fp32 kernels although split is requested"""
+    c0, c1 = x0.shape[1], 0 if x1 is None else x1.shape[1]
+    h, w = x0.shape[-2:]
+    return (pc.weight_split is not None and stride == 1 and pc.cout >= 64 and c0 % 32 == 0 and c1 % 32 == 0 and
+            ((pc.kh == 1 and pad == 0) or (pc.kh == 3 and pad == 1)) and (h * w) % 4 == 0 and w >= 4)
+
+
+_SPLIT_FALLBACKS = [0]
+
+
+def split_fallbacks(device):
+    return _SPLIT_FALLBACKS[0]
+
+
+def conv2d(pc, x0, x1=None, *, stride=1, pad=0, relu_in=False, residual=None, act=real.ACT_NONE, out=None, amp=False,
+           split=False):
+    # split: the contract of the hi/lo split kernels IS the fp32 convolution (to fp32 round-off); only the fall-back
+    # statistic is emulated (an input beyond the fp16 range sends the layer to the fp32 kernels)
+    if split and split_takes(pc, x0, x1, stride, pad):
+        for t in (x0, x1):
+            if t is not None and not bool(((F.relu(t) if relu_in else t).abs() <= 65504.0).all()):
+                _SPLIT_FALLBACKS[0] += 1
+                break
     batch = max(x0.shape[0], 1 if x1 is None else x1.shape[0], 1 if residual is None else residual.shape[0])
     xs = [x0.expand(batch, -1, -1, -1)]
     if x1 is not None:

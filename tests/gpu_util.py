@@ -1,9 +1,23 @@
 """helpers of the -m gpu tests: run a real HIP op and its CPU contract (tests/emu_ops.py) on the
 same seeded inputs and compare."""
+import os
+
 import torch
 
 import emu_ops
 from deva.hip import ops
+
+
+def net_config(**over):
+    """config of the networks the -m gpu tests build: workload.synth.base_config, and with DEVA_TEST_F16_SPLIT=1 in the
+    environment the SAME tests run with --f16_split (fp32-accurate convolutions on the f16 matrix pipes): every parity
+    gate is then held, with unchanged bounds, under that mode (profiles/r05/tests_split/)"""
+    from workload import synth
+    cfg = synth.base_config()
+    if os.environ.get('DEVA_TEST_F16_SPLIT') == '1' and not over.get('amp'):
+        cfg['f16_split'] = True
+    cfg.update(over)
+    return cfg
 
 
 def dev():
@@ -16,7 +30,8 @@ def to_dev(x):
         return x.to(dev())
     if isinstance(x, ops.PackedConv):
         return ops.PackedConv(x.weight.to(dev()), None if x.bias is None else x.bias.to(dev()), x.cin, x.cout,
-                              x.cout_pad, x.kh, x.kw, x.k_layout, None if x.weight_f16 is None else x.weight_f16.to(dev()))
+                              x.cout_pad, x.kh, x.kw, x.k_layout, None if x.weight_f16 is None else x.weight_f16.to(dev()),
+                              None if x.weight_split is None else x.weight_split.to(dev()), x.split_scale_log2)
     if isinstance(x, dict):
         return {k: to_dev(v) for k, v in x.items()}
     if isinstance(x, (list, tuple)):

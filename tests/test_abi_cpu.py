@@ -139,3 +139,37 @@ def test_conv_pack_f16_matches_python_packing(library):
     w = torch.randn(64, 96, 3, 3, generator=g)  # 96 % 64 != 0: not an amp layer
     assert ops.pack_f16(w) is None
     assert L.deva_conv_pack_f16(w.contiguous().data_ptr(), None, 64, 96, 3, 3, ctypes.byref(ctypes.c_int(0))) == -1
+
+
+def test_conv_pack_split_matches_python_packing(library):
+    """deva_conv_pack_split (host function, the --f16_split weights) and ops.pack_split produce the same bytes and the same
+    scale: hi / lo fp16 planes W[K/8][2][cout_pad][8] of w * 2^e, 32-channel slabs for 3x3, round-to-nearest-even; hi + lo
+    reproduces w * 2^e to 2^-22 relative or 2^-25 absolute; layers with cin % 32 != 0 are refused by both"""
+    import torch
+    from deva import hip
+    from deva.hip import ops
+    L = hip.lib()
+    g = torch.Generator().manual_seed(9)
+    for cout, cin, k, gain in ((64, 64, 1, 0.05), (72, 96, 3, 3.0), (1536, 32, 3, 1e-3), (40, 160, 1, 200.0)):
+        w = torch.randn(cout, cin, k, k, generator=g) * gain
+        w.view(-1)[::7] *= 1e-6   # lo planes in the fp16 subnormal range, some exact zeros
+        ref, e_ref = ops.pack_split(w)
+        cpad, e = ctypes.c_int(-1), ctypes.c_int(-999)
+        n = L.deva_conv_pack_split(w.contiguous().data_ptr(), None, cout, cin, k, k, ctypes.byref(cpad), ctypes.byref(e))
+        assert n == ref.numel() and cpad.value == (cout + 31) // 32 * 32 and e.value == e_ref, (cout, cin, k)
+        assert 2.0**13 <= float(w.abs().max()) * 2.0**e_ref < 2.0**14
+        out = torch.zeros(n, dtype=torch.int16)
+        assert L.deva_conv_pack_split(w.contiguous().data_ptr(), out.data_ptr(), cout, cin, k, k, ctypes.byref(cpad),
+                                      ctypes.byref(e)) == n
+        assert torch.equal(out, ref.view(torch.int16)), (cout, cin, k)
+        # hi + lo against the scaled weights (layout undone)
+        planes = ref.view(-1, 2, cpad.value, 8).float()
+        rec = (planes[:, 0] + planes[:, 1]).permute(0, 2, 1).reshape(-1, cpad.value)[:, :cout]  # [K][cout]
+        taps = k * k
+        wk = (w.reshape(cout, cin // 32, 32, taps).permute(1, 3, 2, 0).reshape(-1, cout) if taps > 1
+              else w.reshape(cout, cin).t()) * 2.0**e_ref
+        assert bool(((rec - wk).abs() <= torch.maximum(wk.abs() * 2.0**-22, torch.tensor(2.0**-25))).all())
+    w = torch.randn(64, 48, 3, 3, generator=g)  # 48 % 32 != 0: not a split layer
+    assert ops.pack_split(w) == (None, 0)
+    assert L.deva_conv_pack_split(w.contiguous().data_ptr(), None, 64, 48, 3, 3, ctypes.byref(ctypes.c_int(0)),
+                                  ctypes.byref(ctypes.c_int(0))) == -1

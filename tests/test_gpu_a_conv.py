@@ -166,6 +166,145 @@ def test_conv_amp_matches_fp16_rounded_cpu(case):
         assert torch.equal(want, exact)
 
 
+split_takes = emu_ops.split_takes
+
+
+def _conv64(pc, x0, x1, stride, pad, relu_in, residual, act):
+    """the convolution in fp64 on the CPU: what both the fp32 kernels and the split kernels approximate"""
+    import torch.nn.functional as F
+    batch = max(x0.shape[0], 1 if x1 is None else x1.shape[0], 1 if residual is None else residual.shape[0])
+    xs = [x0.expand(batch, -1, -1, -1)] + ([] if x1 is None else [x1.expand(batch, -1, -1, -1)])
+    x = torch.cat(xs, 1).double()
+    if relu_in:
+        x = F.relu(x)
+    y = F.conv2d(x, emu_ops._unpack(pc).double(), None if pc.bias is None else pc.bias.double(), stride=stride, padding=pad)
+    if residual is not None:
+        y = y + residual.double()
+    return emu_ops._act(y, act)
+
+
+# --f16_split: the hi/lo fp16 split (csrc/conv_f16.hip, PREC 2) is held to the SAME bound as the fp32 kernels against the
+# SAME reference (fp32 F.conv2d on the CPU), over the same cases; the eligible ones among them run on the f16 pipes
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+def test_conv_split_matches_cpu(case):
+    name, c0, c1, cout, k, stride, pad, batch, H, W, bcast0, relu_in, res, act, bias, bn = case
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 100000)
+    cin = c0 + c1
+    w = rand(g, cout, cin, k, k, scale=(2.0 / (cin * k * k))**0.5)
+    b = rand(g, cout, scale=0.1) if bias else None
+    bn_p = None
+    if bn:
+        bn_p = (torch.rand(cout, generator=g) + 0.5, rand(g, cout, scale=0.1), rand(g, cout, scale=0.1),
+                torch.rand(cout, generator=g) + 0.5, 1e-5)
+    pc = ops.pack_conv(w, b, bn_p, split=True)
+    x0 = rand(g, 1 if bcast0 else batch, c0, H, W)
+    x1 = rand(g, batch, c1, H, W) if c1 else None
+    oh, ow = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    residual = None
+    if res == 'full':
+        residual = rand(g, batch, cout, oh, ow)
+    elif res == 'bcast':
+        residual = rand(g, 1, cout, oh, ow)
+        x0 = rand(g, batch, c0, H, W)
+    want = emu_ops.conv2d(pc, x0, x1, stride=stride, pad=pad, relu_in=relu_in, residual=residual, act=act)
+    before = ops.split_fallbacks(dev())
+    got = ops.conv2d(to_dev(pc), _guarded(x0), _guarded(x1), stride=stride, pad=pad, relu_in=relu_in,
+                     residual=to_dev(residual), act=act, split=True)
+    torch.cuda.synchronize()
+    assert not torch.isnan(got).any(), f'{name}: guard-band values leaked into the result'
+    err = max_err(got, want)
+    print(f'{name}: split={split_takes(pc, x0, x1, stride, pad)} max abs err {err:.3e} (|ref|max {want.abs().max().item():.3e})')
+    assert err <= 2e-5 * max(1.0, want.abs().max().item()), (name, err)
+    assert ops.split_fallbacks(dev()) == before, 'inputs inside the fp16 range must not fall back'
+
+
+# shapes the split kernels take, one per tile / kind / K-loop form; against the fp64 convolution the split result must be
+# as close as the fp32 kernels' own (both are fp32-round-off class: the bound is 2x the fp32 kernels' error + 1e-6)
+# (name, c0, c1, cout, k, batch, H, W, bcast0, relu_in, residual, act, in_scale)
+SPLIT_CASES = [
+    ('split_1x1_64tile', 64, 0, 64, 1, 1, 6, 8, False, False, 'none', ops.ACT_NONE, 1.0),
+    ('split_1x1_32ch_cat', 32, 96, 72, 1, 3, 6, 10, True, False, 'full', ops.ACT_RELU, 1.0),
+    ('split_1x1_res_relu', 256, 0, 1024, 1, 1, 30, 54, False, False, 'full', ops.ACT_RELU, 1.0),
+    ('split_3x3_rowwrap', 64, 0, 64, 3, 2, 6, 10, False, True, 'full', ops.ACT_NONE, 1.0),
+    ('split_3x3_cat_relu_in', 512, 256 + 32, 512, 3, 2, 6, 8, True, True, 'none', ops.ACT_NONE, 1.0),
+    ('split_3x3_gru', 512, 512, 1536, 3, 2, 6, 8, False, False, 'none', ops.ACT_NONE, 1.0),
+    ('split_3x3_tile128', 256, 0, 128, 3, 4, 60, 108, False, True, 'full', ops.ACT_NONE, 1.0),
+    ('split_3x3_tile256', 256, 0, 256, 3, 5, 120, 216, False, True, 'full', ops.ACT_NONE, 1.0),
+    ('split_1x1_tile256', 512, 0, 256, 1, 5, 120, 216, False, False, 'none', ops.ACT_SIGMOID, 1.0),
+    ('split_3x3_splitk', 256, 0, 256, 3, 1, 30, 54, False, False, 'none', ops.ACT_RELU, 1.0),
+    ('split_1x1_splitk', 1024, 0, 256, 1, 1, 30, 54, False, False, 'none', ops.ACT_RELU, 1.0),
+    ('split_small_inputs', 256, 0, 256, 3, 2, 12, 16, False, False, 'none', ops.ACT_NONE, 1e-4),
+    ('split_large_inputs', 256, 0, 256, 3, 2, 12, 16, False, False, 'none', ops.ACT_NONE, 3e3),
+    ('split_ragged_cout', 96, 32, 200, 3, 2, 20, 36, True, True, 'full', ops.ACT_RELU, 1.0),
+]
+
+
+@pytest.mark.parametrize('case', SPLIT_CASES, ids=[c[0] for c in SPLIT_CASES])
+def test_conv_split_is_fp32_accurate(case):
+    name, c0, c1, cout, k, batch, H, W, bcast0, relu_in, res, act, in_scale = case
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 100000)
+    cin, pad = c0 + c1, k // 2
+    w = rand(g, cout, cin, k, k, scale=(2.0 / (cin * k * k))**0.5)
+    w.view(-1)[::5] *= 1e-3  # weights far below the layer's largest: their lo planes sit in the fp16 subnormals
+    b = rand(g, cout, scale=0.1)
+    pc = ops.pack_conv(w, b, None, split=True)
+    x0 = rand(g, 1 if bcast0 else batch, c0, H, W, scale=in_scale)
+    x1 = rand(g, batch, c1, H, W, scale=in_scale) if c1 else None
+    residual = rand(g, batch, cout, H, W) if res == 'full' else None
+    assert split_takes(pc, x0, x1, 1, pad), 'the case must run on the split kernels'
+    want = _conv64(pc, x0, x1, 1, pad, relu_in, residual, act)
+    before = ops.split_fallbacks(dev())
+    got = ops.conv2d(to_dev(pc), _guarded(x0), _guarded(x1), pad=pad, relu_in=relu_in, residual=to_dev(residual), act=act,
+                     split=True)
+    f32 = ops.conv2d(to_dev(pc), _guarded(x0), _guarded(x1), pad=pad, relu_in=relu_in, residual=to_dev(residual), act=act)
+    torch.cuda.synchronize()
+    assert not torch.isnan(got).any(), f'{name}: guard-band values leaked into the result'
+    scale = max(1e-30, want.abs().max().item())
+    e_split = (got.double().cpu() - want).abs().max().item() / scale
+    e_f32 = (f32.double().cpu() - want).abs().max().item() / scale
+    print(f'{name}: max err / |ref|max against fp64: split {e_split:.3e}, fp32 kernels {e_f32:.3e}')
+    assert e_split <= 2.0 * e_f32 + 1e-6, (name, e_split, e_f32)
+    assert ops.split_fallbacks(dev()) == before
+
+
+@pytest.mark.parametrize('poison', [7.0e4, -1.0e6, float('inf'), float('nan')], ids=['70000', '-1e6', 'inf', 'nan'])
+@pytest.mark.parametrize('k', [1, 3])
+def test_conv_split_falls_back_beyond_the_fp16_range(poison, k):
+    """one input element beyond +-65504 (or non-finite): the split kernel raises its flag and the fp32 kernels, launched
+    behind it and gated on the flag, produce the output -- bit-identical to the plain fp32 call"""
+    g = torch.Generator().manual_seed(11 + k)
+    w = rand(g, 128, 128, k, k, scale=0.05)
+    pc = to_dev(ops.pack_conv(w, rand(g, 128, scale=0.1), None, split=True))
+    x = rand(g, 2, 128, 24, 32)
+    x[1, 77, 13, 5] = poison
+    xd = _guarded(x)
+    before = ops.split_fallbacks(dev())
+    got = ops.conv2d(pc, xd, pad=k // 2, act=ops.ACT_RELU, split=True)
+    f32 = ops.conv2d(pc, xd, pad=k // 2, act=ops.ACT_RELU)
+    torch.cuda.synchronize()
+    assert ops.split_fallbacks(dev()) == before + 1
+    assert torch.equal(got.isnan(), f32.isnan()) and torch.equal(got.nan_to_num(0.0), f32.nan_to_num(0.0))
+    # the next call with clean inputs gets a fresh flag
+    x[1, 77, 13, 5] = 0.5
+    got = ops.conv2d(pc, _guarded(x), pad=k // 2, act=ops.ACT_RELU, split=True)
+    torch.cuda.synchronize()
+    assert ops.split_fallbacks(dev()) == before + 1 and bool(torch.isfinite(got).all())
+
+
+def test_conv_split_flag_ring_wraps():
+    """more split convolutions than the ring has slots: the raised flags survive in the running total"""
+    g = torch.Generator().manual_seed(3)
+    pc = to_dev(ops.pack_conv(rand(g, 64, 64, 1, 1, scale=0.1), None, None, split=True))
+    x = rand(g, 1, 64, 8, 8)
+    x[0, 3, 2, 1] = 1.0e5
+    bad, good = _guarded(x), _guarded(rand(g, 1, 64, 8, 8))
+    before = ops.split_fallbacks(dev())
+    for i in range(ops._SPLIT_RING + 50):
+        ops.conv2d(pc, bad if i % 1000 == 0 else good, split=True)
+    torch.cuda.synchronize()
+    assert ops.split_fallbacks(dev()) == before + (ops._SPLIT_RING + 50 + 999) // 1000
+
+
 def test_conv_rejects_cpu_tensors():
     pc = ops.pack_conv(torch.zeros(32, 16, 1, 1))
     with pytest.raises(Exception):

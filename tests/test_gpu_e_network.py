@@ -17,7 +17,7 @@ import torch
 
 import memory_audit
 import scenarios
-from gpu_util import dev, max_err
+from gpu_util import dev, max_err, net_config
 from oracle import deva_oracle as O
 from workload import synth
 
@@ -29,7 +29,7 @@ torch.set_grad_enabled(False)
 def network(recipe_state_dict):
     from deva.model.network import DEVA
     sd, _ = recipe_state_dict
-    net = DEVA(synth.base_config())
+    net = DEVA(net_config())
     net.load_weights(sd)
     return net.to(dev()).eval()
 
@@ -41,7 +41,7 @@ _Drift = memory_audit.Drift
 @pytest.fixture(scope='module')
 def peaky_network(peaky_state_dict):
     from deva.model.network import DEVA
-    net = DEVA(synth.base_config())
+    net = DEVA(net_config())
     net.load_weights(peaky_state_dict)
     return net.to(dev()).eval()
 
@@ -274,6 +274,47 @@ def test_amp_lockstep_teacher_forced(recipe_state_dict):
     print(f'amp vs fp32 (oracle, one decoder pass at 480p): logits {float((lg16 - lg32).abs().max()):.2e}, '
           f'prob {float((pr16 - pr32).abs().max()):.2e}')
     assert float((pr16 - pr32).abs().max()) <= 2e-2
+
+
+@pytest.fixture(scope='module')
+def split_network(recipe_state_dict):
+    """the network with --f16_split: value encoder and mask decoder on the hi/lo fp16 split kernels"""
+    from deva.model.network import DEVA
+    net = DEVA(dict(synth.base_config(), f16_split=True))
+    net.load_weights(recipe_state_dict[0])
+    return net.to(dev()).eval()
+
+
+def test_f16_split_lockstep_teacher_forced(split_network, recipe_state_dict):
+    """--f16_split: fp32-ACCURATE convolutions on the f16 matrix pipes in the value encoder and the mask decoder
+    (csrc/conv_f16.hip, PREC 2).  Every stage of every frame teacher-forced against the FP32 oracle with the bounds of
+    the fp32 lock-step (2e-4 relative per stage, 1e-3 on logits and probabilities) at 480p and at 1080p; no
+    convolution may have fallen back to the fp32 kernels (recipe activations sit far inside the fp16 range)."""
+    import lockstep
+    from deva.hip import ops
+    P, _ = recipe_state_dict
+    before = ops.split_fallbacks(dev())
+    worst = lockstep.run(split_network, P, 480, 864, 3, 6, dev())
+    print('f16_split lockstep 480p worst relative errors:', json.dumps({k: float(f'{v:.2e}') for k, v in worst.items()}))
+    worst = lockstep.run(split_network, P, 1088, 1920, 1, 2, dev())
+    print('f16_split lockstep 1080p worst relative errors:', json.dumps({k: float(f'{v:.2e}') for k, v in worst.items()}))
+    assert ops.split_fallbacks(dev()) == before
+
+
+@pytest.mark.parametrize('name', ['lt_evict', 'five_obj'])
+def test_f16_split_e2e_against_reference_golden(split_network, golden_dir, recipe_state_dict, name):
+    """free-running clips of the reference's goldens under --f16_split, same gate as the fp32 run"""
+    sc = scenarios.E2E[name]
+    g = np.load(os.path.join(golden_dir, f'e2e_{name}.npz'))
+    n = len(g['nchan'])
+    outs, _ = _scenario_against_golden(f'f16_split {name}', split_network, recipe_state_dict[0], sc,
+                                       [torch.from_numpy(g[f'prob_sub_{t}']) for t in range(n)])
+    assert [p.shape[0] for p in outs] == g['nchan'].tolist()
+
+
+def test_f16_split_480p_five_objects_against_oracle(split_network, recipe_state_dict):
+    """BASELINE configs[1] size, free-running against the tie-following oracle, under --f16_split"""
+    _five_objects_480p('f16_split 480p/5obj', split_network, recipe_state_dict[0], with_clean=False)
 
 
 def test_1080p_lockstep_teacher_forced(network, recipe_state_dict):

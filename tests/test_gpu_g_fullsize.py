@@ -18,7 +18,7 @@ import pytest
 import torch
 
 import memory_audit
-from gpu_util import dev, to_dev
+from gpu_util import dev, net_config, to_dev
 from deva.hip import ops
 from oracle import deva_oracle as O
 from workload import synth
@@ -33,7 +33,7 @@ torch.set_grad_enabled(False)
 def network(recipe_state_dict):
     from deva.model.network import DEVA
     sd, _ = recipe_state_dict
-    net = DEVA(synth.base_config())
+    net = DEVA(net_config())
     net.load_weights(sd)
     return net.to(dev()).eval()
 

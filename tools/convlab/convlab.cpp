@@ -101,6 +101,7 @@ typedef int (*conv_fn)(const deva_conv_desc*, void*);
 typedef int64_t (*pack_fn)(const float*, float*, int, int, int, int, int, int*, int*);
 typedef const char* (*err_fn)(void);
 typedef int64_t (*pack16_fn)(const float*, uint16_t*, int, int, int, int, int*);
+typedef int64_t (*packsp_fn)(const float*, uint16_t*, int, int, int, int, int*, int*);
 
 struct Lib {
   std::string path;
@@ -109,6 +110,7 @@ struct Lib {
   pack_fn pack;  // optional (newer libraries): deva_conv_pack of include/deva_hip.h
   err_fn err;
   pack16_fn pack16;  // optional: deva_conv_pack_f16 (amp path)
+  packsp_fn packsp;  // optional: deva_conv_pack_split (fp32-accurate hi/lo split on the f16 pipes)
 };
 
 static constexpr int64_t kGuard = 8192;  // like deva/hip/ops.py:_alloc
@@ -133,7 +135,7 @@ int main(int argc, char** argv) {
   std::string libs = "tracking-anything-with-deva_amd/deva/hip/libdeva_hip.so";
   std::string only, set = "frame480", shapes;
   int iters = 20;
-  bool check = false, csv = false, stamps = false, amp = false;
+  bool check = false, csv = false, stamps = false, amp = false, split = false, overflow = false;
   int keepalive_ms = 0;
   int rounds = 1;
   double warm_ms = 15.0, time_ms = 20.0;
@@ -149,6 +151,8 @@ int main(int argc, char** argv) {
     else if (a == "--csv") csv = true;
     else if (a == "--stamps") stamps = true;
     else if (a == "--amp") amp = true;  // fp16 operands on every library but the first (which stays the fp32 reference)
+    else if (a == "--split") split = true;  // hi/lo fp16 split (fp32-accurate) on every library but the first
+    else if (a == "--overflow") overflow = true;  // one input element beyond the fp16 range: the split path must fall back
     else if (a == "--keepalive" && i + 1 < argc) keepalive_ms = atoi(argv[++i]);
     else if (a == "--warm_ms" && i + 1 < argc) warm_ms = atof(argv[++i]);
     else if (a == "--time_ms" && i + 1 < argc) time_ms = atof(argv[++i]);
@@ -188,6 +192,7 @@ int main(int argc, char** argv) {
     l.pack = (pack_fn)dlsym(l.h, "deva_conv_pack");
     l.err = (err_fn)dlsym(l.h, "deva_hip_last_error");
     l.pack16 = (pack16_fn)dlsym(l.h, "deva_conv_pack_f16");
+    l.packsp = (packsp_fn)dlsym(l.h, "deva_conv_pack_split");
     if (!l.conv) { fprintf(stderr, "%s: no deva_conv2d\n", l.path.c_str()); return 1; }
     L.push_back(l);
     p = q + 1;
@@ -224,6 +229,7 @@ int main(int argc, char** argv) {
     fill(h_w, 3, sqrtf(6.0f / (cin * ly.k * ly.k)));
     fill(h_b, 4, 0.1f);
     fill(h_res, 5, 1.0f);
+    if (overflow) h_in0[h_in0.size() / 3] = 1.0e6f;  // beyond fp16: the split path raises its flag, the gated fp32 kernels redo the layer
     float* d_in0 = dev_alloc_guarded(in0_n, keep);
     float* d_in1 = ly.c1 ? dev_alloc_guarded(in1_n, keep) : nullptr;
     float* d_res = ly.res ? dev_alloc_guarded(out_n, keep) : nullptr;
@@ -306,6 +312,20 @@ int main(int argc, char** argv) {
           d.amp = 1;
         }
       }
+      if (split && li > 0 && l.packsp) {
+        int cp = 0, e = 0;
+        const int64_t n16 = l.packsp(h_w.data(), nullptr, ly.cout, cin, ly.k, ly.k, &cp, &e);
+        if (n16 > 0) {
+          std::vector<uint16_t> w16(n16);
+          l.packsp(h_w.data(), w16.data(), ly.cout, cin, ly.k, ly.k, &cp, &e);
+          float* d_w16 = dev_alloc_guarded((n16 + 1) / 2, keep);
+          HIP_OK(hipMemcpy(d_w16, w16.data(), n16 * 2, hipMemcpyHostToDevice));
+          d.weight_f16 = d_w16;
+          d.amp = 2;
+          d.split_scale_log2 = e;
+          d.split_flag = (int32_t*)dev_alloc_guarded(4, keep);  // zeroed
+        }
+      }
       int rc = 0;
       for (int w = 0; w < 2 && !rc; ++w) rc = l.conv(&d, st);
       if (rc) { printf(" | error: %s", l.err ? l.err() : "?"); continue; }
@@ -375,8 +395,11 @@ int main(int argc, char** argv) {
             ma = std::max(ma, dlt);
             mr = std::max(mr, dlt / (fabs((double)ref[i]) + 1.0));
           }
-          char buf[32];
-          snprintf(buf, sizeof buf, " d%.1e", mr);
+          char buf[48];
+          int flag = -1;
+          if (descs[li].split_flag) HIP_OK(hipMemcpy(&flag, descs[li].split_flag, 4, hipMemcpyDeviceToHost));
+          if (flag >= 0) snprintf(buf, sizeof buf, " d%.1e f%d", mr, flag);
+          else snprintf(buf, sizeof buf, " d%.1e", mr);
           tails[li] = buf;
         }
       }

@@ -55,7 +55,11 @@ struct ConvArgs {
   int per_split;     // K steps per split
   float* ws;         // [splits][cout][n_total]
   int64_t in0_span, in1_span;  // elements from the first to one past the last element of each input
-  const void* w16;   // conv_f16.hip: fp16 weights (DEVA_KLAYOUT_H8) or null
+  const void* w16;   // conv_f16.hip: fp16 weights (DEVA_KLAYOUT_H8; hi / lo planes for the split kernels) or null
+  int prec;          // conv_f16.hip: 1 = fp16 operands (amp), 2 = hi/lo split of both operands (fp32-accurate)
+  float out_scale;   // split kernels: 2^-e of the weight scale, applied (exactly) to the accumulators
+  int* flag;         // split kernels: set to 1 when an accumulator came out non-finite (an input beyond the fp16 range)
+  const int* gate;   // non-null: the launch does its work only when *gate != 0 (the fp32 re-run behind a split launch)
 };
 
 // cout tiles per tile-order group (conv_epilogue.h: conv_tile_coords).  With C workgroups of an XCD (resident at a time,
@@ -74,7 +78,8 @@ inline int conv_group_m(int taps, int stride, int bm, int bn, int64_t tiles) {
 int launch_splitk_reduce(const ConvArgs& p, hipStream_t st);
 // conv_mfma.hip: lean-loop kernels for weights in the k-quad layout (DEVA_KLAYOUT_Q4)
 int launch_conv_q4(const ConvArgs& a, hipStream_t st);
-// conv_f16.hip: fp16-operand kernels (opt-in amp path); -1 = shape not eligible, run the fp32 kernels
+// conv_f16.hip: fp16-operand kernels (opt-in amp path, a.prec == 1) and the hi/lo split kernels (a.prec == 2: fp32-accurate
+// on the f16 matrix pipes); -1 = shape not eligible, run the fp32 kernels
 int launch_conv_f16(const ConvArgs& a, hipStream_t st);
 
 }  // namespace deva

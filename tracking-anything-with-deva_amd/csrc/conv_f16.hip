@@ -1,20 +1,35 @@
-// Implicit-GEMM convolution with fp16 OPERANDS and fp32 accumulation: v_mfma_f32_32x32x16_f16 (16x the fp32 matrix
-// rate of gfx950).  The opt-in `--amp` path (deva/inference/eval_args.py:17, evaluation/eval_vos.py:137: the reference
-// wraps its frame loop in fp16 autocast): activations stay fp32 in HBM and are rounded to fp16 (RNE) while they are
-// staged, the weights are packed as fp16 once, products are exact in fp32, sums / bias / residual / activation / output
-// are fp32 -- the arithmetic the oracle's amp mode restates (conv inputs and weights rounded to fp16).
+// Implicit-GEMM convolution on the f16 matrix pipes of gfx950 (v_mfma_f32_32x32x16_f16: 16x the fp32 matrix rate), fp32
+// accumulation.  Two precisions, one tile machinery:
 //
-// Same tile machinery as conv_mfma.hip (buffer-addressed staging two K steps ahead, barrier before the last MFMA
-// group, row reuse of the 3x3 path with the zero column, compile-time buffer indices), with
-//   * 64-deep K steps (four MFMA K-blocks of 16): an fp16 K step of 32 would be 128 matrix-pipe cycles per wave,
-//     less than the barrier and the staging around it cost;
-//   * weights Wh[K/8][cout_pad][8] fp16 (DEVA_KLAYOUT_H8: eight consecutive k of one output channel = 16 bytes = the
-//     A fragment of one lane for one K-block), K ordered in 64-channel slabs for kernels larger than 1x1;
-//   * the activation tile as Bs[k/8][pixel][8] fp16: every thread gathers EIGHT channels x two pixels (eight 8-byte
-//     fp32 loads), converts, and writes one 16-byte octet per pixel -- the transposition costs no shuffles, only the
-//     register naming of the converts; a lane's B fragment of a K-block is one ds_read_b128.
+// PREC 1 -- fp16 OPERANDS (the opt-in `--amp` path; deva/inference/eval_args.py:17, evaluation/eval_vos.py:137: the
+//   reference wraps its frame loop in fp16 autocast): activations stay fp32 in HBM and are rounded to fp16 (RNE) while
+//   they are staged, the weights are packed as fp16 once, products are exact in fp32, sums / bias / residual /
+//   activation / output are fp32 -- the arithmetic the oracle's amp mode restates.
+//
+// PREC 2 -- fp32-ACCURATE on the f16 pipes (hi/lo operand split; the arithmetic of nn.Conv2d in fp32, big_modules.py:
+//   54-212, modules.py:81-169, to fp32 round-off): every fp32 activation x is split while it is staged into
+//   hi = fp16(x), lo = fp16(x - hi) (x - hi is exact in fp32; |x - hi - lo| <= max(2^-22 |x|, 2^-25)), the weights are
+//   packed once as hi / lo fp16 planes of w * 2^e (e per layer: the largest weight lands in [2^13, 2^14], which keeps
+//   the lo plane of every weight that matters out of the fp16 subnormals), and each K-block issues THREE MFMAs into the
+//   same fp32 accumulator: hi.hi + hi.lo + lo.hi (fp16 x fp16 products are exact in fp32; the dropped lo.lo term is
+//   <= 2^-22 |x w|).  The accumulators are scaled by 2^-e (exact) before bias / residual / activation.  An input beyond
+//   the fp16 range (|x| > 65504) or a non-finite one turns hi into inf / NaN, which reaches every accumulator that
+//   reads it: the kernel raises a device flag when an accumulator is not finite, and the caller runs the fp32 kernels
+//   behind this launch, gated on that flag (ConvArgs::gate), so the result is the fp32 kernels' in that case.
+//
+// Same structure as conv_mfma.hip (buffer-addressed staging two K steps ahead, barrier before the last MFMA group, row
+// reuse of the 3x3 path with the zero column, compile-time buffer indices), with
+//   * BKH-deep K steps: 64 for PREC 1 (an fp16 K step of 32 would be 128 matrix-pipe cycles per wave, less than the
+//     barrier and the staging around it cost), 32 for PREC 2 (three MFMAs per K-block: 384 cycles per wave and step on
+//     the 64x32 wave tile, 768 on the 128x32 one, at the LDS footprint of the amp tile);
+//   * weights W16[K/8][NPL][cout_pad][8] fp16 (NPL = 1: DEVA_KLAYOUT_H8; NPL = 2: hi plane, lo plane): eight consecutive
+//     k of one output channel = 16 bytes = the A fragment of one lane for one K-block; K ordered in BKH-channel slabs
+//     for kernels larger than 1x1;
+//   * the activation tile as Bs[k/8][NPL][pixel][8] fp16: every thread gathers EIGHT channels x PX pixels, converts
+//     (splits), and writes one 16-byte octet per pixel and plane -- the transposition costs no shuffles, only the
+//     register naming of the converts; a lane's B fragment of a K-block is one ds_read_b128 per plane.
 // Kinds: 0 = 1x1 stride 1, 1 = 3x3 stride 1 pad 1 (row reuse); both on guard-banded inputs whose channel counts are
-// multiples of 64.  Everything else stays on the fp32 kernels (the caller falls back).
+// multiples of BKH.  Everything else stays on the fp32 kernels (the caller falls back).
 #include <type_traits>
 
 #include "conv_epilogue.h"
@@ -24,9 +39,8 @@ namespace {
 
 typedef conv_f32x16 f32x16;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-
-constexpr int BKH = 64;  // K step
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
@@ -38,26 +52,33 @@ __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, int voff, i
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int KIND, int MINW>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KIND, int MINW, int BKH, int PREC>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(const ConvArgs p) {
   constexpr int THREADS = 64 * WAVES_M * WAVES_N;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
   static_assert(TM >= 1 && TN == 1, "wave tile: one pixel per lane");
   constexpr bool ROW = KIND == 1;
+  constexpr bool SPLIT = PREC == 2;
+  constexpr int NPL = SPLIT ? 2 : 1;               // operand planes: (hi, lo) or the rounded value alone
   constexpr int OCT = BKH / 8;                     // k-octets per K step
-  constexpr int A_V4 = OCT * BM / THREADS;         // 16-byte loads of the weight tile per thread and K step
-  constexpr int A_PASS = THREADS / BM;             // octet rows per pass
-  static_assert(A_V4 >= 1 && A_V4 * THREADS == OCT * BM, "weight tile geometry");
+  constexpr int NKB = BKH / 16;                    // MFMA K-blocks per K step
+  static_assert(NKB == 2 || NKB == 4, "K step of 32 or 64");
+  constexpr int AROWS = OCT * NPL;                 // 16-byte rows of the weight tile per output channel and K step
+  constexpr int A_V4 = AROWS * BM / THREADS;       // 16-byte loads of the weight tile per thread and K step
+  constexpr int A_PASS = THREADS / BM;             // rows per pass
+  static_assert(A_V4 >= 1 && A_V4 * THREADS == AROWS * BM && A_PASS * BM == THREADS, "weight tile geometry");
   constexpr int BNP = ROW ? BN + 8 : BN;           // ROW: columns 3 .. BN+4 hold pixels n0-1 .. n0+BN, column 0 stays zero
-  constexpr int NQ = BN / 2;                       // pixel pairs per tile row
-  constexpr int TASKS = OCT * NQ;                  // (octet, pixel pair) gather tasks per tile: one per thread
-  static_assert(TASKS == THREADS, "one gather task per thread");
-  constexpr int A_HALFS = OCT * BM * 8, B_HALFS = OCT * BNP * 8;
+  constexpr int PX = OCT * BN / THREADS;           // pixels per gather task (eight channels each)
+  static_assert((PX == 1 || PX == 2) && PX * THREADS == OCT * BN, "one gather task per thread");
+  constexpr int NQ = BN / PX;                      // gather tasks per octet
+  constexpr int A_HALFS = AROWS * BM * 8, B_HALFS = OCT * NPL * BNP * 8;
 
   __shared__ __attribute__((aligned(16))) _Float16 smem[2 * A_HALFS + 2 * B_HALFS];
   _Float16* const sA = smem;
   _Float16* const sB = smem + 2 * A_HALFS;
+
+  if (p.gate && *p.gate == 0) return;  // (never set for these kernels today; same contract as the fp32 kernels)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -72,27 +93,27 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
 
-  // ---- weights: thread t loads octet row t / BM (+ A_PASS per pass), output channel m0 + t % BM
+  // ---- weights: thread t loads row t / BM (+ A_PASS per pass) of the step's AROWS rows, output channel m0 + t % BM
   const int a_voff = ((tid / BM) * p.cout_pad + m0 + (tid % BM)) * 16;
   const int a_pass_bytes = A_PASS * p.cout_pad * 16;
-  const int a_step_bytes = OCT * p.cout_pad * 16;
-  const int a_total_bytes = ((p.K + 7) >> 3) * p.cout_pad * 16;
+  const int a_step_bytes = AROWS * p.cout_pad * 16;
+  const int a_total_bytes = ((p.K + 7) >> 3) * NPL * p.cout_pad * 16;
 
-  // ---- gather task of this thread: octet `oct` (8 channels), pixels n0 + 2*vq, +1
+  // ---- gather task of this thread: octet `oct` (8 channels), pixels n0 + PX*vq .. + PX-1
   const int oct = tid / NQ, vq = tid % NQ;
   int b_voff0 = 0, b_voff1 = 0;
   {
-    const int n4 = n0 + 2 * vq;
-    const int nn = (n4 < p.n_total) ? n4 : 0;  // OHW % 4 == 0: a pair never straddles images or the end
+    const int n4 = n0 + PX * vq;
+    const int nn = (n4 < p.n_total) ? n4 : 0;  // PX == 2: OHW % 4 == 0, a pair never straddles images or the end
     const int b = nn / p.OHW;
     const int pix = nn - b * p.OHW;
     b_voff0 = (int)(((int64_t)b * p.bs0 + (int64_t)8 * oct * p.HW + pix) * 4);
     b_voff1 = (int)(((int64_t)b * p.bs1 + (int64_t)8 * oct * p.HW + pix) * 4);
   }
   const int b_row_bytes = (int)(p.HW * 4);
-  // ROW: halo pixels (n0-1, n0+BN) of every octet: 2 * OCT tasks of eight scalar loads, on the first threads
-  const bool has_halo = ROW && tid < 2 * OCT;
-  const int h_side = tid & 1, h_oct = (tid >> 1) % OCT;
+  // ROW: halo pixels (n0-1, n0+BN) of every channel of the step: 2 * BKH scalar loads, one each on the first threads
+  const bool has_halo = ROW && tid < 2 * BKH;
+  const int h_c = tid & 7, h_side = (tid >> 3) & 1, h_oct = (tid >> 4) % OCT;
   int h_voff0 = 0, h_voff1 = 0;
   unsigned cmask = 0;  // 9-bit validity mask (bit dy*3+dx) of the pixel this lane consumes
   if (ROW) {
@@ -100,8 +121,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
     nh = min(max(nh, 0), p.n_total - 1);
     const int b = nh / p.OHW;
     const int pix = nh - b * p.OHW;
-    h_voff0 = (int)(((int64_t)b * p.bs0 + (int64_t)8 * h_oct * p.HW + pix) * 4);
-    h_voff1 = (int)(((int64_t)b * p.bs1 + (int64_t)8 * h_oct * p.HW + pix) * 4);
+    h_voff0 = (int)(((int64_t)b * p.bs0 + (int64_t)(8 * h_oct + h_c) * p.HW + pix) * 4);
+    h_voff1 = (int)(((int64_t)b * p.bs1 + (int64_t)(8 * h_oct + h_c) * p.HW + pix) * 4);
     const int n = n0 + wn0 + l31;
     if (n < p.n_total) {
       const int px = n % p.OHW;
@@ -129,11 +150,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
   const int ks_last = ks0 + max(ksteps, 1) - 1;
 
   // ---- staging registers: two sets for the weights (loads two K steps ahead), one for the activation gather
-  constexpr int ASETS = 2;
+  constexpr int ASETS = (SPLIT && ROW) ? 1 : 2;  // (the split row kind is register-bound: weights one K step ahead)
   f32x4 ra[ASETS][A_V4];
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  f32x2 rb[8];     // eight channels x two pixels
-  float rh[ROW ? 8 : 1];  // halo threads: eight channels of their one pixel
+  float rb[8][PX];        // eight channels x PX pixels
+  float rh = 0.0f;        // halo threads: one channel of one halo pixel
 
   auto load_a = [&](int t_raw, auto setc) {
     constexpr int SET = decltype(setc)::value % ASETS;
@@ -143,7 +163,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
 #pragma unroll
     for (int i = 0; i < A_V4; ++i) ra[SET][i] = buf_load4(r, a_voff, i * a_pass_bytes);
   };
-  // activation tile of K step t (KIND 0) / the (64-channel slab, dy) row tile that starts at step t (KIND 1)
+  // activation tile of K step t (KIND 0) / the (BKH-channel slab, dy) row tile that starts at step t (KIND 1)
   auto load_b = [&](int t_raw) {
     const int t = min(t_raw, ks_last);
     int cbase = t * BKH, shift = 0;
@@ -156,12 +176,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
     const float* base = (first ? p.in0 : p.in1) + ((int64_t)(first ? cbase : cbase - p.c0) * p.HW + shift);
     const __amdgpu_buffer_rsrc_t r = make_rsrc(base, 0x7fffffff);
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
-      rb[c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, first ? b_voff0 : b_voff1, c * b_row_bytes, 0));
-    if (has_halo) {
-#pragma unroll
-      for (int c = 0; c < 8; ++c) rh[c] = buf_load1(r, first ? h_voff0 : h_voff1, c * b_row_bytes);
+    for (int c = 0; c < 8; ++c) {
+      if constexpr (PX == 2) {
+        const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, first ? b_voff0 : b_voff1, c * b_row_bytes, 0));
+        rb[c][0] = v[0];
+        rb[c][PX - 1] = v[1];
+      } else {
+        rb[c][0] = buf_load1(r, first ? b_voff0 : b_voff1, c * b_row_bytes);
+      }
     }
+    if (has_halo) rh = buf_load1(r, first ? h_voff0 : h_voff1, 0);
   };
   auto store_a = [&](auto setc) {
     constexpr int BUF = decltype(setc)::value, SET = BUF % ASETS;
@@ -169,52 +193,69 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
 #pragma unroll
     for (int i = 0; i < A_V4; ++i) *reinterpret_cast<f32x4*>(a + i * THREADS * 8) = ra[SET][i];
   };
-  // fp32 -> fp16 (round to nearest even, like torch's .half()), relu-on-load first; one 16-byte octet per pixel
+  // fp32 -> fp16 (round to nearest even, like torch's .half()), relu-on-load first; one 16-byte octet per pixel and plane.
+  // SPLIT: hi = fp16(v), lo = fp16(v - hi)
+  auto put_octet = [&](_Float16* bt, int o, int col, const float (&v8)[8]) {
+    h8 hi;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) hi[c] = (_Float16)v8[c];
+    *reinterpret_cast<h8*>(bt + ((o * NPL) * BNP + col) * 8) = hi;
+    if constexpr (SPLIT) {
+      h8 lo;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) lo[c] = (_Float16)(v8[c] - (float)hi[c]);
+      *reinterpret_cast<h8*>(bt + ((o * NPL + 1) * BNP + col) * 8) = lo;
+    }
+  };
   auto store_b = [&](int buf) {
     _Float16* bt = sB + buf * B_HALFS;
 #pragma unroll
-    for (int px = 0; px < 2; ++px) {
-      h8 o;
+    for (int px = 0; px < PX; ++px) {
+      float v8[8];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        float v = rb[c][px];
-        if (p.relu_in) v = fmaxf(v, 0.0f);
-        o[c] = (_Float16)v;
-      }
-      *reinterpret_cast<h8*>(bt + (oct * BNP + (ROW ? 4 : 0) + 2 * vq + px) * 8) = o;
+      for (int c = 0; c < 8; ++c) v8[c] = p.relu_in ? fmaxf(rb[c][px], 0.0f) : rb[c][px];
+      put_octet(bt, oct, (ROW ? 4 : 0) + PX * vq + px, v8);
     }
     if (has_halo) {
-      h8 o;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        float v = rh[c];
-        if (p.relu_in) v = fmaxf(v, 0.0f);
-        o[c] = (_Float16)v;
-      }
-      *reinterpret_cast<h8*>(bt + (h_oct * BNP + (h_side ? BN + 4 : 3)) * 8) = o;
+      const float v = p.relu_in ? fmaxf(rh, 0.0f) : rh;
+      const _Float16 hi = (_Float16)v;
+      _Float16* at = bt + ((h_oct * NPL) * BNP + (h_side ? BN + 4 : 3)) * 8 + h_c;
+      at[0] = hi;
+      if constexpr (SPLIT) at[BNP * 8] = (_Float16)(v - (float)hi);
     }
   };
 
-  // ---- fragments: lane (row or pixel l31, k-group half) holds k = 16*kb + 8*half + 0..7 of K-block kb: one ds_read_b128
-  const _Float16* const a_rd0 = sA + (half * BM + wm0 + l31) * 8;
-  const _Float16* const b_rd0 = sB + (half * BNP + wn0 + l31 + (ROW ? 3 : 0)) * 8;
-  const _Float16* const b_zero0 = sB + (half * BNP) * 8;
-  h8 fa[2][TM], fb[2];
+  // ---- fragments: lane (row or pixel l31, k-group half) holds k = 16*kb + 8*half + 0..7 of K-block kb, i.e. octet
+  // 2*kb + half: one ds_read_b128 per plane
+  const _Float16* const a_rd0 = sA + (half * NPL * BM + wm0 + l31) * 8;
+  const _Float16* const b_rd0 = sB + (half * NPL * BNP + wn0 + l31 + (ROW ? 3 : 0)) * 8;
+  const _Float16* const b_zero0 = sB + (half * NPL * BNP) * 8;
+  h8 fa[2][NPL][TM], fb[2][NPL];
   auto frag_load = [&](int set, const _Float16* a_rd, const _Float16* b_rd, int kb) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) fa[set][i] = *reinterpret_cast<const h8*>(a_rd + (2 * kb * BM + 32 * i) * 8);
-    fb[set] = *reinterpret_cast<const h8*>(b_rd + (2 * kb * BNP) * 8);
+    for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[set][pl][i] = *reinterpret_cast<const h8*>(a_rd + ((2 * kb * NPL + pl) * BM + 32 * i) * 8);
+      fb[set][pl] = *reinterpret_cast<const h8*>(b_rd + ((2 * kb * NPL + pl) * BNP) * 8);
+    }
   };
   auto mfma_block = [&](int set) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][i], fb[set], acc[i][0], 0, 0, 0);
+    for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][0][i], fb[set][0], acc[i][0], 0, 0, 0);
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][0][i], fb[set][NPL - 1], acc[i][0], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][NPL - 1][i], fb[set][0], acc[i][0], 0, 0, 0);
+    }
   };
 
   auto taps_of = [&](int t) { return (cmask >> (t % 9 / 3 * 3)) & 7u; };
   unsigned m3 = ROW ? taps_of(ks0) : 0u;
   const _Float16* b_cur = ROW ? ((m3 & 1u) ? b_rd0 : b_zero0) : b_rd0;
 
-  // One K step of four K-blocks; buffer / register-set indices are compile-time (see conv_mfma.hip).
+  // One K step of NKB K-blocks; buffer / register-set indices are compile-time (see conv_mfma.hip).  The staged next
+  // tile is written to LDS beside the second-to-last MFMA group, the barrier sits before the last one.
   auto step = [&](int s, auto dxc, auto parc, auto gbc) {
     constexpr int DX = decltype(dxc)::value, PAR = decltype(parc)::value, GB = decltype(gbc)::value;
     constexpr int DXN = ROW ? (DX + 1) % 3 : 0;
@@ -229,15 +270,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
     } else {
       b_nx = b_rd0 + (PAR ^ 1) * B_HALFS;
     }
-    frag_load(1, a_rd, b_cur, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_block(0);
-    __builtin_amdgcn_sched_barrier(0);
-    frag_load(0, a_rd, b_cur, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_block(1);
-    __builtin_amdgcn_sched_barrier(0);
-    frag_load(1, a_rd, b_cur, 3);
+    if constexpr (NKB == 4) {
+      frag_load(1, a_rd, b_cur, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_block(0);
+      __builtin_amdgcn_sched_barrier(0);
+      frag_load(0, a_rd, b_cur, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_block(1);
+      __builtin_amdgcn_sched_barrier(0);
+      frag_load(1, a_rd, b_cur, 3);
+    } else {
+      frag_load(1, a_rd, b_cur, 1);
+    }
     store_a(std::integral_constant<int, PAR ^ 1>{});
     if (ROW) {
       if (DX == 2) store_b(GB ^ 1);
@@ -265,8 +310,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
   using I2 = std::integral_constant<int, 2>;
 
   // ---- prologue
-  if (ROW) {
-    for (int i = tid; i < 2 * OCT * 8; i += THREADS) sB[(i / (OCT * 8)) * B_HALFS + ((i / 8) % OCT) * BNP * 8 + (i & 7)] = (_Float16)0.0f;
+  if (ROW) {  // the zero column (column 0) of every octet row, both buffers
+    constexpr int ZR = OCT * NPL;
+    for (int i = tid; i < 2 * ZR * 8; i += THREADS) sB[(i / (ZR * 8)) * B_HALFS + ((i / 8) % ZR) * BNP * 8 + (i & 7)] = (_Float16)0.0f;
   }
   load_a(ks0, I0{});
   load_b(ks0);
@@ -302,6 +348,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
     if (s < ksteps) step(s, I0{}, I0{}, I0{});
   }
 
+  if constexpr (SPLIT) {
+    // an operand beyond the fp16 range shows as a non-finite accumulator; undo the weight scale (exact: a power of two)
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        bad |= (__builtin_bit_cast(unsigned, acc[i][0][r]) & 0x7f800000u) == 0x7f800000u;
+        acc[i][0][r] *= p.out_scale;
+      }
+    if (bad && p.flag) atomicOr(p.flag, 1);
+  }
+
   if (p.vec_out && p.splits == 1) {  // (split-K partial sums: the direct stores measured 3-4 % faster on the layers that split)
     static_assert((THREADS / 64) * 4096 <= (2 * A_HALFS + 2 * B_HALFS) * 2, "one 4 KB output-stage scratch per wave fits the dead tile buffers");
     __syncthreads();  // every wave is done with the tiles
@@ -311,9 +370,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
   conv_store_tile<TM, TN>(p, acc, m0, wm0, n0, wn0, l31, half);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MINW>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MINW, int BKH, int PREC>
 int launch_tile_f16(const ConvArgs& a, int kind, hipStream_t st) {
   ConvArgs p = a;
+  p.gate = nullptr;
   p.tiles_m = (int)ceil_div(a.cout, BM);
   p.tiles_n = (int)ceil_div(a.n_total, BN);
   const int ksteps_total = (int)ceil_div(a.K, BKH);
@@ -321,9 +381,10 @@ int launch_tile_f16(const ConvArgs& a, int kind, hipStream_t st) {
   p.splits = 1;
   const int64_t blocks = (int64_t)p.tiles_m * p.tiles_n;
   p.group_m = conv_group_m(a.KH * a.KW, a.stride, BM, BN, blocks);
-  if (a.ws && blocks < 192 && ksteps_total >= 12) {  // few tiles, long K: deterministic split-K like the fp32 kernels
+  constexpr int STEPS_MIN = 384 / BKH;  // K steps a split must keep (6 at BKH 64)
+  if (a.ws && blocks < 192 && ksteps_total >= 2 * STEPS_MIN) {  // few tiles, long K: deterministic split-K like the fp32 kernels
     int64_t sp = ceil_div(512, blocks);
-    if (sp > ksteps_total / 6) sp = ksteps_total / 6;
+    if (sp > ksteps_total / STEPS_MIN) sp = ksteps_total / STEPS_MIN;
     if (sp > 16) sp = 16;
     const int64_t fit = a.ws_elems / ((int64_t)a.cout * a.n_total);
     if (sp > fit) sp = fit;
@@ -336,19 +397,20 @@ int launch_tile_f16(const ConvArgs& a, int kind, hipStream_t st) {
   }
   const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splits), block(64 * WAVES_M * WAVES_N);
   if (kind == 0) {
-    hipLaunchKernelGGL((conv_f16_kernel<BM, BN, WAVES_M, WAVES_N, 0, MINW>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((conv_f16_kernel<BM, BN, WAVES_M, WAVES_N, 0, MINW, BKH, PREC>), grid, block, 0, st, p);
   } else {
-    hipLaunchKernelGGL((conv_f16_kernel<BM, BN, WAVES_M, WAVES_N, 1, MINW>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((conv_f16_kernel<BM, BN, WAVES_M, WAVES_N, 1, MINW, BKH, PREC>), grid, block, 0, st, p);
   }
   if (p.splits > 1) return launch_splitk_reduce(p, st);
-  return check_launch("deva_conv2d (fp16 operands)");
+  return check_launch(PREC == 2 ? "deva_conv2d (fp16 hi/lo split)" : "deva_conv2d (fp16 operands)");
 }
 
 }  // namespace
 
 // -> 0 launched, 1 launch error, -1 not eligible (the caller runs the fp32 kernels)
 int launch_conv_f16(const ConvArgs& a, hipStream_t st) {
-  if (!a.w16 || !a.vec_ok || a.stride != 1 || a.cout < 64 || a.c0 % BKH || a.c1 % BKH) return -1;
+  const int bkh = a.prec == 2 ? 32 : 64;
+  if (!a.w16 || !a.vec_ok || a.stride != 1 || a.cout < 64 || a.c0 % bkh || a.c1 % bkh) return -1;
   int kind;
   if (a.KH == 1 && a.KW == 1) {
     kind = 0;
@@ -358,8 +420,25 @@ int launch_conv_f16(const ConvArgs& a, hipStream_t st) {
     return -1;
   }
   const int64_t blocks128 = ceil_div(a.cout, 128) * ceil_div(a.n_total, 128);
-  if (a.cout >= 128 && blocks128 >= 64) return launch_tile_f16<128, 128, 2, 4, 4>(a, kind, st);
-  return launch_tile_f16<64, 64, 2, 2, 2>(a, kind, st);
+  if (a.prec == 2) {
+#ifdef DEVA_CONV_PROBES  // `make PROBES=1`: A/B runs of the tile policy (tools/convlab)
+    static const int forced = [] {
+      const char* e = getenv("DEVA_SPLIT_TILE");
+      return e ? atoi(e) : 0;
+    }();
+    if (forced == 256 && a.cout >= 256) return launch_tile_f16<256, 128, 2, 4, 2, 32, 2>(a, kind, st);
+    if (forced == 128 && a.cout >= 128) return launch_tile_f16<128, 128, 2, 4, 4, 32, 2>(a, kind, st);
+    if (forced == 64) return launch_tile_f16<64, 64, 2, 2, 2, 32, 2>(a, kind, st);
+#endif
+    // 256x128 tiles (wave tile 128x32: 0.83 KB of LDS fragment reads per MFMA against 1.0 on the 64x32 wave tile, a
+    // quarter less weight + activation staging per flop) where they still give every CU a workgroup
+    const int64_t blocks256 = ceil_div(a.cout, 256) * ceil_div(a.n_total, 128);
+    if (a.cout % 256 == 0 && blocks256 >= 224) return launch_tile_f16<256, 128, 2, 4, 2, 32, 2>(a, kind, st);
+    if (a.cout >= 128 && blocks128 >= 64) return launch_tile_f16<128, 128, 2, 4, 4, 32, 2>(a, kind, st);
+    return launch_tile_f16<64, 64, 2, 2, 2, 32, 2>(a, kind, st);
+  }
+  if (a.cout >= 128 && blocks128 >= 64) return launch_tile_f16<128, 128, 2, 4, 4, 64, 1>(a, kind, st);
+  return launch_tile_f16<64, 64, 2, 2, 2, 64, 1>(a, kind, st);
 }
 
 }  // namespace deva

@@ -15,6 +15,7 @@
 // v_mfma_f32_32x32x2_f32:  A: lane l holds A[i = l&31][k = l>>5],  B: B[k = l>>5][j = l&31],
 // D: reg r of lane l is D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
 #include "conv_args.h"
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -53,6 +54,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
   constexpr int KTAB = 1024;  // MODE 2: k -> (channel | dy << 16 | dx << 24)
   __shared__ unsigned s_ktab[MODE == 2 ? KTAB : 1];
 
+  if (p.gate && *p.gate == 0) return;  // the fp32 re-run behind a split launch (conv_f16.hip) that raised no flag
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -537,6 +539,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8) ? 
 
 // out[b][m][pix] = act(sum_s ws[s][m][n] + bias[m] + residual), n = b*OHW + pix
 __global__ void splitk_reduce_kernel(const ConvArgs p) {
+  if (p.gate && *p.gate == 0) return;  // the fp32 re-run behind a split launch that stayed inside the fp16 range
   const int64_t total = (int64_t)p.cout * p.n_total;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int m = (int)(i / p.n_total);
@@ -663,6 +666,37 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
   DEVA_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "deva_conv2d: bad kernel geometry");
   DEVA_REQUIRE((d->k_layout & ~DEVA_KLAYOUT_Q4) == DEVA_KLAYOUT_TAP_MAJOR || (d->k_layout & ~DEVA_KLAYOUT_Q4) == DEVA_KLAYOUT_CHUNK32,
                "deva_conv2d: unknown k_layout %d", d->k_layout);
+  // the single-channel heads (conv_cout1.hip) read column 0 of [K][cout_pad]: deva_conv_pack never interleaves them
+  DEVA_REQUIRE(!(d->cout == 1 && (d->k_layout & DEVA_KLAYOUT_Q4)), "deva_conv2d: k-quad interleaved weights need cout > 1");
+  DEVA_REQUIRE(d->amp >= 0 && d->amp <= 2, "deva_conv2d: amp must be 0 (fp32), 1 (fp16 operands) or 2 (fp16 hi/lo split)");
+  DEVA_REQUIRE(d->amp != 2 || !d->weight_f16 || d->split_flag, "deva_conv2d: the split path needs a device flag (split_flag)");
+  {
+    // the vector-gather kernels address their inputs with 32-bit byte offsets from the tensor bases: a batch whose inputs
+    // span 2 GiB or more (many objects at 4K) runs as consecutive sub-batches
+    const int64_t hw = (int64_t)d->height * d->width;
+    const int64_t lim = (1ll << 29) - 1;
+    const int64_t span0 = (int64_t)(d->batch - 1) * d->in0_batch_stride + (int64_t)d->c0 * hw;
+    const int64_t span1 = d->c1 ? (int64_t)(d->batch - 1) * d->in1_batch_stride + (int64_t)d->c1 * hw : 0;
+    if ((span0 > lim || span1 > lim) && d->batch > 1) {
+      int64_t per = d->batch;
+      if (d->in0_batch_stride > 0) per = std::min(per, (lim - (int64_t)d->c0 * hw) / d->in0_batch_stride + 1);
+      if (d->c1 && d->in1_batch_stride > 0) per = std::min(per, (lim - (int64_t)d->c1 * hw) / d->in1_batch_stride + 1);
+      if (per >= 1 && per < d->batch) {
+        const int64_t oh = (d->height + 2 * d->pad - d->kh) / d->stride + 1, ow = (d->width + 2 * d->pad - d->kw) / d->stride + 1;
+        for (int64_t b0 = 0; b0 < d->batch; b0 += per) {
+          deva_conv_desc sub = *d;
+          sub.batch = (int32_t)std::min<int64_t>(per, d->batch - b0);
+          sub.in0 = d->in0 + b0 * d->in0_batch_stride;
+          if (d->in1) sub.in1 = d->in1 + b0 * d->in1_batch_stride;
+          if (d->residual) sub.residual = d->residual + b0 * d->residual_batch_stride;
+          sub.out = d->out + b0 * (int64_t)d->cout * oh * ow;
+          const int rc = deva_conv2d(&sub, stream);
+          if (rc) return rc;
+        }
+        return 0;
+      }
+    }
+  }
   ConvArgs a;
   a.in0 = d->in0;
   a.in1 = d->c1 ? d->in1 : nullptr;
@@ -714,6 +748,10 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
   a.ws = d->workspace;
   a.ws_elems = d->workspace ? d->workspace_elems : 0;
   a.w16 = d->amp ? d->weight_f16 : nullptr;
+  a.prec = a.w16 ? d->amp : 0;
+  a.out_scale = 1.0f;
+  a.flag = nullptr;
+  a.gate = nullptr;
   a.in0_span = (int64_t)(d->batch - 1) * a.bs0 + (int64_t)a.c0 * a.HW;
   a.in1_span = a.in1 ? (int64_t)(d->batch - 1) * a.bs1 + (int64_t)a.c1 * a.HW : 0;
 
@@ -754,13 +792,23 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
     if (rows3x3) return launch_conv3x3_cout1_rows(c, st);
     return launch_conv_cout1(c, st);
   }
-  if (a.w16 && a.cout > 1) {
-    // opt-in fp16 operands (fp32 accumulation): eligible shapes only, everything else stays exact fp32
-    DEVA_REQUIRE(a.in0_span < (1ll << 29) && a.in1_span < (1ll << 29),
-                 "deva_conv2d: fp16-operand path needs inputs below 2 GiB (32-bit buffer offsets)");
+  if (a.w16 && a.cout > 1 && a.in0_span < (1ll << 29) && a.in1_span < (1ll << 29)) {
+    // opt-in f16 matrix pipes (fp16 operands, or the fp32-accurate hi/lo split): eligible shapes only, everything else
+    // -- and inputs too large for 32-bit buffer offsets -- stays on the fp32 kernels
+    if (a.prec == 2) {
+      DEVA_REQUIRE(d->split_scale_log2 >= -120 && d->split_scale_log2 <= 120, "deva_conv2d: split_scale_log2 out of range");
+      a.out_scale = ldexpf(1.0f, -d->split_scale_log2);
+      a.flag = d->split_flag;
+    }
     const int rc = launch_conv_f16(a, st);
-    if (rc >= 0) return rc;
+    if (rc > 0 || (rc == 0 && a.prec != 2)) return rc;
+    // split launched: the fp32 kernels run behind it, gated on the flag it raises for inputs beyond the fp16 range
+    if (rc == 0) a.gate = a.flag;
   }
+  a.w16 = nullptr;
+  a.prec = 0;
+  a.out_scale = 1.0f;
+  a.flag = nullptr;
   if (a.k_layout & DEVA_KLAYOUT_Q4) {
     // buffer addressing: 32-bit byte offsets from the tensor bases
     DEVA_REQUIRE(a.in0_span < (1ll << 29) && a.in1_span < (1ll << 29),
@@ -843,6 +891,61 @@ extern "C" int64_t deva_conv_pack_f16(const float* w_oihw, uint16_t* out, int co
         uint16_t bits;
         __builtin_memcpy(&bits, &h, 2);
         out[((k >> 3) * cout_pad + m) * 8 + (k & 7)] = bits;
+      }
+  return elems;
+}
+
+// hi / lo fp16 planes of the split path (host side, model load): with s = 2^e, e such that the largest |w| * s lies in
+// [2^13, 2^14) (e = 0 for an all-zero layer), hi = fp16(w s), lo = fp16(w s - hi) (round to nearest even; w s and the
+// difference are exact in fp32), element (k, plane, m) at (((k/8)*2 + plane)*cout_pad + m)*8 + k%8; K order: tap-major
+// for 1x1, 32-channel slabs otherwise (k = ((c/32)*taps + tap)*32 + c%32).  Needs cin % 32 == 0, else -1: the layer
+// stays on the fp32 kernels.  *scale_log2 = e; deva_conv2d multiplies the accumulators by 2^-e.
+extern "C" int64_t deva_conv_pack_split(const float* w_oihw, uint16_t* out, int cout, int cin, int kh, int kw, int* cout_pad_out,
+                                        int* scale_log2) {
+  using namespace deva;
+  if (!w_oihw || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0 || !cout_pad_out || !scale_log2) {
+    set_error("deva_conv_pack_split: bad arguments");
+    return -1;
+  }
+  const int taps = kh * kw;
+  if (cin % 32 != 0) return -1;
+  const int K = taps * cin;
+  const int cout_pad = (cout + 31) / 32 * 32;
+  const int64_t elems = (int64_t)K * 2 * cout_pad;
+  *cout_pad_out = cout_pad;
+  float wmax = 0.0f;
+  const int64_t n = (int64_t)cout * cin * taps;
+  for (int64_t i = 0; i < n; ++i) {
+    const float v = fabsf(w_oihw[i]);
+    if (!(v <= 3.0e38f)) {
+      set_error("deva_conv_pack_split: non-finite weight");
+      return -1;
+    }
+    if (v > wmax) wmax = v;
+  }
+  int e = 0;
+  if (wmax > 0.0f) {
+    int x;
+    frexpf(wmax, &x);  // wmax = f * 2^x, f in [0.5, 1)
+    e = 14 - x;
+    if (e > 120) e = 120;
+    if (e < -120) e = -120;
+  }
+  *scale_log2 = e;
+  if (!out) return elems;
+  for (int64_t i = 0; i < elems; ++i) out[i] = 0;
+  for (int m = 0; m < cout; ++m)
+    for (int c = 0; c < cin; ++c)
+      for (int t = 0; t < taps; ++t) {
+        const int64_t k = taps > 1 ? ((int64_t)(c / 32) * taps + t) * 32 + c % 32 : c;
+        const float ws = ldexpf(w_oihw[((int64_t)m * cin + c) * taps + t], e);
+        const _Float16 hi = (_Float16)ws;
+        const _Float16 lo = (_Float16)(ws - (float)hi);
+        uint16_t bh, bl;
+        __builtin_memcpy(&bh, &hi, 2);
+        __builtin_memcpy(&bl, &lo, 2);
+        out[(((k >> 3) * 2 + 0) * cout_pad + m) * 8 + (k & 7)] = bh;
+        out[(((k >> 3) * 2 + 1) * cout_pad + m) * 8 + (k & 7)] = bl;
       }
   return elems;
 }

@@ -75,6 +75,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK, (KIND <= 1 || MINW < 2
   // VALU instruction per loaded element either way).  The 3x3 row kind is built as 0 and 2 (36 of the 97 VALU
   // instructions of its loop; worth 0.3-0.7 % on the GRU / fuser layers, tools/convlab --rounds 7); the 1x1 kind keeps
   // the run-time flag -- its loop came out 4 % slower without the instruction (register allocation).
+  if (p.gate && *p.gate == 0) return;  // the fp32 re-run behind a split launch (conv_f16.hip) that raised no flag
   const bool relu_in = RELU == 2 ? true : (RELU == 1 ? (p.relu_in != 0) : false);
   // (the scalar-gather kinds carry 64-bit pointers and per-element validity: two waves per SIMD, no spills)
   constexpr int THREADS = 64 * WAVES_M * WAVES_N;  // threads of one K-slice group

@@ -13,7 +13,7 @@ import torch
 from . import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQUARE_PLUS_ONE, KLAYOUT_CHUNK32, KLAYOUT_Q4, KLAYOUT_TAP_MAJOR,
                ConvDesc, DevaHipError, check, lib)
 
-__all__ = ['PackedConv', 'pack_conv', 'conv2d', 'maxpool3x3s2', 'upsample2x_add', 'area_downsample',
+__all__ = ['PackedConv', 'pack_conv', 'conv2d', 'split_fallbacks', 'maxpool3x3s2', 'upsample2x_add', 'area_downsample',
            'aggregate', 'softmax_channels', 'upsample4x_softmax', 'cbam', 'gru_update',
            'affinity_topk', 'affinity_dense', 'affinity_candidates', 'affinity_merge', 'usage_update', 'readout_sparse', 'bank_append', 'bank_gather_rows',
            'bank_export', 'rank', 'rank_select', 'evict_select', 'similarity_dense', 'softmax_columns',
@@ -81,6 +81,10 @@ class PackedConv:
     k_layout: int = KLAYOUT_TAP_MAJOR
     # opt-in amp path: the same weights rounded to fp16 in the layout of csrc/conv_f16.hip (None: the layer stays fp32)
     weight_f16: Optional[torch.Tensor] = None
+    # opt-in split path (fp32-accurate on the f16 matrix pipes): hi / lo fp16 planes of weight * 2^split_scale_log2
+    # (None: the layer stays on the fp32 kernels)
+    weight_split: Optional[torch.Tensor] = None
+    split_scale_log2: int = 0
 
 
 def pack_f16(w: torch.Tensor) -> Optional[torch.Tensor]:
@@ -101,8 +105,36 @@ def pack_f16(w: torch.Tensor) -> Optional[torch.Tensor]:
     return wk.view(-1, 8, cout_pad).permute(0, 2, 1).contiguous().to(torch.float16).reshape(-1)
 
 
+def pack_split(w: torch.Tensor) -> Tuple[Optional[torch.Tensor], int]:
+    """[cout][cin][kh][kw] fp32 (BatchNorm already folded) -> (hi / lo fp16 planes of the split kernels, e): with
+    s = 2^e such that max|w| * s lies in [2^13, 2^14), hi = fp16(w s), lo = fp16(w s - hi); element (k, plane, m) at
+    (((k/8)*2 + plane)*cout_pad + m)*8 + k%8; K tap-major for 1x1, 32-channel slabs otherwise
+    (k = ((c/32)*taps + tap)*32 + c%32).  (None, 0) when the kernels cannot take the layer (cin % 32 != 0, a single
+    output channel, non-finite weights).  Same arithmetic as deva_conv_pack_split."""
+    import math
+    cout, cin, kh, kw = w.shape
+    taps = kh * kw
+    if cin % 32 or cout < 2 or not bool(torch.isfinite(w).all()):
+        return None, 0
+    wmax = float(w.abs().max())
+    e = 0
+    if wmax > 0.0:
+        e = max(-120, min(120, 14 - math.frexp(wmax)[1]))
+    cout_pad = (cout + 31) // 32 * 32
+    wk = torch.zeros(taps * cin, cout_pad, dtype=torch.float32, device=w.device)
+    if taps > 1:
+        wk[:, :cout] = w.reshape(cout, cin // 32, 32, taps).permute(1, 3, 2, 0).reshape(-1, cout)
+    else:
+        wk[:, :cout] = w.reshape(cout, cin).t()
+    ws = torch.ldexp(wk, torch.tensor(e, dtype=torch.int32, device=w.device))  # exact: a power of two
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.float()).to(torch.float16)
+    planes = torch.stack([hi.view(-1, 8, cout_pad).permute(0, 2, 1), lo.view(-1, 8, cout_pad).permute(0, 2, 1)], 1)
+    return planes.contiguous().reshape(-1), e
+
+
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None,
-              device=None, amp: bool = False) -> PackedConv:
+              device=None, amp: bool = False, split: bool = False) -> PackedConv:
     """One-time weight preparation (model load, not the frame path): fold an eval-mode BatchNorm
     `bn = (gamma, beta, running_mean, running_var, eps)` into the convolution and repack
     [cout][cin][kh][kw] -> [kh*kw*cin][cout_pad]."""
@@ -131,12 +163,14 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
         packed = packed.view(kq, 4, cout_pad).permute(0, 2, 1).contiguous().view(kq * 4, cout_pad)
         layout |= KLAYOUT_Q4
     w16 = pack_f16(w) if amp else None
+    wsp, e = pack_split(w) if split else (None, 0)
     if device is not None:
         packed = packed.to(device)
         b = None if b is None else b.to(device)
         w16 = None if w16 is None else w16.to(device)
+        wsp = None if wsp is None else wsp.to(device)
     return PackedConv(packed.contiguous(), None if b is None else b.contiguous(), cin, cout, cout_pad, kh, kw,
-                      layout, w16)
+                      layout, w16, wsp, e)
 
 
 GUARD = 8192  # floats of readable slack on both sides of every tensor this module allocates
@@ -150,7 +184,9 @@ def _alloc(shape, device) -> torch.Tensor:
         n *= int(s_)
     flat = torch.empty(n + 2 * GUARD, dtype=torch.float32, device=device)
     out = flat[GUARD:GUARD + n].view(*shape)
-    out._deva_guard = GUARD  # what _guard_elems would compute for this very object (views and slices of it recompute)
+    # what _guard_elems would compute for this very object (views and slices of it recompute), with the extent it holds
+    # for: an in-place metadata operation on the object (as_strided_, set_, resize_) must not keep a stale promise
+    out._deva_guard = (GUARD, out.data_ptr(), n)
     return out
 
 
@@ -159,8 +195,8 @@ def _guard_elems(t: Optional[torch.Tensor]) -> int:
     if t is None:
         return 1 << 30
     known = getattr(t, '_deva_guard', None)  # set by _alloc on the tensor object it returns: 3 us less per operand
-    if known is not None:
-        return known
+    if known is not None and known[1] == t.data_ptr() and known[2] == t.numel() and t.is_contiguous():
+        return known[0]
     first = t.storage_offset()
     last = first + sum((int(n) - 1) * int(st) for n, st in zip(t.shape, t.stride()))
     total = t.untyped_storage().nbytes() // 4
@@ -190,12 +226,47 @@ def _workspace(device) -> torch.Tensor:
     return ws
 
 
+_SPLIT_FLAGS = {}
+_SPLIT_RING = 4096  # flag slots per (device, stream); re-zeroed (one fill launch) every _SPLIT_RING split convolutions
+
+
+def _split_flag(device) -> int:
+    """device address of a zeroed int the next split convolution may raise (deva_conv_desc.split_flag): slots of a
+    per-(device, stream) ring; when the ring wraps, the raised slots are added to the ring's running total (slot
+    _SPLIT_RING, read by `split_fallbacks`) and the ring is cleared -- two launches per _SPLIT_RING convolutions"""
+    key = (device, _stream(device))
+    ent = _SPLIT_FLAGS.get(key)
+    if ent is None:
+        _make_room(_SPLIT_FLAGS)
+        ent = _SPLIT_FLAGS[key] = [torch.zeros(_SPLIT_RING + 1, dtype=torch.int32, device=device), 0]
+    ring, nxt = ent
+    if nxt == _SPLIT_RING:
+        ring[_SPLIT_RING:].add_(ring[:_SPLIT_RING].sum(dtype=torch.int32))
+        ring[:_SPLIT_RING].zero_()
+        nxt = 0
+    ent[1] = nxt + 1
+    return ring.data_ptr() + 4 * nxt
+
+
+def split_fallbacks(device) -> int:
+    """number of split convolutions on `device` (all streams of this process) whose inputs left the fp16 range, so
+    that the fp32 kernels behind them produced the output (synchronises: a statistic for tests and the bench)"""
+    total = 0
+    for (dev, _), (ring, _) in _SPLIT_FLAGS.items():
+        if torch.device(dev) == torch.device(device):
+            total += int(ring.sum().item())
+    return total
+
+
 def conv2d(pc: PackedConv, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *, stride: int = 1,
            pad: int = 0, relu_in: bool = False, residual: Optional[torch.Tensor] = None,
-           act: int = ACT_NONE, out: Optional[torch.Tensor] = None, amp: bool = False) -> torch.Tensor:
+           act: int = ACT_NONE, out: Optional[torch.Tensor] = None, amp: bool = False,
+           split: bool = False) -> torch.Tensor:
     """out = act(conv(cat([x0, x1], 1)) + bias + residual); batch-1 operands broadcast.
     amp: fp16 operands (inputs rounded while they are staged, `pc.weight_f16`) with fp32 accumulation where the fp16
-    kernels take the shape, exact fp32 otherwise (include/deva_hip.h: deva_conv_desc.amp)."""
+    kernels take the shape, exact fp32 otherwise (include/deva_hip.h: deva_conv_desc.amp).
+    split: fp32-accurate arithmetic on the f16 matrix pipes (hi/lo fp16 split of both operands, `pc.weight_split`) where
+    the split kernels take the shape, the fp32 kernels otherwise and for inputs beyond the fp16 range (amp == 2)."""
     c0 = x0.shape[1]
     c1 = 0 if x1 is None else x1.shape[1]
     if c0 + c1 != pc.cin:
@@ -240,8 +311,12 @@ def conv2d(pc: PackedConv, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, 
     d.in_guard_elems = min(_guard_elems(x0), _guard_elems(x1), (1 << 31) - 1)
     ws = _workspace(out.device)
     d.workspace, d.workspace_elems = ws.data_ptr(), ws.numel()
+    d.split_scale_log2, d.split_flag = 0, None
     if amp and pc.weight_f16 is not None:
         d.weight_f16, d.amp = _p(pc.weight_f16, torch.float16, 'fp16 weight'), 1
+    elif split and pc.weight_split is not None:
+        d.weight_f16, d.amp = _p(pc.weight_split, torch.float16, 'fp16 hi/lo weight'), 2
+        d.split_scale_log2, d.split_flag = pc.split_scale_log2, _split_flag(out.device)
     else:
         d.weight_f16, d.amp = None, 0
     check(lib().deva_conv2d(d, _stream()), 'deva_conv2d')

@@ -16,6 +16,9 @@ _FLAGS = (
     ('save_all', None, False, 'Save all frames'),
     ('amp', None, False, 'fp16 operands / fp32 accumulation in the value encoder and the mask decoder (key encoder and '
                          'memory read stay fp32); off: everything fp32, the parity target'),
+    ('f16_split', None, False, 'extension: fp32-accurate convolutions on the f16 matrix pipes (hi/lo fp16 split of both '
+                               'operands, fp32 accumulation) in the value encoder and the mask decoder; held to the fp32 '
+                               'parity bounds, 2.5-3x the fp32 rate of those layers'),
     # network widths (C^k, C^v, pixel feature)
     ('key_dim', int, 64, None),
     ('value_dim', int, 512, None),

@@ -109,12 +109,19 @@ class CompiledGraph:
     # encoder and the key projection stay exact fp32 (the memory read's top-k stays bit-faithful), and so do the
     # reference's own fp32 islands (network.py:34 aggregate, big_modules.py:189 pred: a single-channel VALU kernel here)
     AMP_SCOPES = ('mask_encoder.', 'mask_decoder.')
+    # modules whose convolutions run the fp32-accurate hi/lo fp16 split on the f16 matrix pipes under --f16_split (the
+    # same two: 90 % of the frame's flop at 5 objects); the key encoder and the key projection stay on the fp32 kernels
+    # whose FMA order the affinity tests pin, so the inputs of the memory read's top-k do not move by a bit
+    SPLIT_SCOPES = AMP_SCOPES
 
-    def __init__(self, sd: Dict[str, torch.Tensor], device: torch.device, amp: bool = False):
+    def __init__(self, sd: Dict[str, torch.Tensor], device: torch.device, amp: bool = False, split: bool = False):
         ops.require_hip(device, 'DEVA network')
+        if amp and split:
+            raise ValueError('amp (fp16 operands) and f16_split (fp32-accurate on the f16 pipes) are alternatives: pick one')
         self.device = device
         self.sd = sd
         self.amp = bool(amp)
+        self.f16_split = bool(split)
         self.convs: Dict[str, PackedConv] = {}
         self.vecs: Dict[str, torch.Tensor] = {}
         for name in sd:
@@ -122,7 +129,7 @@ class CompiledGraph:
                 continue
             base = name[:-len('.weight')]
             self.convs[base] = ops.pack_conv(sd[name], sd.get(base + '.bias'), self._bn_after(base), device,
-                                             amp=self._amp_of(base))
+                                             amp=self._amp_of(base), split=self._split_of(base))
         for name, t in sd.items():
             if '.ChannelGate.mlp.' in name:
                 self.vecs[name] = t.detach().float().contiguous().to(device)
@@ -149,6 +156,9 @@ class CompiledGraph:
     def _amp_of(self, base: str) -> bool:
         return self.amp and base.startswith(self.AMP_SCOPES)
 
+    def _split_of(self, base: str) -> bool:
+        return self.f16_split and base.startswith(self.SPLIT_SCOPES)
+
     def _split_pack(self, base: str, cx: int) -> Tuple[PackedConv, PackedConv]:
         """(image part without bias, per-object part with the bias) of convolution `base`, BatchNorm folded"""
         w = self.sd[base + '.weight'].detach().float()
@@ -161,23 +171,24 @@ class CompiledGraph:
             shift = beta - mean * scale
             w = w * scale.view(-1, 1, 1, 1)
             b = shift if b is None else b * scale + shift
-        return (ops.pack_conv(w[:, :cx].contiguous(), None, None, self.device, amp=self._amp_of(base)),
-                ops.pack_conv(w[:, cx:].contiguous(), b, None, self.device, amp=self._amp_of(base)))
+        return (ops.pack_conv(w[:, :cx].contiguous(), None, None, self.device, amp=self._amp_of(base), split=self._split_of(base)),
+                ops.pack_conv(w[:, cx:].contiguous(), b, None, self.device, amp=self._amp_of(base), split=self._split_of(base)))
 
     def _conv(self, base: str, *inputs, **kw):
-        """convolution `base` of the value encoder / mask decoder: fp16 operands under --amp where eligible"""
-        return ops.conv2d(self.convs[base], *inputs, amp=self._amp_of(base), **kw)
+        """convolution `base` of the value encoder / mask decoder: fp16 operands under --amp, the hi/lo split under
+        --f16_split, where eligible"""
+        return ops.conv2d(self.convs[base], *inputs, amp=self._amp_of(base), split=self._split_of(base), **kw)
 
     def _conv_shared_x(self, base: str, x, g, **kw):
         """conv over the virtual cat(x broadcast, g): one launch for a single object, otherwise the image
         part once + the per-object part with it as the fused residual"""
-        amp = self._amp_of(base)
+        amp, sp = self._amp_of(base), self._split_of(base)
         if g.shape[0] < 2 or x.shape[0] != 1 or base not in self.split:
-            return ops.conv2d(self.convs[base], x, g, amp=amp, **kw)
+            return ops.conv2d(self.convs[base], x, g, amp=amp, split=sp, **kw)
         wx, wg = self.split[base]
         act = kw.pop('act', 0)  # the activation belongs to the sum of the two parts
-        shared = ops.conv2d(wx, x, amp=amp, **kw)
-        return ops.conv2d(wg, g, residual=shared, amp=amp, act=act, **kw)
+        shared = ops.conv2d(wx, x, amp=amp, split=sp, **kw)
+        return ops.conv2d(wg, g, residual=shared, amp=amp, split=sp, act=act, **kw)
 
     def _bn_after(self, conv: str):
         """the BatchNorm that follows `conv` in the ResNets: convN -> bnN, downsample.0 -> downsample.1"""

@@ -25,6 +25,12 @@ class DEVA(nn.Module):
         # value encoder and the mask decoder run their convolutions on fp16 operands with fp32 accumulation; key encoder,
         # key projection, memory read, aggregate and the mask-logit head stay fp32 (deva/model/_graph.py:AMP_SCOPES)
         self.amp = bool(config.get('amp', False))
+        # --f16_split (an extension, no counterpart in the reference): the same two modules run fp32-ACCURATE
+        # convolutions on the f16 matrix pipes (hi/lo fp16 split of both operands, three MFMAs per block, fp32
+        # accumulation; csrc/conv_f16.hip) -- held to the fp32 parity gates, 2.5-3x the fp32-MFMA rate
+        self.f16_split = bool(config.get('f16_split', False))
+        if self.amp and self.f16_split:
+            raise ValueError('--amp and --f16_split are alternatives: pick one')
         for name, module in build_parameter_tree(self.pix_feat_dim, self.key_dim, self.value_dim).items():
             self.add_module(name, module)
         for p in self.parameters():
@@ -48,7 +54,7 @@ class DEVA(nn.Module):
     def graph(self) -> CompiledGraph:
         if self._graph is None:
             device = next(self.parameters()).device
-            self._graph = CompiledGraph(self.state_dict(), device, amp=self.amp)
+            self._graph = CompiledGraph(self.state_dict(), device, amp=self.amp, split=self.f16_split)
         return self._graph
 
     # ------------------------------------------------------------------ reference API
