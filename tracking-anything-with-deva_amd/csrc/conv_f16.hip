@@ -150,7 +150,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
   const int ks_last = ks0 + max(ksteps, 1) - 1;
 
   // ---- staging registers: two sets for the weights (loads two K steps ahead), one for the activation gather
-  constexpr int ASETS = (SPLIT && ROW) ? 1 : 2;  // (the split row kind is register-bound: weights one K step ahead)
+  constexpr int ASETS = (SPLIT && ROW && BM < 256) ? 1 : 2;  // (the 128-wide split row kind is register-bound: weights one K step ahead)
   f32x4 ra[ASETS][A_V4];
   float rb[8][PX];        // eight channels x PX pixels
   float rh = 0.0f;        // halo threads: one channel of one halo pixel
@@ -239,14 +239,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
       fb[set][pl] = *reinterpret_cast<const h8*>(b_rd + ((2 * kb * NPL + pl) * BNP) * 8);
     }
   };
-  auto mfma_block = [&](int set) {
+  // the MFMAs of one K-block, in the order hi.hi (every row block), hi.lo, lo.hi; `part`: 0 = all, 1 = first half, 2 = rest
+  constexpr int MF = (SPLIT ? 3 : 1) * TM;
+  auto mfma_block = [&](int set, int part = 0) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][0][i], fb[set][0], acc[i][0], 0, 0, 0);
-    if constexpr (SPLIT) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][0][i], fb[set][NPL - 1], acc[i][0], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][NPL - 1][i], fb[set][0], acc[i][0], 0, 0, 0);
+    for (int j = 0; j < MF; ++j) {
+      if ((part == 1 && j >= MF / 2) || (part == 2 && j < MF / 2)) continue;
+      const int term = j / TM, i = j % TM;
+      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][term == 2 ? NPL - 1 : 0][i], fb[set][term == 1 ? NPL - 1 : 0], acc[i][0], 0, 0, 0);
     }
   };
 
@@ -280,29 +280,72 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
       mfma_block(1);
       __builtin_amdgcn_sched_barrier(0);
       frag_load(1, a_rd, b_cur, 3);
+      store_a(std::integral_constant<int, PAR ^ 1>{});
+      if (ROW) {
+        if (DX == 2) store_b(GB ^ 1);
+      } else {
+        store_b(PAR ^ 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_block(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      load_a(t + 1 + ASETS, std::integral_constant<int, PAR ^ 1>{});
+      if (ROW) {
+        if (DX == 0) load_b(t + 3);
+      } else {
+        load_b(t + 2);
+      }
+      frag_load(0, a_nx, b_nx, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_block(1);
+      __builtin_amdgcn_sched_barrier(0);
     } else {
+      // Two K-blocks of MF MFMAs per step, software-pipelined INSIDE the wave: the waves of a workgroup run in lock
+      // step (one barrier per step), so bursts of fragment reads never meet another wave's MFMA phase -- the LDS and
+      // the matrix pipe would take turns (measured: 0.45 MFMA utilisation, LDS 0.3 busy).  Every MFMA is followed by
+      // one LDS read of the next K-block / one LDS write or global load of the staged tiles.
+      // Region 1 (up to the barrier): fragments of K-block 1, MFMAs of K-block 0 and the first half of K-block 1, the
+      // staged tile -> LDS, the global loads of the tile after next (into the registers the stores have just freed).
       frag_load(1, a_rd, b_cur, 1);
+      mfma_block(0);
+      store_a(std::integral_constant<int, PAR ^ 1>{});
+      if (ROW) {
+        if (DX == 2) store_b(GB ^ 1);
+      } else {
+        store_b(PAR ^ 1);
+      }
+      load_a(t + 1 + ASETS, std::integral_constant<int, PAR ^ 1>{});
+      if (ROW) {
+        if (DX == 0) load_b(t + 3);
+      } else {
+        load_b(t + 2);
+      }
+      mfma_block(1, 1);
+      constexpr int NFR = (TM + 1) * NPL;  // LDS reads of one fragment set
+#pragma unroll
+      for (int j = 0; j < MF; ++j) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // MFMA
+        if (j < NFR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+      }
+#pragma unroll
+      for (int j = 0; j < MF / 2; ++j) {
+        __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);  // DS write
+        __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);  // VMEM read
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      // Region 2: fragments of the next step's K-block 0 under the second half of K-block 1
+      frag_load(0, a_nx, b_nx, 0);
+      mfma_block(1, 2);
+#pragma unroll
+      for (int j = 0; j < MF - MF / 2; ++j) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, (NFR + MF - MF / 2 - 1) / (MF - MF / 2), 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    store_a(std::integral_constant<int, PAR ^ 1>{});
-    if (ROW) {
-      if (DX == 2) store_b(GB ^ 1);
-    } else {
-      store_b(PAR ^ 1);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_block(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    load_a(t + 1 + ASETS, std::integral_constant<int, PAR ^ 1>{});
-    if (ROW) {
-      if (DX == 0) load_b(t + 3);
-    } else {
-      load_b(t + 2);
-    }
-    frag_load(0, a_nx, b_nx, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_block(1);
-    __builtin_amdgcn_sched_barrier(0);
     b_cur = b_nx;
   };
   using I0 = std::integral_constant<int, 0>;

@@ -804,6 +804,12 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
     if (rc > 0 || (rc == 0 && a.prec != 2)) return rc;
     // split launched: the fp32 kernels run behind it, gated on the flag it raises for inputs beyond the fp16 range
     if (rc == 0) a.gate = a.flag;
+#ifdef DEVA_CONV_PROBES  // `make PROBES=1`: what the gated launch costs (tools/convlab)
+    {
+      static const bool nogate = getenv("DEVA_SPLIT_NOGATE") != nullptr;
+      if (rc == 0 && nogate) return 0;
+    }
+#endif
   }
   a.w16 = nullptr;
   a.prec = 0;
