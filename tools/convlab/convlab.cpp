@@ -135,7 +135,7 @@ int main(int argc, char** argv) {
   std::string libs = "tracking-anything-with-deva_amd/deva/hip/libdeva_hip.so";
   std::string only, set = "frame480", shapes;
   int iters = 20;
-  bool check = false, csv = false, stamps = false, amp = false, split = false, overflow = false;
+  bool check = false, csv = false, stamps = false, amp = false, split = false, overflow = false, zero_in = false;
   int keepalive_ms = 0;
   int rounds = 1;
   double warm_ms = 15.0, time_ms = 20.0;
@@ -152,6 +152,7 @@ int main(int argc, char** argv) {
     else if (a == "--stamps") stamps = true;
     else if (a == "--amp") amp = true;  // fp16 operands on every library but the first (which stays the fp32 reference)
     else if (a == "--split") split = true;  // hi/lo fp16 split (fp32-accurate) on every library but the first
+    else if (a == "--zero_in") zero_in = true;  // all-zero activations (power probe: operand switching activity)
     else if (a == "--overflow") overflow = true;  // one input element beyond the fp16 range: the split path must fall back
     else if (a == "--keepalive" && i + 1 < argc) keepalive_ms = atoi(argv[++i]);
     else if (a == "--warm_ms" && i + 1 < argc) warm_ms = atof(argv[++i]);
@@ -229,6 +230,10 @@ int main(int argc, char** argv) {
     fill(h_w, 3, sqrtf(6.0f / (cin * ly.k * ly.k)));
     fill(h_b, 4, 0.1f);
     fill(h_res, 5, 1.0f);
+    if (zero_in) {
+      std::fill(h_in0.begin(), h_in0.end(), 0.0f);
+      std::fill(h_in1.begin(), h_in1.end(), 0.0f);
+    }
     if (overflow) h_in0[h_in0.size() / 3] = 1.0e6f;  // beyond fp16: the split path raises its flag, the gated fp32 kernels redo the layer
     float* d_in0 = dev_alloc_guarded(in0_n, keep);
     float* d_in1 = ly.c1 ? dev_alloc_guarded(in1_n, keep) : nullptr;

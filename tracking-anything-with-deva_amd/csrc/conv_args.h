@@ -60,6 +60,7 @@ struct ConvArgs {
   float out_scale;   // split kernels: 2^-e of the weight scale, applied (exactly) to the accumulators
   int* flag;         // split kernels: set to 1 when an accumulator came out non-finite (an input beyond the fp16 range)
   const int* gate;   // non-null: the launch does its work only when *gate != 0 (the fp32 re-run behind a split launch)
+  int ablate;        // `make PROBES=1` builds only (DEVA_SPLIT_ABLATE): timing runs with parts of the K loop switched off
 };
 
 // cout tiles per tile-order group (conv_epilogue.h: conv_tile_coords).  With C workgroups of an XCD (resident at a time,

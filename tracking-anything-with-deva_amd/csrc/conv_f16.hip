@@ -25,17 +25,27 @@
 //   * weights W16[K/8][NPL][cout_pad][8] fp16 (NPL = 1: DEVA_KLAYOUT_H8; NPL = 2: hi plane, lo plane): eight consecutive
 //     k of one output channel = 16 bytes = the A fragment of one lane for one K-block; K ordered in BKH-channel slabs
 //     for kernels larger than 1x1;
-//   * the activation tile as Bs[k/8][NPL][pixel][8] fp16: every thread gathers EIGHT channels x PX pixels, converts
-//     (splits), and writes one 16-byte octet per pixel and plane -- the transposition costs no shuffles, only the
-//     register naming of the converts; a lane's B fragment of a K-block is one ds_read_b128 per plane.
+//   * the activation tile as Bs[NPL][k/2][pixel][2] fp16 (k-pair rows, 4 bytes per pixel): every thread gathers TWO
+//     channels x FOUR consecutive pixels with two 16-byte loads (a vector-memory instruction costs the same ~16 cycles
+//     of the CU's address path whatever its width -- tools/probe/vmem_width_probe.hip: 120 wave-instructions per us and
+//     CU for 4, 8 or 16 bytes per lane -- and the 4-byte gathers of the first version kept that path 50 % busy),
+//     converts (splits) pairs of channels into packed halfs, and writes one 16-byte quad per plane; a lane's B
+//     fragment of a K-block is four 4-byte reads per plane (rows 8 kb + 4 half + 0..3, its own pixel column).
 // Kinds: 0 = 1x1 stride 1, 1 = 3x3 stride 1 pad 1 (row reuse); both on guard-banded inputs whose channel counts are
 // multiples of BKH.  Everything else stays on the fp32 kernels (the caller falls back).
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv_epilogue.h"
 
 namespace deva {
 namespace {
+
+#ifdef DEVA_CONV_PROBES  // timing-only ablations of the K loop (results are wrong): 1 LDS stores, 2 global loads (16: activations only, 32: weights only), 4 barrier, 8 fragments
+#define DEVA_ABL(bit) (p.ablate & (bit))
+#else
+#define DEVA_ABL(bit) false
+#endif
 
 typedef conv_f32x16 f32x16;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -57,7 +67,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
   constexpr int THREADS = 64 * WAVES_M * WAVES_N;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
-  static_assert(TM >= 1 && TN == 1, "wave tile: one pixel per lane");
+  static_assert(TM >= 1 && TN >= 1, "wave tile");
   constexpr bool ROW = KIND == 1;
   constexpr bool SPLIT = PREC == 2;
   constexpr int NPL = SPLIT ? 2 : 1;               // operand planes: (hi, lo) or the rounded value alone
@@ -69,10 +79,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
   constexpr int A_PASS = THREADS / BM;             // rows per pass
   static_assert(A_V4 >= 1 && A_V4 * THREADS == AROWS * BM && A_PASS * BM == THREADS, "weight tile geometry");
   constexpr int BNP = ROW ? BN + 8 : BN;           // ROW: columns 3 .. BN+4 hold pixels n0-1 .. n0+BN, column 0 stays zero
-  constexpr int PX = OCT * BN / THREADS;           // pixels per gather task (eight channels each)
-  static_assert((PX == 1 || PX == 2) && PX * THREADS == OCT * BN, "one gather task per thread");
-  constexpr int NQ = BN / PX;                      // gather tasks per octet
-  constexpr int A_HALFS = AROWS * BM * 8, B_HALFS = OCT * NPL * BNP * 8;
+  constexpr int KP = BKH / 2;                      // k-pair rows of the activation tile
+  constexpr int NQ4 = BN / 4;                      // pixel quads per row
+  constexpr int TPT = KP * NQ4 / THREADS;          // gather tasks (k-pair row, pixel quad) per thread
+  static_assert(TPT >= 1 && TPT * THREADS == KP * NQ4 && THREADS % NQ4 == 0, "activation gather geometry");
+  constexpr int RSTEP = THREADS / NQ4;             // k-pair rows between the tasks of one thread
+  constexpr int A_HALFS = AROWS * BM * 8, B_HALFS = NPL * KP * BNP * 2;
 
   __shared__ __attribute__((aligned(16))) _Float16 smem[2 * A_HALFS + 2 * B_HALFS];
   _Float16* const sA = smem;
@@ -99,38 +111,43 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
   const int a_step_bytes = AROWS * p.cout_pad * 16;
   const int a_total_bytes = ((p.K + 7) >> 3) * NPL * p.cout_pad * 16;
 
-  // ---- gather task of this thread: octet `oct` (8 channels), pixels n0 + PX*vq .. + PX-1
-  const int oct = tid / NQ, vq = tid % NQ;
+  // ---- gather tasks of this thread: k-pair rows kr0 + i * RSTEP (channels 2 r, 2 r + 1), pixels n0 + 4 * vq .. + 3
+  const int kr0 = tid / NQ4, vq = tid % NQ4;
   int b_voff0 = 0, b_voff1 = 0;
   {
-    const int n4 = n0 + PX * vq;
-    const int nn = (n4 < p.n_total) ? n4 : 0;  // PX == 2: OHW % 4 == 0, a pair never straddles images or the end
+    const int n4 = n0 + 4 * vq;
+    const int nn = (n4 < p.n_total) ? n4 : 0;  // OHW % 4 == 0: a quad never straddles images or the end
     const int b = nn / p.OHW;
     const int pix = nn - b * p.OHW;
-    b_voff0 = (int)(((int64_t)b * p.bs0 + (int64_t)8 * oct * p.HW + pix) * 4);
-    b_voff1 = (int)(((int64_t)b * p.bs1 + (int64_t)8 * oct * p.HW + pix) * 4);
+    b_voff0 = (int)(((int64_t)b * p.bs0 + (int64_t)2 * kr0 * p.HW + pix) * 4);
+    b_voff1 = (int)(((int64_t)b * p.bs1 + (int64_t)2 * kr0 * p.HW + pix) * 4);
   }
   const int b_row_bytes = (int)(p.HW * 4);
   // ROW: halo pixels (n0-1, n0+BN) of every channel of the step: 2 * BKH scalar loads, one each on the first threads
   const bool has_halo = ROW && tid < 2 * BKH;
-  const int h_c = tid & 7, h_side = (tid >> 3) & 1, h_oct = (tid >> 4) % OCT;
+  const int h_k = tid % BKH, h_side = (tid / BKH) & 1;
   int h_voff0 = 0, h_voff1 = 0;
-  unsigned cmask = 0;  // 9-bit validity mask (bit dy*3+dx) of the pixel this lane consumes
+  unsigned cmask[TN];  // 9-bit validity masks (bit dy*3+dx) of the TN pixels this lane consumes
+#pragma unroll
+  for (int j = 0; j < TN; ++j) cmask[j] = 0;
   if (ROW) {
     int nh = h_side ? n0 + BN : n0 - 1;
     nh = min(max(nh, 0), p.n_total - 1);
     const int b = nh / p.OHW;
     const int pix = nh - b * p.OHW;
-    h_voff0 = (int)(((int64_t)b * p.bs0 + (int64_t)(8 * h_oct + h_c) * p.HW + pix) * 4);
-    h_voff1 = (int)(((int64_t)b * p.bs1 + (int64_t)(8 * h_oct + h_c) * p.HW + pix) * 4);
-    const int n = n0 + wn0 + l31;
-    if (n < p.n_total) {
-      const int px = n % p.OHW;
-      const int oh = px / p.OW, ow = px - oh * p.OW;
+    h_voff0 = (int)(((int64_t)b * p.bs0 + (int64_t)h_k * p.HW + pix) * 4);
+    h_voff1 = (int)(((int64_t)b * p.bs1 + (int64_t)h_k * p.HW + pix) * 4);
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const bool ok = ((unsigned)(oh + t / 3 - 1) < (unsigned)p.H) && ((unsigned)(ow + t % 3 - 1) < (unsigned)p.W);
-        cmask |= ok ? (1u << t) : 0u;
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn0 + 32 * j + l31;
+      if (n < p.n_total) {
+        const int px = n % p.OHW;
+        const int oh = px / p.OW, ow = px - oh * p.OW;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const bool ok = ((unsigned)(oh + t / 3 - 1) < (unsigned)p.H) && ((unsigned)(ow + t % 3 - 1) < (unsigned)p.W);
+          cmask[j] |= ok ? (1u << t) : 0u;
+        }
       }
     }
   }
@@ -139,7 +156,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.0f;
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   const int ksteps_total = (p.K + BKH - 1) / BKH;
   int ks0 = 0, ksteps = ksteps_total;
@@ -152,11 +171,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
   // ---- staging registers: two sets for the weights (loads two K steps ahead), one for the activation gather
   constexpr int ASETS = (SPLIT && ROW && BM < 256) ? 1 : 2;  // (the 128-wide split row kind is register-bound: weights one K step ahead)
   f32x4 ra[ASETS][A_V4];
-  float rb[8][PX];        // eight channels x PX pixels
+  f32x4 rb[TPT][2];       // per task: two channels x four pixels
   float rh = 0.0f;        // halo threads: one channel of one halo pixel
 
   auto load_a = [&](int t_raw, auto setc) {
     constexpr int SET = decltype(setc)::value % ASETS;
+    if (DEVA_ABL(2 | 32)) return;
     const int t = min(t_raw, ks_last);
     const int off = t * a_step_bytes;
     const __amdgpu_buffer_rsrc_t r = make_rsrc(reinterpret_cast<const char*>(p.w16) + off, max(a_total_bytes - off, 0));
@@ -165,6 +185,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
   };
   // activation tile of K step t (KIND 0) / the (BKH-channel slab, dy) row tile that starts at step t (KIND 1)
   auto load_b = [&](int t_raw) {
+    if (DEVA_ABL(2 | 16)) return;
     const int t = min(t_raw, ks_last);
     int cbase = t * BKH, shift = 0;
     if (ROW) {
@@ -176,83 +197,100 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
     const float* base = (first ? p.in0 : p.in1) + ((int64_t)(first ? cbase : cbase - p.c0) * p.HW + shift);
     const __amdgpu_buffer_rsrc_t r = make_rsrc(base, 0x7fffffff);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      if constexpr (PX == 2) {
-        const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, first ? b_voff0 : b_voff1, c * b_row_bytes, 0));
-        rb[c][0] = v[0];
-        rb[c][PX - 1] = v[1];
-      } else {
-        rb[c][0] = buf_load1(r, first ? b_voff0 : b_voff1, c * b_row_bytes);
-      }
-    }
+    for (int i = 0; i < TPT; ++i)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) rb[i][c] = buf_load4(r, first ? b_voff0 : b_voff1, (2 * i * RSTEP + c) * b_row_bytes);
     if (has_halo) rh = buf_load1(r, first ? h_voff0 : h_voff1, 0);
   };
   auto store_a = [&](auto setc) {
     constexpr int BUF = decltype(setc)::value, SET = BUF % ASETS;
+    if (DEVA_ABL(1)) return;
     _Float16* a = sA + BUF * A_HALFS + tid * 8;
 #pragma unroll
     for (int i = 0; i < A_V4; ++i) *reinterpret_cast<f32x4*>(a + i * THREADS * 8) = ra[SET][i];
   };
-  // fp32 -> fp16 (round to nearest even, like torch's .half()), relu-on-load first; one 16-byte octet per pixel and plane.
-  // SPLIT: hi = fp16(v), lo = fp16(v - hi)
-  auto put_octet = [&](_Float16* bt, int o, int col, const float (&v8)[8]) {
-    h8 hi;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) hi[c] = (_Float16)v8[c];
-    *reinterpret_cast<h8*>(bt + ((o * NPL) * BNP + col) * 8) = hi;
-    if constexpr (SPLIT) {
-      h8 lo;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) lo[c] = (_Float16)(v8[c] - (float)hi[c]);
-      *reinterpret_cast<h8*>(bt + ((o * NPL + 1) * BNP + col) * 8) = lo;
-    }
-  };
+  // fp32 -> fp16 (round to nearest even, like torch's .half()), relu-on-load first; per task one 16-byte quad (four pixels
+  // x the channel pair) per plane.  SPLIT: hi = fp16(v), lo = fp16(v - hi)
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   auto store_b = [&](int buf) {
+    if (DEVA_ABL(1)) return;
     _Float16* bt = sB + buf * B_HALFS;
 #pragma unroll
-    for (int px = 0; px < PX; ++px) {
-      float v8[8];
+    for (int i = 0; i < TPT; ++i) {
+      u32x4 hi4, lo4;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) v8[c] = p.relu_in ? fmaxf(rb[c][px], 0.0f) : rb[c][px];
-      put_octet(bt, oct, (ROW ? 4 : 0) + PX * vq + px, v8);
+      for (int px = 0; px < 4; ++px) {
+        float v0 = rb[i][0][px], v1 = rb[i][1][px];
+        if (p.relu_in) {
+          v0 = fmaxf(v0, 0.0f);
+          v1 = fmaxf(v1, 0.0f);
+        }
+        const h2 hi = {(_Float16)v0, (_Float16)v1};
+        hi4[px] = __builtin_bit_cast(unsigned, hi);
+        if constexpr (SPLIT) {
+          const h2 lo = {(_Float16)(v0 - (float)hi[0]), (_Float16)(v1 - (float)hi[1])};
+          lo4[px] = __builtin_bit_cast(unsigned, lo);
+        }
+      }
+      _Float16* at = bt + ((kr0 + i * RSTEP) * BNP + (ROW ? 4 : 0) + 4 * vq) * 2;
+      *reinterpret_cast<u32x4*>(at) = hi4;
+      if constexpr (SPLIT) *reinterpret_cast<u32x4*>(at + KP * BNP * 2) = lo4;
     }
     if (has_halo) {
       const float v = p.relu_in ? fmaxf(rh, 0.0f) : rh;
       const _Float16 hi = (_Float16)v;
-      _Float16* at = bt + ((h_oct * NPL) * BNP + (h_side ? BN + 4 : 3)) * 8 + h_c;
+      _Float16* at = bt + ((h_k >> 1) * BNP + (h_side ? BN + 4 : 3)) * 2 + (h_k & 1);
       at[0] = hi;
-      if constexpr (SPLIT) at[BNP * 8] = (_Float16)(v - (float)hi);
+      if constexpr (SPLIT) at[KP * BNP * 2] = (_Float16)(v - (float)hi);
     }
   };
 
-  // ---- fragments: lane (row or pixel l31, k-group half) holds k = 16*kb + 8*half + 0..7 of K-block kb, i.e. octet
-  // 2*kb + half: one ds_read_b128 per plane
+  // ---- fragments: lane (row or pixel l31, k-group half) holds k = 16*kb + 8*half + 0..7 of K-block kb: weights octet
+  // 2*kb + half, one ds_read_b128 per plane; activations k-pair rows 8*kb + 4*half + 0..3 of its pixel column, four
+  // 4-byte reads per plane
   const _Float16* const a_rd0 = sA + (half * NPL * BM + wm0 + l31) * 8;
-  const _Float16* const b_rd0 = sB + (half * NPL * BNP + wn0 + l31 + (ROW ? 3 : 0)) * 8;
-  const _Float16* const b_zero0 = sB + (half * NPL * BNP) * 8;
-  h8 fa[2][NPL][TM], fb[2][NPL];
-  auto frag_load = [&](int set, const _Float16* a_rd, const _Float16* b_rd, int kb) {
+  const _Float16* const b_rd0 = sB + (4 * half * BNP + wn0 + l31 + (ROW ? 3 : 0)) * 2;
+  const _Float16* const b_zero0 = sB + (4 * half * BNP) * 2;
+  h8 fa[2][NPL][TM], fb[2][NPL][TN];
+  struct BRd {  // read bases of the lane's TN pixels (own column + dx, or the zero column for a padded tap)
+    const _Float16* q[TN];
+  };
+  auto frag_load = [&](int set, const _Float16* a_rd, const BRd& b_rd, int kb) {
+    if (DEVA_ABL(8)) return;
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) fa[set][pl][i] = *reinterpret_cast<const h8*>(a_rd + ((2 * kb * NPL + pl) * BM + 32 * i) * 8);
-      fb[set][pl] = *reinterpret_cast<const h8*>(b_rd + ((2 * kb * NPL + pl) * BNP) * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        u32x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = *reinterpret_cast<const unsigned*>(b_rd.q[j] + ((pl * KP + 8 * kb + e) * BNP) * 2);
+        fb[set][pl][j] = __builtin_bit_cast(h8, w);
+      }
     }
   };
   // the MFMAs of one K-block, in the order hi.hi (every row block), hi.lo, lo.hi; `part`: 0 = all, 1 = first half, 2 = rest
-  constexpr int MF = (SPLIT ? 3 : 1) * TM;
+  constexpr int MF = (SPLIT ? 3 : 1) * TM * TN;
   auto mfma_block = [&](int set, int part = 0) {
 #pragma unroll
-    for (int j = 0; j < MF; ++j) {
-      if ((part == 1 && j >= MF / 2) || (part == 2 && j < MF / 2)) continue;
-      const int term = j / TM, i = j % TM;
-      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][term == 2 ? NPL - 1 : 0][i], fb[set][term == 1 ? NPL - 1 : 0], acc[i][0], 0, 0, 0);
+    for (int q = 0; q < MF; ++q) {
+      if ((part == 1 && q >= MF / 2) || (part == 2 && q < MF / 2)) continue;
+      const int term = q / (TM * TN), i = q % TM, j = q / TM % TN;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][term == 2 ? NPL - 1 : 0][i], fb[set][term == 1 ? NPL - 1 : 0][j],
+                                                         acc[i][j], 0, 0, 0);
     }
   };
 
-  auto taps_of = [&](int t) { return (cmask >> (t % 9 / 3 * 3)) & 7u; };
-  unsigned m3 = ROW ? taps_of(ks0) : 0u;
-  const _Float16* b_cur = ROW ? ((m3 & 1u) ? b_rd0 : b_zero0) : b_rd0;
+  auto taps_of = [&](int j, int t) { return (cmask[j] >> (t % 9 / 3 * 3)) & 7u; };
+  unsigned m3[TN];
+  BRd b_cur;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    m3[j] = ROW ? taps_of(j, ks0) : 0u;
+    b_cur.q[j] = (ROW && !(m3[j] & 1u)) ? b_zero0 : b_rd0 + 32 * j * 2;
+  }
 
   // One K step of NKB K-blocks; buffer / register-set indices are compile-time (see conv_mfma.hip).  The staged next
   // tile is written to LDS beside the second-to-last MFMA group, the barrier sits before the last one.
@@ -263,12 +301,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
     const int t = ks0 + s;
     const _Float16* a_rd = a_rd0 + PAR * A_HALFS;
     const _Float16* a_nx = a_rd0 + (PAR ^ 1) * A_HALFS;
-    const _Float16* b_nx;
-    if (ROW) {
-      if (DX == 2) m3 = taps_of(t + 1);
-      b_nx = ((m3 >> DXN) & 1u) ? (b_rd0 + GBN * B_HALFS + 8 * DXN) : (b_zero0 + GBN * B_HALFS);
-    } else {
-      b_nx = b_rd0 + (PAR ^ 1) * B_HALFS;
+    BRd b_nx;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      if (ROW) {
+        if (DX == 2) m3[j] = taps_of(j, t + 1);
+        b_nx.q[j] = ((m3[j] >> DXN) & 1u) ? (b_rd0 + GBN * B_HALFS + 2 * DXN + 32 * j * 2) : (b_zero0 + GBN * B_HALFS);
+      } else {
+        b_nx.q[j] = b_rd0 + (PAR ^ 1) * B_HALFS + 32 * j * 2;
+      }
     }
     if constexpr (NKB == 4) {
       frag_load(1, a_rd, b_cur, 1);
@@ -322,7 +363,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
         load_b(t + 2);
       }
       mfma_block(1, 1);
-      constexpr int NFR = (TM + 1) * NPL;  // LDS reads of one fragment set
+      constexpr int NFR = (TM + 4 * TN) * NPL;  // LDS reads of one fragment set (the compiler pairs the 4-byte ones)
 #pragma unroll
       for (int j = 0; j < MF; ++j) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // MFMA
@@ -335,7 +376,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
       }
       __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();
+      if (!DEVA_ABL(4)) __syncthreads();
       // Region 2: fragments of the next step's K-block 0 under the second half of K-block 1
       frag_load(0, a_nx, b_nx, 0);
       mfma_block(1, 2);
@@ -354,8 +395,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
 
   // ---- prologue
   if (ROW) {  // the zero column (column 0) of every octet row, both buffers
-    constexpr int ZR = OCT * NPL;
-    for (int i = tid; i < 2 * ZR * 8; i += THREADS) sB[(i / (ZR * 8)) * B_HALFS + ((i / 8) % ZR) * BNP * 8 + (i & 7)] = (_Float16)0.0f;
+    constexpr int ZR = NPL * KP;
+    for (int i = tid; i < 2 * ZR * 2; i += THREADS) sB[(i / (ZR * 2)) * B_HALFS + ((i / 2) % ZR) * BNP * 2 + (i & 1)] = (_Float16)0.0f;
   }
   load_a(ks0, I0{});
   load_b(ks0);
@@ -397,10 +438,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        bad |= (__builtin_bit_cast(unsigned, acc[i][0][r]) & 0x7f800000u) == 0x7f800000u;
-        acc[i][0][r] *= p.out_scale;
-      }
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          bad |= (__builtin_bit_cast(unsigned, acc[i][j][r]) & 0x7f800000u) == 0x7f800000u;
+          acc[i][j][r] *= p.out_scale;
+        }
     if (bad && p.flag) atomicOr(p.flag, 1);
   }
 
@@ -417,6 +460,15 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int MINW, int BKH, int PREC>
 int launch_tile_f16(const ConvArgs& a, int kind, hipStream_t st) {
   ConvArgs p = a;
   p.gate = nullptr;
+#ifdef DEVA_CONV_PROBES
+  {
+    static const int abl = [] {
+      const char* e = getenv("DEVA_SPLIT_ABLATE");
+      return e ? atoi(e) : 0;
+    }();
+    p.ablate = abl;
+  }
+#endif
   p.tiles_m = (int)ceil_div(a.cout, BM);
   p.tiles_n = (int)ceil_div(a.n_total, BN);
   const int ksteps_total = (int)ceil_div(a.K, BKH);
@@ -471,6 +523,7 @@ int launch_conv_f16(const ConvArgs& a, hipStream_t st) {
     }();
     if (forced == 256 && a.cout >= 256) return launch_tile_f16<256, 128, 2, 4, 2, 32, 2>(a, kind, st);
     if (forced == 128 && a.cout >= 128) return launch_tile_f16<128, 128, 2, 4, 4, 32, 2>(a, kind, st);
+    if (forced == 1284 && a.cout >= 128) return launch_tile_f16<128, 128, 2, 2, 2, 32, 2>(a, kind, st);
     if (forced == 64) return launch_tile_f16<64, 64, 2, 2, 2, 32, 2>(a, kind, st);
 #endif
     // 256x128 tiles (wave tile 128x32: 0.83 KB of LDS fragment reads per MFMA against 1.0 on the 64x32 wave tile, a

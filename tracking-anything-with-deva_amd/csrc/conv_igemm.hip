@@ -752,6 +752,7 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
   a.out_scale = 1.0f;
   a.flag = nullptr;
   a.gate = nullptr;
+  a.ablate = 0;
   a.in0_span = (int64_t)(d->batch - 1) * a.bs0 + (int64_t)a.c0 * a.HW;
   a.in1_span = a.in1 ? (int64_t)(d->batch - 1) * a.bs1 + (int64_t)a.c1 * a.HW : 0;
 
