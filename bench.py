@@ -112,13 +112,13 @@ def mfma_probe(device, iters=6000, reps=4):
     return out
 
 
-def build_network(device, amp=False, split=False):
+def build_network(device, amp=False, split=False, split_key_encoder=False):
     from workload import synth, weights
     from deva.model.network import DEVA
     with open(os.path.join(ROOT, 'tests', 'golden', 'state_dict_spec.json')) as f:
         spec = json.load(f)['tensors']
     sd = weights.make_state_dict([(k, tuple(s), getattr(torch, d)) for k, s, d in spec], seed=0)
-    net = DEVA(dict(synth.base_config(), amp=amp, f16_split=split))
+    net = DEVA(dict(synth.base_config(), amp=amp, f16_split=split, f16_split_key_encoder=split_key_encoder))
     net.load_weights(sd)
     return net.to(device).eval(), sd
 
@@ -298,6 +298,27 @@ def affinity_microbench(device, n=10000, hw=8160, k=30, iters=20):
             torch.cuda.synchronize()
             us[mode] = e0.elapsed_time(e1) / iters * 1e3
         flag = L.deva_affinity_read_flag(scratch.data_ptr(), st)
+        # the read as the frames BETWEEN two memory frames run it: bank operands of the pre-filter kept in a prepared-bank
+        # buffer (deva_affinity_read_prepared, MemoryManager._prep_of), the three bank kernels skipped
+        prep = torch.empty((L.deva_affinity_bank_prep_bytes(n) // 8 + 8,), dtype=torch.int64, device=device)
+
+        def read_cached(valid):
+            rc = L.deva_affinity_read_prepared(None, None, 0, key.data_ptr(), shr.data_ptr(), n, qk.data_ptr(), qe.data_ptr(), hw, k,
+                                               scratch.data_ptr(), idx.data_ptr(), wgt.data_ptr(), fix.data_ptr(), None, None, 0,
+                                               prep.data_ptr(), valid, st)
+            assert rc == 0, L.deva_hip_last_error()
+
+        read_cached(0)
+        for _ in range(3):
+            read_cached(1)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            read_cached(1)
+        e1.record()
+        torch.cuda.synchronize()
+        us_cached = e0.elapsed_time(e1) / iters * 1e3
     finally:
         L.deva_affinity_force_prefilter(1)
     t = us[1] * 1e-6
@@ -305,7 +326,8 @@ def affinity_microbench(device, n=10000, hw=8160, k=30, iters=20):
     f16_flops = 2 * 2.0 * 144 * n * hw              # what the pre-filter issues: two passes of K = 144 (P, m x bsq, Q chains)
     b_alg = 4.0 * (64 * n + n + 2 * 64 * hw) + 8.0 * k * hw + 4.0 * n
     b_mat = 12.0 * 4 * n * hw
-    return dict(shape=dict(n=n, hw=hw, k=k), us_read=us[1], us_read_fp32_kernels_only=us[0], speedup_over_fp32_kernels=us[0] / us[1],
+    return dict(shape=dict(n=n, hw=hw, k=k), us_read=us[1], us_read_bank_operands_cached=us_cached,
+                us_read_fp32_kernels_only=us[0], speedup_over_fp32_kernels=us[0] / us[1],
                 prefilter_fell_back=bool(flag),
                 bound='f16 MFMA operand delivery + VALU scoring (the fp32 matrix rate no longer binds: only ~35 of the '
                       f'{n} tokens per query are scored in fp32)',
@@ -1113,6 +1135,7 @@ def main():
         if isinstance(result.get('affinity'), dict) and 'us_read' in result['affinity']:
             a = result['affinity']
             result['roofline']['affinity_read_us_10k_x_8160'] = round(a['us_read'], 1)
+            result['roofline']['affinity_read_us_10k_x_8160_bank_cached'] = round(a['us_read_bank_operands_cached'], 1)
             result['roofline']['affinity_f16_mfma_frac'] = round(a['f16_mfma_frac'], 4)
             result['roofline']['affinity_hbm_algorithmic_frac'] = round(a['hbm_algorithmic_frac'], 5)
             if a.get('hbm_counter_traffic_over_algorithmic'):

@@ -286,6 +286,24 @@ int deva_affinity_read(const float* key_long, const float* shr_long, int n_long,
                        const float* qk, const float* qe, int hw, int k, uint64_t* scratch,
                        int32_t* idx, float* weight, uint64_t* usage_fix,
                        uint64_t* out_keys, uint32_t* out_counts, int64_t token_offset, void* stream);
+/* The same read with the bank side of the pre-filter kept between reads.  The reference re-derives nothing either while
+ * the bank stands still: a bucket's bank changes only when a memory frame is added or consolidated
+ * (deva/inference/memory_manager.py:171-218: every mem_every-th frame), the frames between read it unchanged
+ * (memory_manager.py:91-169).  bank_prep: deva_affinity_bank_prep_bytes(n_long + n_work) bytes of device memory that the
+ * CALLER keeps per bank (NULL: everything lives in `scratch`, like deva_affinity_read); the call writes the bank's mean
+ * key, operand scales and fp16 MFMA fragments there.  bank_prep_valid != 0 is the caller's promise that bank_prep was
+ * filled by an earlier call on the SAME bank contents (same rows in both segments, same n_long and n_work): the three
+ * bank kernels (mean key, operand statistics, fragment preparation) are skipped.  A stale promise is a silent wrong
+ * answer -- keep a version counter beside every bank (deva/inference/kv_memory_store.py: version()).  Reads that the
+ * pre-filter does not serve (deva_affinity_prefilter_enabled == 0, k > 32) ignore both arguments.  Results are
+ * bit-identical to deva_affinity_read. */
+int deva_affinity_read_prepared(const float* key_long, const float* shr_long, int n_long,
+                                const float* key_work, const float* shr_work, int n_work,
+                                const float* qk, const float* qe, int hw, int k, uint64_t* scratch,
+                                int32_t* idx, float* weight, uint64_t* usage_fix,
+                                uint64_t* out_keys, uint32_t* out_counts, int64_t token_offset,
+                                uint64_t* bank_prep, int bank_prep_valid, void* stream);
+int64_t deva_affinity_bank_prep_bytes(int n_total);
 int64_t deva_affinity_read_scratch(int n_total, int hw, int k);
 int deva_affinity_prefilter_enabled(int n_total, int hw, int k);
 int deva_affinity_force_prefilter(int mode);

@@ -163,7 +163,7 @@ def _bank(key_long, n_long, key_work, n_work):
 
 
 def affinity_topk(key_long, shr_long, n_long, key_work, shr_work, n_work, qk, qe, k, usage_fix=None,
-                  splits=None):
+                  splits=None, prep=None, prep_key=None):  # (prepared bank operands: a cache, no arithmetic to emulate)
     mk = _bank(key_long, n_long, key_work, n_work)          # [N,64] token-major
     ms = _bank(shr_long, n_long, shr_work, n_work)          # [N]
     if mk.shape[0] < k:

@@ -14,8 +14,10 @@ def net_config(**over):
     gate is then held, with unchanged bounds, under that mode (profiles/r05/tests_split/)"""
     from workload import synth
     cfg = synth.base_config()
-    if os.environ.get('DEVA_TEST_F16_SPLIT') == '1' and not over.get('amp'):
+    mode = os.environ.get('DEVA_TEST_F16_SPLIT')  # '1': value encoder + mask decoder; 'all': the key encoder too
+    if mode in ('1', 'all') and not over.get('amp'):
         cfg['f16_split'] = True
+        cfg['f16_split_key_encoder'] = mode == 'all'
     cfg.update(over)
     return cfg
 

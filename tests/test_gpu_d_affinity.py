@@ -373,3 +373,44 @@ def test_token_sharded_read_merges_to_the_unsharded_result(world):
     err = max_err(total, full.cpu())
     print(f'world={world}: merged selection bit-identical; partial read-outs sum to the full one within {err:.2e}')
     assert err <= 1e-5 * max(1.0, full.abs().max().item())
+
+
+def _read(rows, shr, n_long, qk, qe, k, prep=None, key=None):
+    """one read through ops.affinity_topk on device-resident banks; -> (idx, weight, usage) on the host"""
+    n = rows.shape[0]
+    fix = torch.zeros(n, dtype=torch.int64, device=dev())
+    kl, sl = (rows[:n_long], shr[:n_long]) if n_long else (None, None)
+    idx, w = ops.affinity_topk(kl, sl, n_long, rows[n_long:], shr[n_long:], n - n_long, qk, qe, k, fix, prep=prep, prep_key=key)
+    torch.cuda.synchronize()
+    return idx.cpu(), w.cpu(), (fix.cpu().double() / 2**40).float()
+
+
+@pytest.mark.parametrize('n,hw,n_long', [(10000, 2040, 0), (9000, 1620, 4000)])
+def test_prepared_bank_read_is_bit_identical_and_follows_the_bank(n, hw, n_long):
+    """deva_affinity_read_prepared: the bank side of the pre-filter (mean key, scales, fp16 fragments) kept between reads.
+    (1) filling the buffer and (2) re-using it for other queries give the plain read's result bit for bit; (3) after the
+    bank has changed -- same sizes, other rows -- a read under a NEW key gives the fresh result; (4) a buffer that is
+    too small for a grown bank is replaced; no read falls back."""
+    if os.environ.get('DEVA_TEST_DRYRUN') == '1':
+        pytest.skip('kernel-path property: nothing to compare on the emulated ops')
+    k = 30
+    mk, ms, qk, qe = synth.affinity_inputs(n, hw, seed=n + 7 * hw, key_scale=1.3)
+    mk2, ms2, qk2, qe2 = synth.affinity_inputs(n + 3000, hw, seed=11, key_scale=0.7)
+    rows, shr = to_dev(mk.t().contiguous()), to_dev(ms.reshape(-1).contiguous())
+    rows2, shr2 = to_dev(mk2.t().contiguous()), to_dev(ms2.reshape(-1).contiguous())
+    q = [(to_dev(a), to_dev(b)) for a, b in ((qk, qe), (qk2, qe2))]
+    prep = ops.BankPrep()
+    first = _read(rows, shr, n_long, *q[0], k, prep, 'v1')
+    _assert_identical('fill', _read(rows, shr, n_long, *q[0], k), first)
+    assert ops.affinity_last_read_flag(dev()) == 0
+    again = _read(rows, shr, n_long, *q[1], k, prep, 'v1')                       # cached operands, other queries
+    _assert_identical('re-use', _read(rows, shr, n_long, *q[1], k), again)
+    assert ops.affinity_last_read_flag(dev()) == 0
+    rows[n_long + 5:n_long + 4000].copy_(rows2[:3995])                           # the bank changes in place ...
+    shr[100:2000].mul_(1.7)
+    fresh = _read(rows, shr, n_long, *q[1], k, prep, 'v2')                       # ... and the owner says so
+    _assert_identical('after a change', _read(rows, shr, n_long, *q[1], k), fresh)
+    assert not torch.equal(fresh[0], again[0]), 'the changed bank must change the read'
+    grown = _read(rows2, shr2, n_long, *q[0], k, prep, 'v3')                     # more tokens than the buffer holds
+    _assert_identical('grown bank', _read(rows2, shr2, n_long, *q[0], k), grown)
+    _assert_identical('grown bank, cached', _read(rows2, shr2, n_long, *q[1], k), _read(rows2, shr2, n_long, *q[1], k, prep, 'v3'))

@@ -222,6 +222,37 @@ def test_prefetched_key_encoder_is_bit_identical(network):
     assert all(torch.equal(a, b) for a, b in zip(outs['plain'], outs['prefetch']))
 
 
+def test_bank_prep_cache_is_bit_identical_over_memory_frames(network):
+    """the memory read keeps the bank side of its pre-filter (mean key, scales, fp16 fragments) per bucket while the bank
+    stands still (MemoryManager._prep_of, keyed on the stores' bucket versions): a 480p clip with a pre-filled 10 000-token
+    long-term bank, memory frames every 2nd frame and a consolidation in the run must give the same output, bit for bit,
+    with the cache and without it"""
+    from deva.inference.inference_core import DEVAInferenceCore
+    H, W, frames = 480, 864, 14
+    cfg = synth.base_config(mem_every=2, max_mid_term_frames=4, min_mid_term_frames=2)
+    stream = synth.FrameStream(H, W, seed=9)
+    imgs = [stream.next().to(dev()) for _ in range(frames)]
+    mask0 = synth.box_mask(H, W, 1).to(dev())
+    key, shr, vals = synth.prefill_bank(10000, [1], seed=1)
+    outs, reads = {}, {}
+    for cached in (True, False):
+        core = DEVAInferenceCore(network, cfg)
+        core.memory.bank_prep_enabled = cached
+        res = [core.step(imgs[0], mask0, [1])]
+        core.memory.long_mem.add(key.to(dev()), {o: v.to(dev()) for o, v in vals.items()}, shr.to(dev()), selection=None,
+                                 supposed_bucket_id=0)
+        for t in range(1, frames):
+            res.append(core.step(imgs[t]))
+        torch.cuda.synchronize()
+        outs[cached] = [r.cpu() for r in res]
+        reads[cached] = (core.memory.long_mem.size(0), core.memory.work_mem.size(0))
+        if cached and os.environ.get('DEVA_TEST_DRYRUN') != '1':  # (the emulated ops have no operands to keep)
+            prep = core.memory._bank_prep[0]
+            assert prep.buf is not None and prep.key is not None, 'the cached run never used the prepared-bank path'
+    assert reads[True] == reads[False] and reads[True][0] > 10000 - 200, reads   # a consolidation added prototypes
+    assert all(torch.equal(a, b) for a, b in zip(outs[True], outs[False]))
+
+
 def test_480p_lockstep_teacher_forced(network, recipe_state_dict):
     """Every stage of every frame at full 480x864 size on IDENTICAL inputs (tests/lockstep.py)."""
     import lockstep

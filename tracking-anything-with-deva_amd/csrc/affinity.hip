@@ -1351,7 +1351,9 @@ struct PfState {     // device block, written by the prep kernel of every read
   uint32_t max_q;    // max 2 |mk - mu| m
   uint32_t max_m;    // max m
   float mu[CK];      // mean key of the bank (the common shift of both operand sides)
+  uint32_t bank_flag;  // the flag as the bank alone sets it (non-finite key / shrinkage): what a read on cached operands starts from
 };
+static_assert(sizeof(PfState) <= 512, "the state block is 512 bytes of the scratch / of a prepared-bank buffer");
 constexpr float PF_EQ = 4e-5f;  // reference fp32 round-off carried by the shift: E_q = PF_EQ * max m * sum qe mu^2
 
 // power of two P with x * P in [2^14, 2^15)
@@ -1462,7 +1464,7 @@ __global__ __launch_bounds__(256) void affinity_pf_stats_kernel(const PfBank b, 
 
 // one thread per (token slot of the padded bank, half-lane): writes the 9 x 16 B this MFMA lane will load
 __global__ __launch_bounds__(256) void affinity_pf_prep_kernel(const PfBank b, const uint32_t* __restrict__ part,
-                                                                PfState* st, int n_pad, uint8_t* __restrict__ a16) {
+                                                                PfState* st, PfState* keep, int n_pad, uint8_t* __restrict__ a16) {
   // every block reduces the partial maxima of the stats kernel itself (one wave); block 0 publishes
   // them together with the cleared fall-back flag for the kernels that follow in the stream
   __shared__ float s_max[4];
@@ -1479,10 +1481,20 @@ __global__ __launch_bounds__(256) void affinity_pf_prep_kernel(const PfBank b, c
 #pragma unroll
       for (int c = 0; c < 4; ++c) s_max[c] = v[c];
       if (blockIdx.x == 0) {
-        st->flag = v[3] > 0.0f ? 1u : 0u;
+        st->flag = st->bank_flag = v[3] > 0.0f ? 1u : 0u;
         st->max_p = __float_as_uint(v[0]);
         st->max_q = __float_as_uint(v[1]);
         st->max_m = __float_as_uint(v[2]);
+      }
+    }
+    // a prepared-bank buffer keeps the state beside the operands: reads of the unchanged bank start from this image
+    if (blockIdx.x == 0 && keep) {
+      keep->mu[lane] = st->mu[lane];
+      if (lane == 0) {
+        keep->flag = keep->bank_flag = v[3] > 0.0f ? 1u : 0u;
+        keep->max_p = __float_as_uint(v[0]);
+        keep->max_q = __float_as_uint(v[1]);
+        keep->max_m = __float_as_uint(v[2]);
       }
     }
   }
@@ -1518,6 +1530,18 @@ __global__ __launch_bounds__(256) void affinity_pf_prep_kernel(const PfBank b, c
   }
 #pragma unroll
   for (int kb = 0; kb < PF_KB; ++kb) *reinterpret_cast<h8*>(dst + kb * 1024) = out[kb];
+}
+
+// a read on cached bank operands: the state image of the prepared-bank buffer -> the scratch's state block (flag = the bank's own)
+__global__ __launch_bounds__(64) void affinity_pf_restore_kernel(const PfState* __restrict__ keep, PfState* __restrict__ st) {
+  const int lane = threadIdx.x;
+  st->mu[lane] = keep->mu[lane];
+  if (lane == 0) {
+    st->flag = st->bank_flag = keep->bank_flag;
+    st->max_p = keep->max_p;
+    st->max_q = keep->max_q;
+    st->max_m = keep->max_m;
+  }
 }
 
 struct PfArgs {
@@ -2447,10 +2471,24 @@ extern "C" int64_t deva_affinity_read_scratch(int n_total, int hw, int k) {
   return pf_layout(n_total, hw, k).bytes / 8;
 }
 
+extern "C" int64_t deva_affinity_bank_prep_bytes(int n_total) {
+  if (n_total <= 0) return 512;
+  return 512 + (ceil_div(n_total, TOKT) * (int64_t)PF_TILE_BYTES + 255) / 256 * 256;
+}
+
 extern "C" int deva_affinity_read(const float* key_long, const float* shr_long, int n_long, const float* key_work,
                                   const float* shr_work, int n_work, const float* qk, const float* qe, int hw, int k,
                                   uint64_t* scratch, int32_t* idx, float* weight, uint64_t* usage_fix,
                                   uint64_t* out_keys, uint32_t* out_counts, int64_t token_offset, void* stream) {
+  return deva_affinity_read_prepared(key_long, shr_long, n_long, key_work, shr_work, n_work, qk, qe, hw, k, scratch, idx, weight,
+                                     usage_fix, out_keys, out_counts, token_offset, nullptr, 0, stream);
+}
+
+extern "C" int deva_affinity_read_prepared(const float* key_long, const float* shr_long, int n_long, const float* key_work,
+                                           const float* shr_work, int n_work, const float* qk, const float* qe, int hw, int k,
+                                           uint64_t* scratch, int32_t* idx, float* weight, uint64_t* usage_fix,
+                                           uint64_t* out_keys, uint32_t* out_counts, int64_t token_offset,
+                                           uint64_t* bank_prep, int bank_prep_valid, void* stream) {
   DEVA_REQUIRE(qk && qe && scratch && hw > 0, "deva_affinity_read: bad query args");
   DEVA_REQUIRE((idx && weight && !out_keys && !out_counts) || (out_keys && out_counts && !idx && !weight && !usage_fix),
                "deva_affinity_read: pass either idx + weight (+ usage_fix) or out_keys + out_counts");
@@ -2485,16 +2523,25 @@ extern "C" int deva_affinity_read(const float* key_long, const float* shr_long, 
     b.n_total = (int)n_total;
     uint32_t* stat_part = reinterpret_cast<uint32_t*>(base + L.off_state + 512);  // [PF_STAT_BLOCKS][4], after the state
     float* sums = reinterpret_cast<float*>(base + L.off_state + 512 + PF_STAT_BLOCKS * 16);  // [PF_STAT_BLOCKS][64]
-    hipLaunchKernelGGL(affinity_pf_mean_kernel, dim3(PF_STAT_BLOCKS), dim3(256), 0, st, b, sums);
-    hipLaunchKernelGGL(affinity_pf_stats_kernel, dim3(PF_STAT_BLOCKS), dim3(256), 0, st, b, sums, stat_part, state->mu);
-    const int n_pad = L.tiles * TOKT;
-    hipLaunchKernelGGL(affinity_pf_prep_kernel, dim3((unsigned)ceil_div((int64_t)n_pad * 2, 256)), dim3(256), 0, st, b,
-                       stat_part, state, n_pad, base + L.off_a16);
+    // the bank side of the operands (mean key, scales, fp16 fragments) depends on the bank alone: with a prepared-bank
+    // buffer it lives there, and a read that the caller declares to be on the UNCHANGED bank (same rows, same n_long /
+    // n_work as the read that filled the buffer) skips the three bank kernels
+    uint8_t* const a16 = bank_prep ? reinterpret_cast<uint8_t*>(bank_prep) + 512 : base + L.off_a16;
+    PfState* const keep = bank_prep ? reinterpret_cast<PfState*>(bank_prep) : nullptr;
+    if (keep && bank_prep_valid) {
+      hipLaunchKernelGGL(affinity_pf_restore_kernel, dim3(1), dim3(64), 0, st, keep, state);
+    } else {
+      hipLaunchKernelGGL(affinity_pf_mean_kernel, dim3(PF_STAT_BLOCKS), dim3(256), 0, st, b, sums);
+      hipLaunchKernelGGL(affinity_pf_stats_kernel, dim3(PF_STAT_BLOCKS), dim3(256), 0, st, b, sums, stat_part, state->mu);
+      const int n_pad = L.tiles * TOKT;
+      hipLaunchKernelGGL(affinity_pf_prep_kernel, dim3((unsigned)ceil_div((int64_t)n_pad * 2, 256)), dim3(256), 0, st, b,
+                         stat_part, state, keep, n_pad, a16);
+    }
     hipLaunchKernelGGL(affinity_pf_query_kernel, dim3((unsigned)ceil_div(hw, 4 * QT)), dim3(256), 0, st, qk, qe, hw, state,
                        base + L.off_bq16, reinterpret_cast<float*>(base + L.off_eq));
     PfArgs a;
     a.bq16 = base + L.off_bq16;
-    a.a16 = base + L.off_a16;
+    a.a16 = a16;
     a.n_total = (int)n_total;
     a.total_tiles = L.tiles;
     a.qk = qk;

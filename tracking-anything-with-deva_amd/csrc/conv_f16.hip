@@ -526,10 +526,11 @@ int launch_conv_f16(const ConvArgs& a, hipStream_t st) {
     if (forced == 1284 && a.cout >= 128) return launch_tile_f16<128, 128, 2, 2, 2, 32, 2>(a, kind, st);
     if (forced == 64) return launch_tile_f16<64, 64, 2, 2, 2, 32, 2>(a, kind, st);
 #endif
-    // 256x128 tiles (wave tile 128x32: 0.83 KB of LDS fragment reads per MFMA against 1.0 on the 64x32 wave tile, a
-    // quarter less weight + activation staging per flop) where they still give every CU a workgroup
-    const int64_t blocks256 = ceil_div(a.cout, 256) * ceil_div(a.n_total, 128);
-    if (a.cout % 256 == 0 && blocks256 >= 224) return launch_tile_f16<256, 128, 2, 4, 2, 32, 2>(a, kind, st);
+    // 128x128 tiles, 8 waves (wave tile 64x32), two workgroups per CU.  Measured against it on the layers of the 480p / 5-object
+    // and the 1080p / 11-object frames (tools/convlab, DEVA_SPLIT_TILE in `make PROBES=1` builds; profiles/r05/lab): 256x128
+    // tiles (wave tile 128x32, one workgroup per CU) -1..4 %, 128x128 on four waves (wave tile 64x64) +-1 %: under real
+    // operand data the kernels run at the chip's power limit (all-zero activations: +25..34 % at an unchanged instruction
+    // stream), so fewer LDS bytes per MFMA buy nothing.
     if (a.cout >= 128 && blocks128 >= 64) return launch_tile_f16<128, 128, 2, 4, 4, 32, 2>(a, kind, st);
     return launch_tile_f16<64, 64, 2, 2, 2, 32, 2>(a, kind, st);
   }

@@ -70,6 +70,10 @@ SIGNATURES = {
     'deva_affinity_select': (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
     'deva_affinity_read': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    'deva_affinity_read_prepared': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int,
+                                            c_void_p]),
+    'deva_affinity_bank_prep_bytes': (c_int64, [c_int]),
     'deva_affinity_read_scratch': (c_int64, [c_int, c_int, c_int]),
     'deva_affinity_dense': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                             c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -15,7 +15,7 @@ from . import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQUARE_PLUS_ONE, KLAYOUT_CHU
 
 __all__ = ['PackedConv', 'pack_conv', 'conv2d', 'split_fallbacks', 'maxpool3x3s2', 'upsample2x_add', 'area_downsample',
            'aggregate', 'softmax_channels', 'upsample4x_softmax', 'cbam', 'gru_update',
-           'affinity_topk', 'affinity_dense', 'affinity_candidates', 'affinity_merge', 'usage_update', 'readout_sparse', 'bank_append', 'bank_gather_rows',
+           'affinity_topk', 'BankPrep', 'affinity_dense', 'affinity_candidates', 'affinity_merge', 'usage_update', 'readout_sparse', 'bank_append', 'bank_gather_rows',
            'bank_export', 'rank', 'rank_select', 'evict_select', 'similarity_dense', 'softmax_columns',
            'label_histogram', 'merge_paint', 'lut_remap', 'index_mask', 'input_head',
            'ACT_NONE', 'ACT_RELU', 'ACT_SIGMOID', 'ACT_SQUARE_PLUS_ONE']
@@ -440,12 +440,35 @@ def _affinity_workspace(elems: int, device) -> torch.Tensor:
     return ws
 
 
+class BankPrep:
+    """The bank side of the pre-filtered memory read (mean key, operand scales, fp16 MFMA fragments of every token), kept
+    by the caller per bank between reads (include/deva_hip.h: deva_affinity_read_prepared).  `key` is whatever the owner
+    uses to tell one state of the bank from another (MemoryManager: the stores' bucket versions and sizes); a read
+    whose key equals the key of the read that filled the buffer skips the bank kernels."""
+
+    def __init__(self):
+        self.buf: Optional[torch.Tensor] = None
+        self.key = None
+
+    def prepare(self, nbytes: int, device, key) -> Tuple[int, int]:
+        """-> (device address of the buffer, 1 if it holds the operands of this very bank state)"""
+        if self.buf is None or self.buf.numel() * 8 < nbytes or self.buf.device != torch.device(device):
+            # (a bank grows by one frame of tokens per memory frame: grow with slack like the read scratch)
+            self.buf = torch.empty(((nbytes + nbytes // 4) // 8 + 64,), dtype=torch.int64, device=device)
+            self.key = None
+        valid = int(key is not None and self.key == key)
+        self.key = key
+        return self.buf.data_ptr(), valid
+
+
 def affinity_topk(key_long, shr_long, n_long: int, key_work, shr_work, n_work: int, qk: torch.Tensor,
                   qe: torch.Tensor, k: int, usage_fix: Optional[torch.Tensor] = None,
-                  splits: Optional[int] = None):
+                  splits: Optional[int] = None, prep: Optional[BankPrep] = None, prep_key=None):
     """Fused similarity -> top-k -> softmax.  key_* token-major [>=n,64] arenas, shr_* [>=n];
     qk/qe [64,hw].  Returns idx int32 [hw,k] (long-then-work token index), weight fp32 [hw,k];
-    adds weight*2^40 into usage_fix (uint64 viewed as int64, [>= n_long+n_work]) if given."""
+    adds weight*2^40 into usage_fix (uint64 viewed as int64, [>= n_long+n_work]) if given.
+    prep / prep_key: the caller's `BankPrep` of this bank and the key of the bank's current state -- reads of an
+    unchanged bank then re-use the prepared fp16 operands (bit-identical results)."""
     hw = qk.shape[1]
     if qk.shape[0] != 64 or tuple(qe.shape) != tuple(qk.shape):
         raise DevaHipError('affinity_topk: queries must be [64, hw]')
@@ -456,10 +479,15 @@ def affinity_topk(key_long, shr_long, n_long: int, key_work, shr_work, n_work: i
         # the library picks the kernels: fp16 pre-filter + exact fp32 re-scoring on banks where it pays, else the fp32
         # kernels (also its device-side fall-back); bit-identical results either way
         scratch = _affinity_workspace(L.deva_affinity_read_scratch(n_long + n_work, hw, k), qk.device)
-        check(L.deva_affinity_read(_p(key_long) if n_long else None, _p(shr_long) if n_long else None, n_long,
-                                   _p(key_work) if n_work else None, _p(shr_work) if n_work else None, n_work,
-                                   _p(qk), _p(qe), hw, k, _p(scratch, torch.int64), _p(idx, torch.int32), _p(weight),
-                                   _p(usage_fix, torch.int64), None, None, 0, _stream()), 'deva_affinity_read')
+        bank_prep, valid = None, 0
+        if prep is not None and L.deva_affinity_prefilter_enabled(n_long + n_work, hw, k):
+            bank_prep, valid = prep.prepare(L.deva_affinity_bank_prep_bytes(n_long + n_work), qk.device,
+                                            None if prep_key is None else (prep_key, n_long, n_work))
+        check(L.deva_affinity_read_prepared(_p(key_long) if n_long else None, _p(shr_long) if n_long else None, n_long,
+                                            _p(key_work) if n_work else None, _p(shr_work) if n_work else None, n_work,
+                                            _p(qk), _p(qe), hw, k, _p(scratch, torch.int64), _p(idx, torch.int32), _p(weight),
+                                            _p(usage_fix, torch.int64), None, None, 0, bank_prep, valid, _stream()),
+              'deva_affinity_read_prepared')
         return idx, weight
     part = _affinity_workspace(L.deva_affinity_workspace(hw, k, splits), qk.device)
     check(L.deva_affinity_topk(_p(key_long) if n_long else None, _p(shr_long) if n_long else None, n_long,

@@ -19,6 +19,8 @@ _FLAGS = (
     ('f16_split', None, False, 'extension: fp32-accurate convolutions on the f16 matrix pipes (hi/lo fp16 split of both '
                                'operands, fp32 accumulation) in the value encoder and the mask decoder; held to the fp32 '
                                'parity bounds, 2.5-3x the fp32 rate of those layers'),
+    ('f16_split_key_encoder', None, False, 'extension, with --f16_split: the key encoder on the split kernels too (the memory '
+                                           "read's inputs then move by fp32 round-off, as under any change of accumulation order)"),
     # network widths (C^k, C^v, pixel feature)
     ('key_dim', int, 64, None),
     ('value_dim', int, 512, None),

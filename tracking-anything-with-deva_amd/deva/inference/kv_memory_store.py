@@ -67,6 +67,11 @@ class KeyValueMemoryStore:
         self._v: Dict[int, _Arena] = {}
         self._obj_bucket: Dict[int, int] = {}
         self._vshard: Optional[Tuple[int, int]] = None  # (rank, world) once shard_values() was called
+        # version of every bucket's key / shrinkage rows: bumped by every call that adds, drops or moves rows (add, the
+        # sieve / eviction / range removals through _rebuild); what the cached pre-filter operands of the memory read
+        # are keyed on (memory_manager.py: _bank_prep) -- the usage counters change on every read and are not part of it
+        self._ver: Dict[int, int] = {}
+        self._tick = 0
 
     # ------------------------------------------------------------------ value-sharded storage (several GPUs, one clip)
     def shard_values(self, rank: int, world: int) -> None:
@@ -99,6 +104,14 @@ class KeyValueMemoryStore:
         return first, first + own.numel(), own
 
     # ------------------------------------------------------------------ internal accessors
+    def version(self, bucket_id: int) -> int:
+        """changes whenever the rows of the bucket's key / shrinkage arenas change (0: no such bucket)"""
+        return self._ver.get(bucket_id, 0)
+
+    def _bump(self, bucket_id: int) -> None:
+        self._tick += 1
+        self._ver[bucket_id] = self._tick
+
     def bucket_of(self, obj: int) -> int:
         return self._obj_bucket[obj]
 
@@ -153,6 +166,9 @@ class KeyValueMemoryStore:
                     b = fresh
                 if b not in touched:
                     touched.append(b)
+
+        for b in touched:
+            self._bump(b)
 
         def put(arena: _Arena, src: torch.Tensor, n_old: int):
             dst = arena.ensure(n_old + n_new, n_old)
@@ -244,6 +260,7 @@ class KeyValueMemoryStore:
     # ------------------------------------------------------------------ compaction
     def _rebuild(self, bucket_id: int, parts: Sequence[Union[Tuple[int, int], Tuple[torch.Tensor, int]]]):
         """keep `parts` (each a (lo, hi) row range or an (int32 row-index tensor, count)) in order"""
+        self._bump(bucket_id)
         bk = self._b[bucket_id]
         total = sum((p[1] - p[0]) if isinstance(p[0], int) else p[1] for p in parts)
         arenas = [bk.k, bk.s] + ([bk.e] if bk.e else []) + ([bk.use, bk.life] if bk.use else [])
@@ -338,6 +355,7 @@ class KeyValueMemoryStore:
             if not self.buckets[b]:
                 del self.buckets[b]
                 self._b.pop(b, None)
+                self._ver.pop(b, None)
         self._v = {o: a for o, a in self._v.items() if o in keep}
         self._obj_bucket = {o: b for o, b in self._obj_bucket.items() if o in keep}
 

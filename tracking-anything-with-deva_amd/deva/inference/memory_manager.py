@@ -256,11 +256,27 @@ class MemoryManager:
             self.long_mem.key_arena(bucket_id) if with_long else None,
             self.long_mem.shrinkage_arena(bucket_id) if with_long else None, n_long,
             self.work_mem.key_arena(bucket_id), self.work_mem.shrinkage_arena(bucket_id), n_work,
-            qk, qe, self.top_k, usage_fix)
+            qk, qe, self.top_k, usage_fix, **self._prep_of(bucket_id, with_long))
         if self.use_long_term:
             self._apply_usage(bucket_id, usage_fix, with_long, n_long)
         for i, obj in enumerate(bucket):
             self._readout_into(rows[i], idx, weight, bucket_id, obj, with_long, n_long)
+
+    def _prep_of(self, bucket_id: int, with_long: bool) -> dict:
+        """the bucket's prepared pre-filter operands and the key of the bank's present state: the bank changes on memory
+        frames only (add / consolidation / eviction / purge bump the stores' bucket versions), the frames between read it
+        unchanged and skip the bank kernels of the read (memory_manager.py:91-169 reads, :171-218 writes)"""
+        if not getattr(self, 'bank_prep_enabled', True):  # (tests: the same clip with and without the cache)
+            return {}
+        preps = self.__dict__.setdefault('_bank_prep', {})
+        for b in [b for b in preps if b not in self.work_mem.buckets]:  # purged buckets
+            del preps[b]
+        prep = preps.get(bucket_id)
+        if prep is None:
+            prep = preps[bucket_id] = ops.BankPrep()
+        key = (self.work_mem.version(bucket_id), self.long_mem.version(bucket_id) if with_long else -1,
+               self.work_mem.key_arena(bucket_id).data_ptr(), self.long_mem.key_arena(bucket_id).data_ptr() if with_long else 0)
+        return dict(prep=prep, prep_key=key)
 
     def _read_bucket_query_sharded(self, bucket_id: int, bucket: List[int], qk, qe, rows) -> None:
         """rank r matches and reads out query columns [r*per, (r+1)*per); the column slabs are gathered
@@ -280,7 +296,8 @@ class MemoryManager:
             self.long_mem.key_arena(bucket_id) if with_long else None,
             self.long_mem.shrinkage_arena(bucket_id) if with_long else None, n_long,
             self.work_mem.key_arena(bucket_id), self.work_mem.shrinkage_arena(bucket_id), n_work,
-            qk_r, qe_r, self.top_k, usage_fix if (self.use_long_term and n_mine) else None)
+            qk_r, qe_r, self.top_k, usage_fix if (self.use_long_term and n_mine) else None,
+            **self._prep_of(bucket_id, with_long))
         if self.use_long_term:
             dist.all_reduce(usage_fix[:n_long + n_work], op=dist.ReduceOp.SUM, group=self._shard_group)
             self.comm_bytes += 8 * (n_long + n_work)
@@ -518,4 +535,10 @@ class MemoryManager:
         if self._sensory_stack is not None and list(ids) == self._sensory_ids and all(
                 self.sensory[o].data_ptr() == self._sensory_stack[0, i].data_ptr() for i, o in enumerate(ids)):
             return self._sensory_stack
-        return torch.stack([self.sensory[obj] for obj in ids], dim=0).unsqueeze(0)
+        # a changed object set (detections added / purged objects): re-stack into a GUARD-BANDED tensor -- the stack feeds
+        # the GRU convolutions, whose vector gathers (and with them the f16 kernels) need readable slack around their
+        # inputs; a plain torch.stack result sent those launches down the scalar-gather fp32 kernels
+        rows = [self.sensory[obj] for obj in ids]
+        out = ops._alloc((1, len(rows), *rows[0].shape), rows[0].device)
+        torch.stack(rows, dim=0, out=out[0])
+        return out

@@ -114,7 +114,8 @@ class CompiledGraph:
     # whose FMA order the affinity tests pin, so the inputs of the memory read's top-k do not move by a bit
     SPLIT_SCOPES = AMP_SCOPES
 
-    def __init__(self, sd: Dict[str, torch.Tensor], device: torch.device, amp: bool = False, split: bool = False):
+    def __init__(self, sd: Dict[str, torch.Tensor], device: torch.device, amp: bool = False, split: bool = False,
+                 split_key_encoder: bool = False):
         ops.require_hip(device, 'DEVA network')
         if amp and split:
             raise ValueError('amp (fp16 operands) and f16_split (fp32-accurate on the f16 pipes) are alternatives: pick one')
@@ -122,6 +123,13 @@ class CompiledGraph:
         self.sd = sd
         self.amp = bool(amp)
         self.f16_split = bool(split)
+        # second level of the opt-in: the key encoder (ResNet-50 stages + the two projections; 6 % of the flop at 5 objects,
+        # 3.7 ms of a 1080p frame on the fp32 kernels) on the split kernels too.  Its outputs feed the key projection --
+        # which stays on the fp32 kernels either way -- so the memory read's inputs then differ from the fp32 run's by
+        # fp32 round-off (like any change of accumulation order), no longer bit for bit
+        self.split_scopes = self.SPLIT_SCOPES + (('pixel_encoder.',) if split_key_encoder else ())
+        if split_key_encoder and not split:
+            raise ValueError('f16_split_key_encoder extends f16_split: set both')
         self.convs: Dict[str, PackedConv] = {}
         self.vecs: Dict[str, torch.Tensor] = {}
         for name in sd:
@@ -151,13 +159,13 @@ class CompiledGraph:
         self.proj_split = w1.shape[0]
         self.convs['pixel_encoder.proj12'] = ops.pack_conv(
             torch.cat([w1, w2], 0), torch.cat([sd['pixel_encoder.proj1.bias'], sd['pixel_encoder.proj2.bias']], 0), None,
-            device)
+            device, split=self._split_of('pixel_encoder.proj12'))
 
     def _amp_of(self, base: str) -> bool:
         return self.amp and base.startswith(self.AMP_SCOPES)
 
     def _split_of(self, base: str) -> bool:
-        return self.f16_split and base.startswith(self.SPLIT_SCOPES)
+        return self.f16_split and base.startswith(self.split_scopes)
 
     def _split_pack(self, base: str, cx: int) -> Tuple[PackedConv, PackedConv]:
         """(image part without bias, per-object part with the bias) of convolution `base`, BatchNorm folded"""

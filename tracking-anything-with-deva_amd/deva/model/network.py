@@ -31,6 +31,10 @@ class DEVA(nn.Module):
         self.f16_split = bool(config.get('f16_split', False))
         if self.amp and self.f16_split:
             raise ValueError('--amp and --f16_split are alternatives: pick one')
+        # --f16_split_key_encoder: the key encoder on the split kernels as well (deva/model/_graph.py:split_scopes)
+        self.f16_split_key_encoder = bool(config.get('f16_split_key_encoder', False))
+        if self.f16_split_key_encoder and not self.f16_split:
+            raise ValueError('--f16_split_key_encoder extends --f16_split: pass both')
         for name, module in build_parameter_tree(self.pix_feat_dim, self.key_dim, self.value_dim).items():
             self.add_module(name, module)
         for p in self.parameters():
@@ -54,7 +58,8 @@ class DEVA(nn.Module):
     def graph(self) -> CompiledGraph:
         if self._graph is None:
             device = next(self.parameters()).device
-            self._graph = CompiledGraph(self.state_dict(), device, amp=self.amp, split=self.f16_split)
+            self._graph = CompiledGraph(self.state_dict(), device, amp=self.amp, split=self.f16_split,
+                                        split_key_encoder=self.f16_split_key_encoder)
         return self._graph
 
     # ------------------------------------------------------------------ reference API
