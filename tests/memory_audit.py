@@ -58,8 +58,8 @@ class ReadTap:
         self._orig = ops.affinity_topk
         tap = self
 
-        def wrapped(key_long, shr_long, n_long, key_work, shr_work, n_work, qk, qe, k, usage_fix=None, splits=None):
-            idx, w = tap._orig(key_long, shr_long, n_long, key_work, shr_work, n_work, qk, qe, k, usage_fix, splits)
+        def wrapped(key_long, shr_long, n_long, key_work, shr_work, n_work, qk, qe, k, usage_fix=None, splits=None, **prep):
+            idx, w = tap._orig(key_long, shr_long, n_long, key_work, shr_work, n_work, qk, qe, k, usage_fix, splits, **prep)
             rows = [key_long[:n_long]] if n_long else []
             shr = [shr_long[:n_long]] if n_long else []
             rows.append(key_work[:n_work])

@@ -224,7 +224,7 @@ def test_prefetched_key_encoder_is_bit_identical(network):
 
 def test_bank_prep_cache_is_bit_identical_over_memory_frames(network):
     """the memory read keeps the bank side of its pre-filter (mean key, scales, fp16 fragments) per bucket while the bank
-    stands still (MemoryManager._prep_of, keyed on the stores' bucket versions): a 480p clip with a pre-filled 10 000-token
+    stands still (MemoryManager._prep_of, keyed on the stores' bucket versions): a 480p clip with a pre-filled 9 000-token
     long-term bank, memory frames every 2nd frame and a consolidation in the run must give the same output, bit for bit,
     with the cache and without it"""
     from deva.inference.inference_core import DEVAInferenceCore
@@ -233,7 +233,7 @@ def test_bank_prep_cache_is_bit_identical_over_memory_frames(network):
     stream = synth.FrameStream(H, W, seed=9)
     imgs = [stream.next().to(dev()) for _ in range(frames)]
     mask0 = synth.box_mask(H, W, 1).to(dev())
-    key, shr, vals = synth.prefill_bank(10000, [1], seed=1)
+    key, shr, vals = synth.prefill_bank(9000, [1], seed=1)  # (+ 2 x 128 prototypes stays below LTmax: no eviction)
     outs, reads = {}, {}
     for cached in (True, False):
         core = DEVAInferenceCore(network, cfg)
@@ -249,7 +249,7 @@ def test_bank_prep_cache_is_bit_identical_over_memory_frames(network):
         if cached and os.environ.get('DEVA_TEST_DRYRUN') != '1':  # (the emulated ops have no operands to keep)
             prep = core.memory._bank_prep[0]
             assert prep.buf is not None and prep.key is not None, 'the cached run never used the prepared-bank path'
-    assert reads[True] == reads[False] and reads[True][0] > 10000 - 200, reads   # a consolidation added prototypes
+    assert reads[True] == reads[False] and reads[True][0] > 9000, reads   # consolidations added prototypes
     assert all(torch.equal(a, b) for a, b in zip(outs[True], outs[False]))
 
 

@@ -170,17 +170,58 @@ def read(prefix, out):
             entry['l2_hit_rate'] = c['TCC_HIT_sum'] / (c['TCC_HIT_sum'] + c['TCC_MISS_sum'])
         entry['raw_per_dispatch'] = c
         res['kernels'][name] = entry
+    # one read = one dispatch of every kernel of the pre-filter path + the two gated fall-back kernels; the fp32-only passes
+    # of the same command (pre-filter forced off) dispatch affinity_topk* / affinity_finalize* with real work, so the sum
+    # below takes the pre-filter kernels only and adds the cheapest observed fall-back dispatches separately
     pf = [k for k in res['kernels'] if k.startswith('affinity_pf_')]
     tot = lambda key: sum(res['kernels'][k].get(key, 0.0) for k in pf)
     res['prefilter_total'] = {'hbm_read_bytes': tot('hbm_read_bytes (FETCH_SIZE KiB x 1024 x 2)'),
                               'hbm_write_bytes': tot('hbm_write_bytes (WRITE_SIZE KiB x 1024)')}
     res['prefilter_total']['hbm_bytes'] = res['prefilter_total']['hbm_read_bytes'] + res['prefilter_total']['hbm_write_bytes']
     res['prefilter_total']['traffic_over_algorithmic'] = res['prefilter_total']['hbm_bytes'] / res['algorithmic_bytes']
+    res['read_total'] = dict(res['prefilter_total'], note='FETCH_SIZE x 2 (gfx950) + WRITE_SIZE per dispatch, summed over the '
+                             'affinity_pf_* kernels of one deva_affinity_read at this shape (what bench.py divides by the '
+                             'algorithmic bytes)')
     with open(out, 'w') as f:
         json.dump(res, f, indent=1)
     slim = {k: {kk: vv for kk, vv in v.items() if kk != 'raw_per_dispatch'} for k, v in res['kernels'].items()}
     print(json.dumps({'prefilter_total': res['prefilter_total'], 'kernels': slim}, indent=1))
 
 
+def clock(probe_prefix, bench_prefix, out):
+    """effective shader clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel wall time, per kernel family: the register-only fp32 MFMA
+    probe and the convolution kernels of the bench command (the power-cap claim of DESIGN section 7 on a counter)"""
+    res = {'method': 'rocprofv3 --pmc GRBM_GUI_ACTIVE (+ SQ_VALU_MFMA_BUSY_CYCLES) --kernel-trace; clock = GUI_ACTIVE / 8 / (End - Start)'}
+    for tag, prefix in (('probe', probe_prefix), ('bench', bench_prefix)):
+        counters, durations = load(prefix)
+        fam = defaultdict(lambda: [0.0, 0.0, 0.0, 0])
+        for name, c in counters.items():
+            if 'GRBM_GUI_ACTIVE' not in c:
+                continue
+            key = ('mfma_probe' if 'probe' in name else 'conv_mfma_kernel' if name.startswith('conv_mfma') else
+                   'conv_f16_kernel' if name.startswith('conv_f16') else None)
+            if key is None:
+                continue
+            f = fam[key]
+            n = c['GRBM_GUI_ACTIVE'][1]
+            f[0] += c['GRBM_GUI_ACTIVE'][0]
+            f[1] += durations[name][0] * n / max(durations[name][1], 1)  # ns of the dispatches this group saw
+            f[2] += c.get('SQ_VALU_MFMA_BUSY_CYCLES', [0.0, 0])[0]
+            f[3] += n
+        for key, (gui, ns, busy, n) in fam.items():
+            if ns <= 0:
+                continue
+            e = {'dispatches': n, 'effective_clock_ghz': gui / 8.0 / ns, 'kernel_time_ms': ns / 1e6}
+            if busy:
+                e['mfma_util_frac'] = busy / (gui / 8.0 * 1024)
+            res[f'{tag}:{key}'] = e
+    with open(out, 'w') as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps(res, indent=1))
+
+
 if __name__ == '__main__':
-    {'conv': conv, 'aff': aff, 'read': read}[sys.argv[1]](sys.argv[2], sys.argv[3])
+    if sys.argv[1] == 'clock':
+        clock(sys.argv[2], sys.argv[3], sys.argv[4])
+    else:
+        {'conv': conv, 'aff': aff, 'read': read}[sys.argv[1]](sys.argv[2], sys.argv[3])

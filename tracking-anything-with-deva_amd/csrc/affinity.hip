@@ -1229,12 +1229,13 @@ __global__ __launch_bounds__(256) void readout_sparse_kernel(const int32_t* __re
       // independent 16-byte loads in flight instead of an index -> row dependency chain per term
       int row = 0, is_long = 0;
       float wj = 0.0f;
+      bool live = false;
       if (lane < k) {
         const int t = idx[(int64_t)q * k + lane];
         wj = weight[(int64_t)q * k + lane];
         is_long = (t < n_long) ? 1 : 0;
         row = is_long ? t : t - n_long;
-        bool live = t >= tok_lo && t < tok_hi;
+        live = t >= tok_lo && t < tok_hi;
         const int32_t* map = is_long ? map_long : map_work;
         if (live && map) {
           row = map[row];
@@ -1246,6 +1247,9 @@ __global__ __launch_bounds__(256) void readout_sparse_kernel(const int32_t* __re
           is_long = n_long > 0 ? is_long : 0;
         }
       }
+      // a term this launch does not add is SKIPPED, not added with weight 0: its stand-in row (row 0 of an arena that may be
+      // uninitialised on a rank without local rows) never enters the sum, so 0 * NaN cannot either
+      const uint64_t live_bits = __builtin_amdgcn_ballot_w64(live);
       const float* col = nullptr;
       for (int j0 = 0; j0 < k; j0 += 8) {
         float4 v[8];
@@ -1261,7 +1265,7 @@ __global__ __launch_bounds__(256) void readout_sparse_kernel(const int32_t* __re
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {  // terms in index order, like the one-at-a-time loop: same sums
-          if (w8[u] != 0.0f || j0 + u < k) {
+          if ((live_bits >> (j0 + u)) & 1ull) {
             acc.x += w8[u] * v[u].x;
             acc.y += w8[u] * v[u].y;
             acc.z += w8[u] * v[u].z;

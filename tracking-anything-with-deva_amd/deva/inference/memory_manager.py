@@ -48,8 +48,8 @@ class MemoryManager:
     @classmethod
     def _checked_top_k(cls, top_k) -> int:
         if top_k is None or not 1 <= int(top_k) <= cls.MAX_TOP_K:
-            raise ValueError(f'top_k={top_k} is not supported by the HIP memory read (1..{cls.MAX_TOP_K}; the '
-                             'reference default is 30)')
+            raise ValueError(f'top_k={top_k} is not supported by the HIP memory read: the limit is {cls.MAX_TOP_K} (1..32 on '
+                             f'the list kernels, 33..{cls.MAX_TOP_K} on the dense kernel; the reference default is 30)')
         return int(top_k)
 
     def __init__(self, config: Dict):
@@ -93,7 +93,12 @@ class MemoryManager:
         # memory_manager.py:47-62
         self.config_stale = True
         self.sensory_dim = config['value_dim']
-        self.top_k = self._checked_top_k(config['top_k'])
+        top_k = self._checked_top_k(config['top_k'])
+        if getattr(self, '_shard_mode', None) == 'bank' and self._shard_group is not None and top_k > self.MAX_TOP_K_SHARDED_BANK:
+            raise ValueError(f'top_k={top_k} > {self.MAX_TOP_K_SHARDED_BANK} (the largest top_k of a token-sharded bank: its '
+                             f'hand-over format holds {self.MAX_TOP_K_SHARDED_BANK} entries per range; --top_k up to '
+                             f'{self.MAX_TOP_K} needs an unsharded or query-sharded read)')
+        self.top_k = top_k
         assert self.use_long_term == config['enable_long_term'], 'cannot update this'
         assert self.count_long_term_usage == config['enable_long_term_count_usage'], 'cannot update this'
         if self.use_long_term:
