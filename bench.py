@@ -24,7 +24,7 @@ Extra objects on the JSON line:
                 `sustained_mfma_probe` = what a register-only fp32 MFMA loop reaches on this box, timed right
                 here (the chip clocks to its power budget: ~0.78 of the data sheet).  `traffic` =
                 HBM bytes per frame of those kernels from the committed rocprofv3 --pmc passes over
-                this same command (profiles/pmc_r04/conv_traffic.json, tools/pmc_bench.sh; bench.py cannot collect PMC
+                this same command (profiles/pmc_r05/conv_traffic.json, tools/pmc_bench.sh; bench.py cannot collect PMC
                 counters itself), next to the algorithmic bytes per frame computed here.
   affinity      the north-star read (similarity -> exact top-k -> softmax -> usage): event-timed at the
                 BASELINE shape (N=10 000 bank, 1080p queries) through deva_affinity_read (fp16 MFMA
@@ -33,8 +33,14 @@ Extra objects on the JSON line:
                 by), as f16 MFMA TFLOP/s, and as HBM GB/s on algorithmic and on materialised-equivalent
                 bytes (SURVEY.md §8d asks for all three).
   cpu_baseline  the CPU oracle (port of the reference's PyTorch path) on the same workload, on this
-                box's host cores: one continuous 30-frame run timed in three parts (range), per-stage ms.
-  also          further lines of BASELINE.json's metric, each with its own warm-up and timed frames:
+                box's host cores: median of three runs (warm-up frames first) with the spread, per-stage ms; the five
+                kernel-only affinity shapes: one warm-up call + median of three.
+                `config` / `roofline` also carry, as plain scalars, the lines a reader looks for first (`fps_1080p_1obj_10k_bank`,
+                `fps_1080p_8seg*`, `fps_4k_*`, `affinity_read_us_*`, `f16_split_*`): a record that keeps only the keys of
+                the contract still holds them; the full entries are in `also`.
+  also          further lines of BASELINE.json's metric, each with its own warm-up and timed frames (incl. the headline,
+                the north-star target line and the 8-segment clip with --f16_split: fp32-accurate convolutions on the f16
+                matrix pipes, `dtype: "f32 via 3x f16 split, f32 acc"`, conv roofline against the f16 peak counting 3 MFMAs):
                 1080p / detections every 5th frame / 10k-token long-term bank (BASELINE configs[2] and
                 the north-star target line) and 4K / 50k-token bank (configs[4] on this one GPU).  Each
                 names the -m gpu test that gates its parity.
@@ -1067,7 +1073,7 @@ def main():
             torch.cuda.synchronize()
         # HBM traffic of these kernels per frame, from the committed rocprofv3 --pmc passes over this same
         # command (tools/pmc_bench.sh; FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes)
-        for pmc_dir in ('pmc_r04', 'pmc_r03'):
+        for pmc_dir in ('pmc_r05', 'pmc_r04', 'pmc_r03'):
             pmc = os.path.join(ROOT, 'profiles', pmc_dir, 'conv_traffic.json')
             if not os.path.exists(pmc):
                 continue
