@@ -854,12 +854,18 @@ def extra_lines(net, device, cfg, args):
                   'test_conv_split_is_fp32_accurate (against fp64) + tests/test_gpu_e_network.py::'
                   'test_f16_split_lockstep_teacher_forced (480p, 1080p; fp32 bounds) + test_f16_split_e2e_against_reference_golden '
                   '+ the whole -m gpu suite under DEVA_TEST_F16_SPLIT=1 (profiles/r05/tests_split/)')
-    _split = []
+    SPLIT_ALL_DTYPE = 'f32 via 3x f16 split, f32 acc (key encoder, value encoder, mask decoder); f32 elsewhere'
+    _split, _split_all = [], []
 
     def split_net():
         if not _split:
             _split.append(build_network(device, split=True)[0])
         return _split[0]
+
+    def split_all_net():
+        if not _split_all:
+            _split_all.append(build_network(device, split=True, split_key_encoder=True)[0])
+        return _split_all[0]
     return [
         line('propagation FPS @480p (5 objects, working memory only) WITH next-frame key-encoder prefetch',
              lambda: run_prefetched(net, device, cfg, args.height, args.width, args.objects, args.steps, args.warmup,
@@ -918,6 +924,20 @@ def extra_lines(net, device, cfg, args):
              lambda: run_1080p_segments(split_net(), device, steps=25, warmup=6, segments=8, conv_roofline=True), 25, 6,
              'BASELINE configs[2] (the 8-segment clip above) with --f16_split', SPLIT_GATE, 'state_at_end',
              dtype=SPLIT_DTYPE, target_fps=30.0),
+        line('propagation FPS @480p, --f16_split --f16_split_key_encoder (5 objects, working memory only)',
+             lambda: run_480p_headline(split_all_net(), device, cfg, args), args.steps, args.warmup,
+             'the headline clip and loop with the key encoder on the split kernels too (second level of the opt-in)',
+             SPLIT_GATE, 'state_at_end', dtype=SPLIT_ALL_DTYPE),
+        line('propagation FPS @1080p, --f16_split --f16_split_key_encoder (1 object, 10k-token long-term bank)',
+             lambda: run_1080p(split_all_net(), device, steps=25, warmup=6, detections=False, conv_roofline=True), 25, 6,
+             'the north-star target line with the key encoder on the split kernels too', SPLIT_GATE, 'state_at_end',
+             dtype=SPLIT_ALL_DTYPE, target_fps=30.0),
+        line('propagation FPS @1080p, --f16_split --f16_split_key_encoder (8-segment detections merged every 5th frame, ~10 live '
+             'objects, 10k-token long-term bank)',
+             lambda: run_1080p_segments(split_all_net(), device, steps=25, warmup=6, segments=8, conv_roofline=True), 25, 6,
+             'BASELINE configs[2] (the 8-segment clip above) with the key encoder on the split kernels too (second level of the '
+             'opt-in: the memory read\'s inputs then move by fp32 round-off)', SPLIT_GATE, 'state_at_end',
+             dtype=SPLIT_ALL_DTYPE, target_fps=30.0),
         line('propagation FPS @4K (1 object, 50k-token long-term bank), one GPU',
              lambda: run_long4k(net, device, steps=20, warmup=5, seed=11, shard=None, dist=None)[:2], 20, 5,
              'BASELINE configs[4] on ONE GPU: synthetic 3840x2160 clip, 1 object, long-term memory pre-filled to '
@@ -1128,13 +1148,17 @@ def main():
             short = (('fps_480p_1obj', '@480p (1 object'), ('fps_1080p_1obj_10k_bank', '@1080p (1 object, 10k'),
                      ('fps_1080p_8seg', '@1080p (8-segment'), ('fps_1080p_8seg_amp', '@1080p, --amp'),
                      ('fps_480p_5obj_f16_split', '@480p, --f16_split'), ('fps_1080p_1obj_10k_bank_f16_split', '@1080p, --f16_split (1 object'),
-                     ('fps_1080p_8seg_f16_split', '@1080p, --f16_split (8-segment'), ('fps_4k_1obj_50k_bank', '@4K'))
+                     ('fps_1080p_8seg_f16_split', '@1080p, --f16_split (8-segment'),
+                     ('fps_480p_5obj_f16_split_key_encoder', '@480p, --f16_split --f16_split_key_encoder'),
+                     ('fps_1080p_1obj_10k_bank_f16_split_key_encoder', '@1080p, --f16_split --f16_split_key_encoder (1 object'),
+                     ('fps_1080p_8seg_f16_split_key_encoder', '@1080p, --f16_split --f16_split_key_encoder (8-segment'),
+                     ('fps_4k_1obj_50k_bank', '@4K'))
             for key, frag in short:
                 for e in result['also']:
                     if frag in e['metric'] and e.get('value') is not None:
                         result['config'][key] = round(e['value'], 2)
                         cr = (e.get('config', {}).get('state_at_end') or {}).get('conv_roofline', {}).get('split_kernels')
-                        if cr and key.endswith('f16_split'):
+                        if cr and 'f16_split' in key:
                             result['roofline'][key.replace('fps_', 'f16_split_fp32_equiv_tflops_')] = round(cr['fp32_equivalent_tflops'], 1)
                             result['roofline'][key.replace('fps_', 'f16_split_frac_of_f16_peak_')] = round(cr['frac_of_f16_mfma_peak'], 3)
                         break

@@ -15,7 +15,7 @@ for t in tests tests_split; do
     if [ $(stat -c %s $f) -gt 200000 ]; then tail -c 150000 $f > $D/$t/$b.tail.log; else cp $f $D/$t/$b.log; fi
   done
 done
-for f in gpurun_out/lab/split_*.txt gpurun_out/lab/amp_v4.txt gpurun_out/lab/pmc_split/table.txt; do
+for f in gpurun_out/lab/split_*.txt gpurun_out/lab/amp_v4.txt gpurun_out/lab/pmc_split/table.txt gpurun_out/lab/pmc_split_final/table.txt gpurun_out/lab/pmc_split_final_zero/table.txt; do
   [ -f $f ] && cp $f $D/lab/$(basename $(dirname $f))_$(basename $f)
 done
 ls -la $D $D/tests $D/tests_split $D/lab | head -80

@@ -190,30 +190,33 @@ def read(prefix, out):
 
 def clock(probe_prefix, bench_prefix, out):
     """effective shader clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel wall time, per kernel family: the register-only fp32 MFMA
-    probe and the convolution kernels of the bench command (the power-cap claim of DESIGN section 7 on a counter)"""
-    res = {'method': 'rocprofv3 --pmc GRBM_GUI_ACTIVE (+ SQ_VALU_MFMA_BUSY_CYCLES) --kernel-trace; clock = GUI_ACTIVE / 8 / (End - Start)'}
+    probe and the convolution kernels of the bench command; MFMA busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GUI_ACTIVE / 8 x
+    1024 SIMDs).  Every counter is averaged per dispatch over the passes that collected it (counters of one kernel may come
+    from different passes of the same command)."""
+    res = {'method': 'rocprofv3 --pmc GRBM_GUI_ACTIVE (+ SQ_VALU_MFMA_BUSY_CYCLES) --kernel-trace; clock = GUI_ACTIVE / 8 / (End - Start), '
+                     'per-dispatch averages; the bench command is `python bench.py --steps 5 --warmup 2 --no_cpu_baseline --no_extra --no_affinity`'}
     for tag, prefix in (('probe', probe_prefix), ('bench', bench_prefix)):
         counters, durations = load(prefix)
-        fam = defaultdict(lambda: [0.0, 0.0, 0.0, 0])
+        fam = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+        dur = defaultdict(lambda: [0.0, 0])
         for name, c in counters.items():
-            if 'GRBM_GUI_ACTIVE' not in c:
-                continue
-            key = ('mfma_probe' if 'probe' in name else 'conv_mfma_kernel' if name.startswith('conv_mfma') else
+            key = ('mfma_probe_kernel' if 'probe' in name else 'conv_mfma_kernel' if name.startswith('conv_mfma') else
                    'conv_f16_kernel' if name.startswith('conv_f16') else None)
-            if key is None:
+            if key is None or 'GRBM_GUI_ACTIVE' not in c:
                 continue
-            f = fam[key]
-            n = c['GRBM_GUI_ACTIVE'][1]
-            f[0] += c['GRBM_GUI_ACTIVE'][0]
-            f[1] += durations[name][0] * n / max(durations[name][1], 1)  # ns of the dispatches this group saw
-            f[2] += c.get('SQ_VALU_MFMA_BUSY_CYCLES', [0.0, 0])[0]
-            f[3] += n
-        for key, (gui, ns, busy, n) in fam.items():
-            if ns <= 0:
-                continue
-            e = {'dispatches': n, 'effective_clock_ghz': gui / 8.0 / ns, 'kernel_time_ms': ns / 1e6}
-            if busy:
-                e['mfma_util_frac'] = busy / (gui / 8.0 * 1024)
+            for cn in ('GRBM_GUI_ACTIVE', 'SQ_VALU_MFMA_BUSY_CYCLES'):
+                if cn in c:
+                    fam[key][cn][0] += c[cn][0]
+                    fam[key][cn][1] += c[cn][1]
+            dur[key][0] += durations[name][0]
+            dur[key][1] += durations[name][1]
+        for key, cs in fam.items():
+            gui = cs['GRBM_GUI_ACTIVE'][0] / max(cs['GRBM_GUI_ACTIVE'][1], 1) / 8.0  # cycles per dispatch
+            ns = dur[key][0] / max(dur[key][1], 1)
+            e = {'dispatches_per_pass': dur[key][1], 'avg_kernel_us': ns / 1e3, 'effective_clock_ghz': gui / ns}
+            if 'SQ_VALU_MFMA_BUSY_CYCLES' in cs and cs['SQ_VALU_MFMA_BUSY_CYCLES'][1]:
+                e['mfma_busy_frac'] = cs['SQ_VALU_MFMA_BUSY_CYCLES'][0] / cs['SQ_VALU_MFMA_BUSY_CYCLES'][1] / (gui * 1024)
+                e['tflops_fp32_mfma_at_this_clock_and_busy_frac'] = 64.0 * 1024 * e['effective_clock_ghz'] * e['mfma_busy_frac'] / 1e3
             res[f'{tag}:{key}'] = e
     with open(out, 'w') as f:
         json.dump(res, f, indent=1)
