@@ -18,7 +18,8 @@ def _check(name, got, want, tol=1e-5):
     assert err <= tol * max(1.0, want.abs().max().item()), (name, err)
 
 
-@pytest.mark.parametrize('shape', [(1, 64, 48, 64), (2, 8, 45, 65), (1, 3, 1, 1), (3, 5, 2, 7)])
+# (widths that are multiples of 8 take the four-outputs-per-thread kernel, the others the scalar one)
+@pytest.mark.parametrize('shape', [(1, 64, 48, 64), (2, 8, 45, 65), (1, 3, 1, 1), (3, 5, 2, 7), (2, 3, 5, 8), (1, 2, 9, 16), (1, 4, 1, 24)])
 @pytest.mark.parametrize('relu', [False, True])
 def test_maxpool(shape, relu):
     x = rand(torch.Generator().manual_seed(1), *shape)
