@@ -531,7 +531,9 @@ int launch_conv_f16(const ConvArgs& a, hipStream_t st) {
     // tiles (wave tile 128x32, one workgroup per CU) -1..4 %, 128x128 on four waves (wave tile 64x64) +-1 %: under real
     // operand data the kernels run at the chip's power limit (all-zero activations: +25..34 % at an unchanged instruction
     // stream), so fewer LDS bytes per MFMA buy nothing.
-    if (a.cout >= 128 && blocks128 >= 64) return launch_tile_f16<128, 128, 2, 4, 4, 32, 2>(a, kind, st);
+    // (few tiles but a long K loop -- the 512 -> 512 3x3 image part of the fusers at 30x54: 52 tiles, 144 steps -- also takes
+    // the 128x128 tile: its split-K fills the chip, 45 against 72 us on 64x64 tiles)
+    if (a.cout >= 128 && (blocks128 >= 64 || (blocks128 >= 32 && a.K >= 128 * 32))) return launch_tile_f16<128, 128, 2, 4, 4, 32, 2>(a, kind, st);
     return launch_tile_f16<64, 64, 2, 2, 2, 32, 2>(a, kind, st);
   }
   if (a.cout >= 128 && blocks128 >= 64) return launch_tile_f16<128, 128, 2, 4, 4, 64, 1>(a, kind, st);
