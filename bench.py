@@ -190,7 +190,8 @@ class ConvTimer:
             # the shapes csrc/conv_f16.hip takes when amp is requested (launch_conv_f16 + the vector-gather geometry)
             # (d.amp: 1 = fp16 operands, K steps of 64; 2 = hi/lo split, K steps of 32)
             gran = 64 if d.amp == 1 else 32
-            f16 = bool(d.amp and d.weight_f16 and d.stride == 1 and d.cout >= 64 and d.c0 % gran == 0 and d.c1 % gran == 0
+            tail_ok = d.amp == 2 and d.kh == 1 and (d.c0 % gran == 0 if d.c1 else True)  # split 1x1: partial last K step
+            f16 = bool(d.amp and d.weight_f16 and d.stride == 1 and d.cout >= 64 and ((d.c0 % gran == 0 and d.c1 % gran == 0) or tail_ok)
                        and ((d.kh == 1 and d.pad == 0) or (d.kh == 3 and d.pad == 1)) and (oh * ow) % 4 == 0 and ow >= 4)
             f16 = (d.amp if f16 else 0)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -60,7 +60,9 @@ def split_takes(pc, x0, x1, stride, pad):
     geometry of deva_conv2d); everything else runs the fp32 kernels although split is requested"""
     c0, c1 = x0.shape[1], 0 if x1 is None else x1.shape[1]
     h, w = x0.shape[-2:]
-    return (pc.weight_split is not None and stride == 1 and pc.cout >= 64 and c0 % 32 == 0 and c1 % 32 == 0 and
+    whole = c0 % 32 == 0 and c1 % 32 == 0
+    tail = pc.kh == 1 and (c0 % 32 == 0 if c1 else True)  # 1x1: a partial last K step (513 = 512 + 1 channels) is taken too
+    return (pc.weight_split is not None and stride == 1 and pc.cout >= 64 and (whole or tail) and
             ((pc.kh == 1 and pad == 0) or (pc.kh == 3 and pad == 1)) and (h * w) % 4 == 0 and w >= 4)
 
 

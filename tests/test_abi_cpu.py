@@ -150,7 +150,7 @@ def test_conv_pack_split_matches_python_packing(library):
     from deva.hip import ops
     L = hip.lib()
     g = torch.Generator().manual_seed(9)
-    for cout, cin, k, gain in ((64, 64, 1, 0.05), (72, 96, 3, 3.0), (1536, 32, 3, 1e-3), (40, 160, 1, 200.0)):
+    for cout, cin, k, gain in ((64, 64, 1, 0.05), (72, 96, 3, 3.0), (1536, 32, 3, 1e-3), (40, 160, 1, 200.0), (64, 513, 1, 0.1)):
         w = torch.randn(cout, cin, k, k, generator=g) * gain
         w.view(-1)[::7] *= 1e-6   # lo planes in the fp16 subnormal range, some exact zeros
         ref, e_ref = ops.pack_split(w)
@@ -168,6 +168,8 @@ def test_conv_pack_split_matches_python_packing(library):
         taps = k * k
         wk = (w.reshape(cout, cin // 32, 32, taps).permute(1, 3, 2, 0).reshape(-1, cout) if taps > 1
               else w.reshape(cout, cin).t()) * 2.0**e_ref
+        assert rec.shape[0] == (taps * cin + 31) // 32 * 32 and bool((rec[taps * cin:] == 0).all())  # (1x1: zero rows up to a K step)
+        rec = rec[:taps * cin]
         assert bool(((rec - wk).abs() <= torch.maximum(wk.abs() * 2.0**-22, torch.tensor(2.0**-25))).all())
     w = torch.randn(64, 48, 3, 3, generator=g)  # 48 % 32 != 0: not a split layer
     assert ops.pack_split(w) == (None, 0)

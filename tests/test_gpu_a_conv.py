@@ -236,6 +236,11 @@ SPLIT_CASES = [
     ('split_small_inputs', 256, 0, 256, 3, 2, 12, 16, False, False, 'none', ops.ACT_NONE, 1e-4),
     ('split_large_inputs', 256, 0, 256, 3, 2, 12, 16, False, False, 'none', ops.ACT_NONE, 3e3),
     ('split_ragged_cout', 96, 32, 200, 3, 2, 20, 36, True, True, 'full', ops.ACT_RELU, 1.0),
+    # 1x1 with a partial last K step: the one-channel tails of sensory_compress / g4_conv, a single source with a tail
+    ('split_1x1_tail513', 512, 1, 512, 1, 2, 6, 8, False, False, 'full', ops.ACT_NONE, 1.0),
+    ('split_1x1_tail257_bcast', 256, 1, 512, 1, 3, 30, 54, True, False, 'full', ops.ACT_RELU, 1.0),
+    ('split_1x1_single_tail', 72, 0, 136, 1, 2, 10, 12, False, True, 'none', ops.ACT_NONE, 1.0),
+    ('split_1x1_tail_31_of_32', 64, 31, 64, 1, 1, 6, 8, False, False, 'none', ops.ACT_SIGMOID, 1.0),
 ]
 
 

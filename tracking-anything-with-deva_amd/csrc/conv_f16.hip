@@ -172,6 +172,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
   constexpr int ASETS = (SPLIT && ROW && BM < 256) ? 1 : 2;  // (the 128-wide split row kind is register-bound: weights one K step ahead)
   f32x4 ra[ASETS][A_V4];
   f32x4 rb[TPT][2];       // per task: two channels x four pixels
+  int rb_rows = BKH;      // channels of the staged activation tile that exist (KIND 0: a partial last step)
   float rh = 0.0f;        // halo threads: one channel of one halo pixel
 
   auto load_a = [&](int t_raw, auto setc) {
@@ -194,8 +195,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
       shift = ((t - chunk * 9) / 3 - 1) * p.W;
     }
     const bool first = cbase < p.c0;
-    const float* base = (first ? p.in0 : p.in1) + ((int64_t)(first ? cbase : cbase - p.c0) * p.HW + shift);
-    const __amdgpu_buffer_rsrc_t r = make_rsrc(base, 0x7fffffff);
+    const int lc = first ? cbase : cbase - p.c0;  // first channel of the step inside its source
+    const float* base = (first ? p.in0 : p.in1) + ((int64_t)lc * p.HW + shift);
+    int range = 0x7fffffff;
+    if constexpr (!ROW) {
+      // 1x1 layers may end in a partial step (513 = 512 + 1 channels): the rows beyond the source's last channel are not
+      // loaded from beyond the tensor (the descriptor ends where the tensor ends: such loads return 0) and are zeroed
+      // before they are staged (rb_rows); the weights of those k are zero as well
+      rb_rows = min(BKH, (first ? p.c0 : p.c1) - lc);
+      if (rb_rows < BKH) range = (int)max((int64_t)0, ((first ? p.in0_span : p.in1_span) - (int64_t)lc * p.HW) * 4);
+    }
+    const __amdgpu_buffer_rsrc_t r = make_rsrc(base, range);
 #pragma unroll
     for (int i = 0; i < TPT; ++i)
 #pragma unroll
@@ -216,6 +226,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv_f16_kernel(
   auto store_b = [&](int buf) {
     if (DEVA_ABL(1)) return;
     _Float16* bt = sB + buf * B_HALFS;
+    if (!ROW && rb_rows < BKH) {  // (wave-uniform, the last step of a 513- / 257-channel layer only)
+#pragma unroll
+      for (int i = 0; i < TPT; ++i)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+          if (2 * (kr0 + i * RSTEP) + c >= rb_rows) rb[i][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
 #pragma unroll
     for (int i = 0; i < TPT; ++i) {
       u32x4 hi4, lo4;
@@ -505,9 +522,14 @@ int launch_tile_f16(const ConvArgs& a, int kind, hipStream_t st) {
 // -> 0 launched, 1 launch error, -1 not eligible (the caller runs the fp32 kernels)
 int launch_conv_f16(const ConvArgs& a, hipStream_t st) {
   const int bkh = a.prec == 2 ? 32 : 64;
-  if (!a.w16 || !a.vec_ok || a.stride != 1 || a.cout < 64 || a.c0 % bkh || a.c1 % bkh) return -1;
+  if (!a.w16 || !a.vec_ok || a.stride != 1 || a.cout < 64) return -1;
+  const bool is1x1 = a.KH == 1 && a.KW == 1;
+  // whole K steps per source; the split 1x1 kind also takes a partial LAST step (the second source's tail, or the only
+  // source's: sensory_compress 512 + 1, g4_conv 256 + 1): deva_conv_pack_split pads those weights with zeros
+  const bool tail_ok = a.prec == 2 && is1x1 && (a.c1 > 0 ? a.c0 % bkh == 0 : true);
+  if (!tail_ok && (a.c0 % bkh || a.c1 % bkh)) return -1;
   int kind;
-  if (a.KH == 1 && a.KW == 1) {
+  if (is1x1) {
     kind = 0;
   } else if (a.KH == 3 && a.KW == 3 && a.pad == 1) {
     kind = 1;

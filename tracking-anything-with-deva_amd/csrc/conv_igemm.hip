@@ -905,8 +905,9 @@ extern "C" int64_t deva_conv_pack_f16(const float* w_oihw, uint16_t* out, int co
 // hi / lo fp16 planes of the split path (host side, model load): with s = 2^e, e such that the largest |w| * s lies in
 // [2^13, 2^14) (e = 0 for an all-zero layer), hi = fp16(w s), lo = fp16(w s - hi) (round to nearest even; w s and the
 // difference are exact in fp32), element (k, plane, m) at (((k/8)*2 + plane)*cout_pad + m)*8 + k%8; K order: tap-major
-// for 1x1, 32-channel slabs otherwise (k = ((c/32)*taps + tap)*32 + c%32).  Needs cin % 32 == 0, else -1: the layer
-// stays on the fp32 kernels.  *scale_log2 = e; deva_conv2d multiplies the accumulators by 2^-e.
+// for 1x1 (any cin: K is padded with zero rows to a multiple of 32), 32-channel slabs otherwise
+// (k = ((c/32)*taps + tap)*32 + c%32; needs cin % 32 == 0, else -1: the layer stays on the fp32 kernels).
+// *scale_log2 = e; deva_conv2d multiplies the accumulators by 2^-e.
 extern "C" int64_t deva_conv_pack_split(const float* w_oihw, uint16_t* out, int cout, int cin, int kh, int kw, int* cout_pad_out,
                                         int* scale_log2) {
   using namespace deva;
@@ -915,8 +916,8 @@ extern "C" int64_t deva_conv_pack_split(const float* w_oihw, uint16_t* out, int 
     return -1;
   }
   const int taps = kh * kw;
-  if (cin % 32 != 0) return -1;
-  const int K = taps * cin;
+  if (cin % 32 != 0 && taps > 1) return -1;
+  const int K = (taps * cin + 31) / 32 * 32;  // 1x1 layers with a channel tail (513, 257): zero rows up to the next K step
   const int cout_pad = (cout + 31) / 32 * 32;
   const int64_t elems = (int64_t)K * 2 * cout_pad;
   *cout_pad_out = cout_pad;

@@ -109,23 +109,24 @@ def pack_split(w: torch.Tensor) -> Tuple[Optional[torch.Tensor], int]:
     """[cout][cin][kh][kw] fp32 (BatchNorm already folded) -> (hi / lo fp16 planes of the split kernels, e): with
     s = 2^e such that max|w| * s lies in [2^13, 2^14), hi = fp16(w s), lo = fp16(w s - hi); element (k, plane, m) at
     (((k/8)*2 + plane)*cout_pad + m)*8 + k%8; K tap-major for 1x1, 32-channel slabs otherwise
-    (k = ((c/32)*taps + tap)*32 + c%32).  (None, 0) when the kernels cannot take the layer (cin % 32 != 0, a single
-    output channel, non-finite weights).  Same arithmetic as deva_conv_pack_split."""
+    (k = ((c/32)*taps + tap)*32 + c%32); a 1x1 layer may have any cin (513, 257: K is padded with zero rows to a multiple
+    of 32).  (None, 0) when the kernels cannot take the layer (3x3 with cin % 32 != 0, a single output channel, non-finite
+    weights).  Same arithmetic as deva_conv_pack_split."""
     import math
     cout, cin, kh, kw = w.shape
     taps = kh * kw
-    if cin % 32 or cout < 2 or not bool(torch.isfinite(w).all()):
+    if (cin % 32 and taps > 1) or cout < 2 or not bool(torch.isfinite(w).all()):
         return None, 0
     wmax = float(w.abs().max())
     e = 0
     if wmax > 0.0:
         e = max(-120, min(120, 14 - math.frexp(wmax)[1]))
     cout_pad = (cout + 31) // 32 * 32
-    wk = torch.zeros(taps * cin, cout_pad, dtype=torch.float32, device=w.device)
+    wk = torch.zeros((taps * cin + 31) // 32 * 32, cout_pad, dtype=torch.float32, device=w.device)  # (1x1: K padded to 32)
     if taps > 1:
         wk[:, :cout] = w.reshape(cout, cin // 32, 32, taps).permute(1, 3, 2, 0).reshape(-1, cout)
     else:
-        wk[:, :cout] = w.reshape(cout, cin).t()
+        wk[:cin, :cout] = w.reshape(cout, cin).t()
     ws = torch.ldexp(wk, torch.tensor(e, dtype=torch.int32, device=w.device))  # exact: a power of two
     hi = ws.to(torch.float16)
     lo = (ws - hi.float()).to(torch.float16)
