@@ -114,8 +114,10 @@ typedef struct deva_conv_desc {
    * K-block runs hi.hi + hi.lo + lo.hi with fp32 accumulation, and the accumulators are scaled back exactly.
    * split_flag: one device int the caller has zeroed; the kernel sets it when an input lay beyond the fp16 range
    * (|x| > 65504 or non-finite), and the fp32 kernels -- launched behind the split kernel on the same stream, gated on
-   * that int -- then produce the output.  Shapes the split kernels do not cover (stride 2, channel counts that are not
-   * multiples of 32, single-channel heads, unguarded inputs) run the fp32 kernels on `weight` directly. */
+   * that int -- then produce the output.  Shapes the split kernels do not cover (stride 2, 3x3 layers whose channel counts
+   * are not multiples of 32, kernels other than 1x1 / 3x3, single-channel heads, unguarded inputs) run the fp32 kernels
+   * on `weight` directly.  1x1 layers may have any channel count behind a first source that is a multiple of 32
+   * (513 = 512 + 1, 257 = 256 + 1: a partial last K step). */
   int32_t split_scale_log2;
   int32_t* split_flag;
 } deva_conv_desc;
@@ -125,7 +127,8 @@ int deva_conv2d(const deva_conv_desc* desc, void* stream);
  * -1 when the layer is not eligible (cin % 64 != 0) or on bad arguments */
 int64_t deva_conv_pack_f16(const float* w_oihw, uint16_t* out, int cout, int cin, int kh, int kw, int* cout_pad);
 /* hi / lo fp16 planes of the split path (HOST pointers, model load): -> number of uint16 elements (out == NULL: size
- * query; *scale_log2 is set either way), -1 when the layer is not eligible (cin % 32 != 0), holds a non-finite weight,
+ * query; *scale_log2 is set either way), -1 when the layer is not eligible (kh*kw > 1 and cin % 32 != 0; a 1x1 layer of any
+ * cin is packed with its K rows padded with zeros to a multiple of 32), holds a non-finite weight,
  * or on bad arguments.  *scale_log2 = e with max|w| * 2^e in [2^13, 2^14): pass it as deva_conv_desc.split_scale_log2. */
 int64_t deva_conv_pack_split(const float* w_oihw, uint16_t* out, int cout, int cin, int kh, int kw, int* cout_pad,
                              int* scale_log2);
