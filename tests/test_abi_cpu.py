@@ -175,3 +175,23 @@ def test_conv_pack_split_matches_python_packing(library):
     assert ops.pack_split(w) == (None, 0)
     assert L.deva_conv_pack_split(w.contiguous().data_ptr(), None, 64, 48, 3, 3, ctypes.byref(ctypes.c_int(0)),
                                   ctypes.byref(ctypes.c_int(0))) == -1
+
+
+def test_conv_descriptor_validation_of_the_f16_paths(library):
+    """deva_conv2d refuses, before any launch: amp outside {0, 1, 2}; the split path (amp = 2 with weights) without a flag;
+    k-quad interleaved weights for a single output channel"""
+    from deva import hip
+    L = hip.lib()
+    d = hip.ConvDesc()
+    d.in0, d.weight, d.out = 4096, 8192, 12288               # never dereferenced: validation fails first
+    d.c0, d.c1, d.batch, d.height, d.width = 32, 0, 1, 8, 8
+    d.cout, d.cout_pad, d.k_layout = 64, 64, hip.KLAYOUT_TAP_MAJOR | hip.KLAYOUT_Q4
+    d.kh = d.kw = d.stride = 1
+    d.amp = 3
+    assert L.deva_conv2d(ctypes.byref(d), None) != 0 and b'amp must be' in L.deva_hip_last_error()
+    d.amp, d.weight_f16, d.split_flag = 2, 16384, None
+    assert L.deva_conv2d(ctypes.byref(d), None) != 0 and b'split_flag' in L.deva_hip_last_error()
+    d.amp, d.weight_f16, d.cout, d.cout_pad = 0, None, 1, 32
+    assert L.deva_conv2d(ctypes.byref(d), None) != 0 and b'cout > 1' in L.deva_hip_last_error()
+    assert L.deva_affinity_bank_prep_bytes(0) == 512
+    assert L.deva_affinity_bank_prep_bytes(10000) == 512 + (313 * 9216 + 255) // 256 * 256   # 313 tiles of 32 tokens

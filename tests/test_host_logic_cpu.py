@@ -502,3 +502,76 @@ def test_conv_tile_order_is_a_permutation():
     assert {1, 2, 3, 5, 8} <= seen_groups  # partial last groups (3 of 2, 5 of 3, ...) were among the cases
     # the two sizes the comments quote: 3x3 on 128x128 tiles -> 2 cout tiles per group, 1x1 -> 8
     assert group_m(9, 1, 128, 128, 768) == 2 and group_m(1, 1, 128, 128, 2026) == 8
+
+
+def test_bank_versions_follow_every_change_of_the_rows(emu):
+    """the cached pre-filter operands of the memory read (MemoryManager._prep_of) are keyed on
+    KeyValueMemoryStore.version(bucket): it must change with EVERY call that adds, drops or moves key / shrinkage rows
+    (add, sieve / range removal, least-usage eviction, purge of the bucket) and with nothing else (usage bookkeeping,
+    read-only views) -- a missed bump would be a silently stale read"""
+    from deva.inference.kv_memory_store import KeyValueMemoryStore
+    g = torch.Generator().manual_seed(0)
+    store = KeyValueMemoryStore(save_selection=True, save_usage=True)
+    assert store.version(0) == 0
+
+    def frame(n):
+        return (torch.randn(64, n, generator=g), {1: torch.randn(512, n, generator=g), 2: torch.randn(512, n, generator=g)},
+                torch.rand(1, n, generator=g) + 1, torch.rand(64, n, generator=g))
+
+    seen = []
+
+    def changed(what):
+        v = store.version(0)
+        assert v not in seen and v > 0, f'{what}: the bucket version did not change'
+        seen.append(v)
+
+    k, v, s, e = frame(40)
+    store.add(k, v, s, e)
+    changed('first add')
+    k, v, s, e = frame(24)
+    store.add(k, v, s, e)
+    changed('append')
+    before = store.version(0)
+    store.update_bucket_usage(0, torch.rand(64))          # counters only: the rows stand still
+    store.get_all_sliced(0, 8, 16)
+    _ = store.key, store.shrinkage, store.size(0), store.engaged(0)
+    assert store.version(0) == before, 'usage bookkeeping / read-only views must not invalidate the prepared operands'
+    store.sieve_by_range(0, 8, -8, 10)
+    changed('sieve_by_range')
+    store.remove_obsolete_features(0, store.size(0) - 5)
+    changed('remove_obsolete_features')
+    k, v, s, e = frame(12)
+    store.add(k, {3: v[1]}, s, e)                          # a second bucket: bucket 0 untouched
+    assert store.version(0) == seen[-1] and store.version(1) > seen[-1]
+    store.purge_except([3])
+    assert store.version(0) == 0 and store.version(1) > 0  # purged bucket: nothing left to be stale about
+
+
+def test_memory_manager_keys_its_prepared_banks_on_the_versions(emu):
+    """MemoryManager._prep_of: one BankPrep per live bucket, a key that changes when either store's bucket version (or an
+    arena's address) changes, nothing handed out when bank_prep_enabled is off, entries of purged buckets dropped"""
+    from deva.inference.memory_manager import MemoryManager
+    cfg = synth.base_config(mem_every=1, max_mid_term_frames=3, min_mid_term_frames=2, num_prototypes=4)
+    mem = MemoryManager(cfg)
+    g = torch.Generator().manual_seed(1)
+    h, w = 4, 6
+
+    def add(objs):
+        key = torch.randn(1, 64, h, w, generator=g)
+        mem.add_memory(key, torch.rand(1, 1, h, w, generator=g) + 1, torch.randn(1, len(objs), 512, h, w, generator=g), objs,
+                       selection=torch.rand(1, 64, h, w, generator=g))
+
+    add([1, 2])
+    p0 = mem._prep_of(0, False)
+    assert set(p0) == {'prep', 'prep_key'} and mem._prep_of(0, False)['prep'] is p0['prep']
+    assert mem._prep_of(0, False)['prep_key'] == p0['prep_key']
+    add([1, 2])
+    assert mem._prep_of(0, False)['prep_key'] != p0['prep_key'], 'a memory frame must change the key of the bucket'
+    add([1, 2, 7])                                                     # object 7 opens bucket 1
+    assert mem._prep_of(1, False)['prep'] is not p0['prep']
+    mem.bank_prep_enabled = False
+    assert mem._prep_of(0, False) == {}
+    mem.bank_prep_enabled = True
+    mem.purge_except([7])
+    mem._prep_of(1, False)
+    assert 0 not in mem._bank_prep and 1 in mem._bank_prep
