@@ -291,7 +291,14 @@ def test_amp_lockstep_teacher_forced(recipe_state_dict):
         # closer than amp is to fp32 (5.0e-3 / 9.7e-4, printed below).  The kernels are therefore held to the amp
         # arithmetic where it is a function -- single convolutions, 1e-6, tests/test_gpu_a_conv.py -- and whole stages to
         # the order of the quantisation noise
-        worst = lockstep.run(net, P, 480, 864, 3, 3, dev(), stage_tol=1e-1, logits_tol=2e-2, prob_tol=5e-3)
+        # Per stage: the key encoder and the key projection are not under --amp and keep the fp32 gate; the value encoder
+        # and the deep sensory update sit upstream of the first rounding-boundary flip and are held to ~4x their
+        # measured worst (MI355X: value 6.7e-4, sensory_deep 4.7e-3, logits 1.0e-3 relative); only the decoder's GRU
+        # output (sensory_seg, measured 3.2e-2) keeps the loose bound.
+        tight = dict.fromkeys(('f16', 'f8', 'f4', 'feat', 'key', 'shrinkage', 'selection'), 2e-4)
+        tight.update(value=3e-3, sensory_deep=2e-2, logits=5e-3, prob=5e-3)
+        worst = lockstep.run(net, P, 480, 864, 3, 3, dev(), stage_tol=1e-1, logits_tol=2e-2, prob_tol=5e-3,
+                             stage_tols=tight)
     print('amp lockstep 480p worst relative errors:', json.dumps({k: float(f'{v:.3g}') for k, v in worst.items()}))
     # distance of the amp arithmetic from the fp32 target on one decoder pass (reported, bounded loosely: fp16 operand
     # rounding is 2^-11 relative per operand)
