@@ -59,7 +59,7 @@ def _run(rank, world, port, name, mode, out):
     for p in (ROOT, os.path.join(ROOT, 'tracking-anything-with-deva_amd'), os.path.join(ROOT, 'tests')):
         sys.path.insert(0, p)
     torch.set_grad_enabled(False)
-    torch.set_num_threads(2)
+    torch.set_num_threads(max(1, min(4, (os.cpu_count() or 2) // world)))
     import emu_ops
     import scenarios
     from workload import synth, weights
