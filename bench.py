@@ -948,6 +948,90 @@ def extra_lines(net, device, cfg, args):
     ]
 
 
+LINE_LIMIT = 4096  # bytes of the final stdout line (a 27 KB line was not read back by the driver)
+CONTRACT_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'rccl_ranks')
+ROOFLINE_KEYS = ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_over_algorithmic',
+                 'gflop_per_frame', 'ms_in_kernel_per_frame', 'launches_per_frame', 'algorithmic_bytes_per_frame',
+                 'frac_of_sustained_probe')
+CPU_KEYS = ('value', 'unit', 'cores', 'kind', 'range_fps', 'stage_ms_per_frame', 'sample')
+
+
+def _round(x, digits=4):
+    """floats to `digits` significant figures (the full-precision numbers are in bench_extra.json)"""
+    if isinstance(x, float):
+        return float(f'{x:.{digits}g}')
+    if isinstance(x, dict):
+        return {k: _round(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_round(v, digits) for v in x]
+    return x
+
+
+def compact_line(result):
+    """the ONE line of the contract: exactly CONTRACT_KEYS, scalars only below the second level, <= LINE_LIMIT bytes.
+    Everything else (`also`, `also_kernels`, `affinity`, `timed_like_eval_vos`, per-shape CPU rows, method strings,
+    parity gates) is in bench_extra.json."""
+    line = {k: result[k] for k in CONTRACT_KEYS if k in result}
+    for k in ('value', 'ms_per_step'):
+        if isinstance(line.get(k), float):
+            line[k] = float(f'{line[k]:.6g}')
+    cfg = dict(line.get('config', {}))
+    line['config'] = {k: _round(v) for k, v in cfg.items() if not isinstance(v, (dict, list)) or k in ('frame_padded', 'bank_tokens_at_end')}
+    if 'also_multi_gpu' in result:  # N > 1: the one-clip-on-N-GPUs line of BASELINE configs[4], as scalars
+        for e in result['also_multi_gpu']:
+            line['config']['fps_4k_one_clip_on_all_gpus'] = _round(e['value'])
+            line['config']['collective_bytes_per_frame_rank0'] = _round(e['config'].get('collective_bytes_per_frame_rank0'))
+    if 'roofline' in result:
+        r = result['roofline']
+        out = {k: r[k] for k in ROOFLINE_KEYS if k in r}
+        out['kernel'] = 'conv_mfma_kernel / conv_igemm_kernel (fp32 MFMA implicit GEMM)'
+        out.update({k: v for k, v in r.items() if k.startswith(('affinity_', 'f16_split_frac_of_f16_peak_'))
+                    and not isinstance(v, (dict, list, str))})
+        p = r.get('sustained_mfma_probe')
+        if isinstance(p, dict) and 'random_operands_tflops' in p:
+            out['sustained_mfma_probe_tflops'] = p['random_operands_tflops']
+        line['roofline'] = _round(out)
+    if 'cpu_baseline' in result:
+        c = result['cpu_baseline']
+        out = {k: c[k] for k in CPU_KEYS if k in c}
+        if 'sample' in out:
+            out['sample'] = out['sample'][:160]
+        line['cpu_baseline'] = _round(out)
+    line['extra'] = 'bench_extra.json'
+    text = json.dumps(line, separators=(',', ':'))
+    # never over the limit: drop the optional scalars, least important first
+    droppable = ([('roofline', k) for k in list(line.get('roofline', {})) if k.startswith('f16_split_')] +
+                 [('cpu_baseline', 'sample'), ('cpu_baseline', 'stage_ms_per_frame')] +
+                 [('roofline', k) for k in list(line.get('roofline', {})) if k.startswith('affinity_')] +
+                 [('config', k) for k in reversed(list(line['config'])) if k.startswith('fps_')])
+    while len(text) > LINE_LIMIT and droppable:
+        sect, k = droppable.pop(0)
+        line[sect].pop(k, None)
+        text = json.dumps(line, separators=(',', ':'))
+    assert len(text) <= LINE_LIMIT, len(text)
+    return text
+
+
+def emit(result):
+    """full record -> bench_extra.json (next to bench.py, and gpurun_out/ when it exists) + stderr; then the compact
+    contract line as the LAST line of stdout"""
+    full = json.dumps(result, indent=1)
+    dirs = [os.environ['DEVA_BENCH_EXTRA_DIR']] if os.environ.get('DEVA_BENCH_EXTRA_DIR') else [ROOT, os.path.join(ROOT, 'gpurun_out')]
+    for d in dirs:
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, 'bench_extra.json'), 'w') as f:
+                    f.write(full + '\n')
+            except OSError as exc:
+                print(f'bench_extra.json not written in {d}: {exc}', file=sys.stderr)
+    print(full, file=sys.stderr)
+    sys.stderr.flush()
+    sys.stdout.flush()
+    print(compact_line(result))
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -1053,7 +1137,7 @@ def main():
                         'bank_tokens_at_end': bank_own, 'collective_bytes_per_frame_rank0': comm_own}}]
 
     if rank == 0 and emulated:
-        print(json.dumps(result))
+        emit(result)
     elif rank == 0:
         # ---- roofline of the dominant kernel: event-timed replay of as many frames, continuing the same clip
         # (un-synchronised events, see ConvTimer); warm the replay with two frames first
@@ -1178,7 +1262,7 @@ def main():
                 result['cpu_baseline']['affinity_kernels'] = cpu_affinity_kernels()
             except Exception as exc:  # noqa: BLE001
                 result['cpu_baseline']['affinity_kernels'] = {'error': f'{type(exc).__name__}: {exc}'[:300]}
-        print(json.dumps(result))
+        emit(result)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
