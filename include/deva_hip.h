@@ -112,6 +112,14 @@ typedef struct deva_conv_desc {
    * (((k/8)*2 + plane)*cout_pad + m)*8 + k%8, K tap-major for 1x1, 32-channel slabs otherwise) of the weights scaled
    * by 2^split_scale_log2; every activation is split into hi = fp16(x), lo = fp16(x - hi) while it is staged, each
    * K-block runs hi.hi + hi.lo + lo.hi with fp32 accumulation, and the accumulators are scaled back exactly.
+   * ERROR MODEL (tests/test_split_arithmetic_cpu.py): per product |x w - (hi.hi + hi.lo + lo.hi)| <= 2^-21 |x w| PLUS
+   * an ABSOLUTE floor of 2^-25 |w| -- activations are not pre-scaled, so below |x| ~ 2^-3 the lo plane enters the fp16
+   * subnormals (spacing 2^-24) and the representation error of x stops shrinking with x.  With activations of ordinary
+   * magnitude (max |x| of the layer >= ~0.1) the floor is below the fp32 kernels' own accumulation round-off; a layer whose
+   * inputs are ALL tiny (|x| ~ 1e-4) is 11..12-bit accurate in x (fp16-operand class), not 22-bit.  "fp32-accurate" in this
+   * file and in the flags' help means: to fp32 round-off of max(|x|, 2^-3) |w| per product.
+   * `out` must not overlap in0 / in1 / residual for the split kernels to run (the fp32 re-run behind them reads those
+   * after `out` has been written): an overlapping call -- an in-place residual add -- runs the fp32 kernels instead.
    * split_flag: one device int the caller has zeroed; the kernel sets it when an input lay beyond the fp16 range
    * (|x| > 65504 or non-finite), and the fp32 kernels -- launched behind the split kernel on the same stream, gated on
    * that int -- then produce the output.  Shapes the split kernels do not cover (stride 2, 3x3 layers whose channel counts

@@ -77,7 +77,9 @@ def conv2d(pc, x0, x1=None, *, stride=1, pad=0, relu_in=False, residual=None, ac
            split=False):
     # split: the contract of the hi/lo split kernels IS the fp32 convolution (to fp32 round-off); only the fall-back
     # statistic is emulated (an input beyond the fp16 range sends the layer to the fp32 kernels)
-    if split and split_takes(pc, x0, x1, stride, pad):
+    def _overlaps(t):  # (deva_conv2d: an output that overlaps an operand sends a split call to the fp32 kernels alone)
+        return (t is not None and out is not None and t.untyped_storage().data_ptr() == out.untyped_storage().data_ptr())
+    if split and split_takes(pc, x0, x1, stride, pad) and not any(_overlaps(t) for t in (x0, x1, residual)):
         for t in (x0, x1):
             if t is not None and not bool(((F.relu(t) if relu_in else t).abs() <= 65504.0).all()):
                 _SPLIT_FALLBACKS[0] += 1

@@ -7,7 +7,9 @@
 //   activation / output are fp32 -- the arithmetic the oracle's amp mode restates.
 //
 // PREC 2 -- fp32-ACCURATE on the f16 pipes (hi/lo operand split; the arithmetic of nn.Conv2d in fp32, big_modules.py:
-//   54-212, modules.py:81-169, to fp32 round-off): every fp32 activation x is split while it is staged into
+//   54-212, modules.py:81-169, to fp32 round-off of max(|x|, 2^-3) |w| per product -- see the error model in
+//   include/deva_hip.h: the activations are not pre-scaled, their lo plane has an absolute floor of 2^-25): every fp32
+//   activation x is split while it is staged into
 //   hi = fp16(x), lo = fp16(x - hi) (x - hi is exact in fp32; |x - hi - lo| <= max(2^-22 |x|, 2^-25)), the weights are
 //   packed once as hi / lo fp16 planes of w * 2^e (e per layer: the largest weight lands in [2^13, 2^14], which keeps
 //   the lo plane of every weight that matters out of the fp16 subnormals), and each K-block issues THREE MFMAs into the

@@ -796,12 +796,25 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
   if (a.w16 && a.cout > 1 && a.in0_span < (1ll << 29) && a.in1_span < (1ll << 29)) {
     // opt-in f16 matrix pipes (fp16 operands, or the fp32-accurate hi/lo split): eligible shapes only, everything else
     // -- and inputs too large for 32-bit buffer offsets -- stays on the fp32 kernels
+    // amp == 2: the gated fp32 re-run reads in0 / in1 / residual AFTER the split kernel has written `out`.  An output that
+    // overlaps one of them (an in-place residual add, say, which is fine on the plain fp32 path: every element is read
+    // before it is written by the same thread) would make the re-run add the residual twice: such calls take the fp32
+    // kernels directly (include/deva_hip.h)
+    bool aliased = false;
+    if (a.prec == 2) {
+      const auto overlaps = [&](const float* q, int64_t elems) {
+        const int64_t out_elems = (int64_t)d->batch * a.cout * a.OHW;
+        return q && elems > 0 && q < a.out + out_elems && a.out < q + elems;
+      };
+      const int64_t res_elems = d->residual ? (int64_t)(d->batch - 1) * a.res_bs + (int64_t)a.cout * a.OHW : 0;
+      aliased = overlaps(a.in0, a.in0_span) || overlaps(a.in1, a.in1_span) || overlaps(d->residual, res_elems);
+    }
     if (a.prec == 2) {
       DEVA_REQUIRE(d->split_scale_log2 >= -120 && d->split_scale_log2 <= 120, "deva_conv2d: split_scale_log2 out of range");
       a.out_scale = ldexpf(1.0f, -d->split_scale_log2);
       a.flag = d->split_flag;
     }
-    const int rc = launch_conv_f16(a, st);
+    const int rc = aliased ? -1 : launch_conv_f16(a, st);
     if (rc > 0 || (rc == 0 && a.prec != 2)) return rc;
     // split launched: the fp32 kernels run behind it, gated on the flag it raises for inputs beyond the fp16 range
     if (rc == 0) a.gate = a.flag;

@@ -228,7 +228,27 @@ def _workspace(device) -> torch.Tensor:
 
 
 _SPLIT_FLAGS = {}
+_SPLIT_EVICTED = {}  # device index -> fall-backs counted by rings that _make_room has dropped
 _SPLIT_RING = 4096  # flag slots per (device, stream); re-zeroed (one fill launch) every _SPLIT_RING split convolutions
+
+
+def _dev_index(device) -> int:
+    """torch.device('cuda') and torch.device('cuda:0') name the same device when 0 is current"""
+    d = torch.device(device)
+    if d.type != 'cuda':
+        return -1
+    return torch.cuda.current_device() if d.index is None else d.index
+
+
+def _evict_split_rings() -> None:
+    """before a NEW ring is inserted: the rings beyond the bound are dropped, their totals folded into _SPLIT_EVICTED
+    (after a device synchronise: the ring may belong to another stream with launches in flight)"""
+    while len(_SPLIT_FLAGS) >= _MAX_STREAM_CACHES:
+        (dev, _), (ring, _) = next(iter(_SPLIT_FLAGS.items()))
+        if ring.is_cuda:
+            torch.cuda.synchronize(ring.device)
+        _SPLIT_EVICTED[_dev_index(dev)] = _SPLIT_EVICTED.get(_dev_index(dev), 0) + int(ring.sum().item())
+        _SPLIT_FLAGS.pop(next(iter(_SPLIT_FLAGS)))
 
 
 def _split_flag(device) -> int:
@@ -238,7 +258,7 @@ def _split_flag(device) -> int:
     key = (device, _stream(device))
     ent = _SPLIT_FLAGS.get(key)
     if ent is None:
-        _make_room(_SPLIT_FLAGS)
+        _evict_split_rings()
         ent = _SPLIT_FLAGS[key] = [torch.zeros(_SPLIT_RING + 1, dtype=torch.int32, device=device), 0]
     ring, nxt = ent
     if nxt == _SPLIT_RING:
@@ -252,9 +272,12 @@ def _split_flag(device) -> int:
 def split_fallbacks(device) -> int:
     """number of split convolutions on `device` (all streams of this process) whose inputs left the fp16 range, so
     that the fp32 kernels behind them produced the output (synchronises: a statistic for tests and the bench)"""
-    total = 0
+    want = _dev_index(device)
+    if torch.device(device).type == 'cuda':
+        torch.cuda.synchronize(torch.device('cuda', want))  # rings of OTHER streams (key-encoder prefetch) are read below
+    total = _SPLIT_EVICTED.get(want, 0)
     for (dev, _), (ring, _) in _SPLIT_FLAGS.items():
-        if torch.device(dev) == torch.device(device):
+        if _dev_index(dev) == want:
             total += int(ring.sum().item())
     return total
 
@@ -450,6 +473,7 @@ class BankPrep:
     def __init__(self):
         self.buf: Optional[torch.Tensor] = None
         self.key = None
+        self._pending = None
 
     def prepare(self, nbytes: int, device, key) -> Tuple[int, int]:
         """-> (device address of the buffer, 1 if it holds the operands of this very bank state)"""
@@ -458,8 +482,14 @@ class BankPrep:
             self.buf = torch.empty(((nbytes + nbytes // 4) // 8 + 64,), dtype=torch.int64, device=device)
             self.key = None
         valid = int(key is not None and self.key == key)
-        self.key = key
+        # the key is committed by `commit` AFTER the read that fills the buffer has been launched successfully: a call that
+        # raises (bad arguments, launch error) must not leave a promise about a buffer that was never filled
+        self._pending = key
+        self.key = None
         return self.buf.data_ptr(), valid
+
+    def commit(self) -> None:
+        self.key = self._pending
 
 
 def affinity_topk(key_long, shr_long, n_long: int, key_work, shr_work, n_work: int, qk: torch.Tensor,
@@ -489,6 +519,8 @@ def affinity_topk(key_long, shr_long, n_long: int, key_work, shr_work, n_work: i
                                             _p(qk), _p(qe), hw, k, _p(scratch, torch.int64), _p(idx, torch.int32), _p(weight),
                                             _p(usage_fix, torch.int64), None, None, 0, bank_prep, valid, _stream()),
               'deva_affinity_read_prepared')
+        if bank_prep is not None:
+            prep.commit()
         return idx, weight
     part = _affinity_workspace(L.deva_affinity_workspace(hw, k, splits), qk.device)
     check(L.deva_affinity_topk(_p(key_long) if n_long else None, _p(shr_long) if n_long else None, n_long,

@@ -18,7 +18,8 @@ _FLAGS = (
                          'memory read stay fp32); off: everything fp32, the parity target'),
     ('f16_split', None, False, 'extension: fp32-accurate convolutions on the f16 matrix pipes (hi/lo fp16 split of both '
                                'operands, fp32 accumulation) in the value encoder and the mask decoder; held to the fp32 '
-                               'parity bounds, 2.5-3x the fp32 rate of those layers'),
+                               'parity bounds, 2.5-3x the fp32 rate of those layers.  Error per product: 2^-21 |x w| + 2^-25 |w| '
+                               '(absolute floor: activations are not pre-scaled; layers whose inputs are all << 0.1 lose bits)'),
     ('f16_split_key_encoder', None, False, 'extension, with --f16_split: the key encoder on the split kernels too (the memory '
                                            "read's inputs then move by fp32 round-off, as under any change of accumulation order)"),
     # network widths (C^k, C^v, pixel feature)
