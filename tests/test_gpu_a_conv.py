@@ -292,8 +292,10 @@ def test_conv_split_is_fp32_accurate(case):
 @pytest.mark.parametrize('poison', [7.0e4, -1.0e6, float('inf'), float('nan')], ids=['70000', '-1e6', 'inf', 'nan'])
 @pytest.mark.parametrize('k', [1, 3])
 def test_conv_split_falls_back_beyond_the_fp16_range(poison, k):
-    """one input element beyond +-65504 (or non-finite): the split kernel raises its flag and the fp32 kernels, launched
-    behind it and gated on the flag, produce the output -- bit-identical to the plain fp32 call"""
+    """one input element beyond +-65504 (or non-finite): the split kernel raises its flag and the fp32 kernel launched
+    behind it, gated on the flag, produces the output: the fp32 kernels' arithmetic in their plain K order (a persistent
+    64x64-tile launch without K slices -- csrc/conv_mfma.hip PERSIST --, so bit-identical to the plain fp32 call wherever
+    the tile policy of that call does not slice K, and within the fp32 kernels' own bound of it otherwise)"""
     g = torch.Generator().manual_seed(11 + k)
     w = rand(g, 128, 128, k, k, scale=0.05)
     pc = to_dev(ops.pack_conv(w, rand(g, 128, scale=0.1), None, split=True))
@@ -305,12 +307,36 @@ def test_conv_split_falls_back_beyond_the_fp16_range(poison, k):
     f32 = ops.conv2d(pc, xd, pad=k // 2, act=ops.ACT_RELU)
     torch.cuda.synchronize()
     assert ops.split_fallbacks(dev()) == before + 1
-    assert torch.equal(got.isnan(), f32.isnan()) and torch.equal(got.nan_to_num(0.0), f32.nan_to_num(0.0))
+    assert torch.equal(got.isnan(), f32.isnan()) and torch.equal(got.isinf(), f32.isinf())
+    a, b = got.nan_to_num(0.0, 0.0, 0.0), f32.nan_to_num(0.0, 0.0, 0.0)
+    if k == 1:  # 4 K steps on 48 tiles: the plain call runs the same unsliced K loop
+        assert torch.equal(a, b)
+    assert max_err(a, b) <= 2e-5 * max(1.0, b.abs().max().item())
     # the next call with clean inputs gets a fresh flag
     x[1, 77, 13, 5] = 0.5
     got = ops.conv2d(pc, _guarded(x), pad=k // 2, act=ops.ACT_RELU, split=True)
     torch.cuda.synchronize()
     assert ops.split_fallbacks(dev()) == before + 1 and bool(torch.isfinite(got).all())
+
+
+@pytest.mark.parametrize('k,cin,cout,relu_in', [(3, 256, 256, True), (3, 128, 192, False), (1, 512, 256, False)])
+def test_conv_split_fallback_walks_every_tile(k, cin, cout, relu_in):
+    """the gated re-run is a PERSISTENT launch (at most 1 024 workgroups walk over the 64x64 tiles): a layer with several
+    thousand tiles, one poisoned input -- every output must come from the fp32 arithmetic.  On these shapes the plain fp32
+    call runs 128x128 tiles without K slices, i.e. the same K order: bit-identical, residual and bias included"""
+    g = torch.Generator().manual_seed(31 + k + cin)
+    pc = to_dev(ops.pack_conv(rand(g, cout, cin, k, k, scale=(2.0 / (cin * k * k))**0.5), rand(g, cout, scale=0.1), None,
+                              split=True))
+    x = rand(g, 2, cin, 120, 216)
+    x[1, 17, 100, 200] = 3.0e5
+    xd = _guarded(x)
+    res = to_dev(rand(g, 2, cout, 120, 216))
+    before = ops.split_fallbacks(dev())
+    got = ops.conv2d(pc, xd, pad=k // 2, relu_in=relu_in, residual=res, act=ops.ACT_RELU, split=True)
+    f32 = ops.conv2d(pc, xd, pad=k // 2, relu_in=relu_in, residual=res, act=ops.ACT_RELU)
+    torch.cuda.synchronize()
+    assert ops.split_fallbacks(dev()) == before + 1
+    assert torch.equal(got, f32)
 
 
 def test_conv_split_in_place_residual_takes_the_fp32_kernels():

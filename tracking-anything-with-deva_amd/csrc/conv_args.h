@@ -79,6 +79,9 @@ inline int conv_group_m(int taps, int stride, int bm, int bn, int64_t tiles) {
 int launch_splitk_reduce(const ConvArgs& p, hipStream_t st);
 // conv_mfma.hip: lean-loop kernels for weights in the k-quad layout (DEVA_KLAYOUT_Q4)
 int launch_conv_q4(const ConvArgs& a, hipStream_t st);
+// conv_mfma.hip: the gated fp32 re-run behind a split launch as a persistent kernel (<= 1 024 workgroups whatever the
+// layer's size); -1 = shape not covered, launch the regular kernels with the gate
+int launch_conv_q4_gated(const ConvArgs& a, hipStream_t st);
 // conv_f16.hip: fp16-operand kernels (opt-in amp path, a.prec == 1) and the hi/lo split kernels (a.prec == 2: fp32-accurate
 // on the f16 matrix pipes); -1 = shape not eligible, run the fp32 kernels
 int launch_conv_f16(const ConvArgs& a, hipStream_t st);

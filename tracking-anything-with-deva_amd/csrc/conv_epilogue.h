@@ -15,8 +15,7 @@ typedef float conv_f32x16 __attribute__((ext_vector_type(16)));
 // tiles, and that rectangle is what streams through the XCD's 4 MB L2 per K step: group_m weight tiles + the pixel tiles'
 // activations.  A 3x3 weight tile is ~9x the bytes of a pixel tile's activations, so few cout tiles per group there
 // (measured on the 1024->1536 GRU convolution: L2 fills 1.36 GB -> see profiles/r04b), all cout tiles for 1x1.
-__device__ __forceinline__ void conv_tile_coords(const ConvArgs& p, int& tile_m, int& tile_n) {
-  const int nb = gridDim.x, b = blockIdx.x;
+__device__ __forceinline__ void conv_tile_coords(const ConvArgs& p, int b, int nb, int& tile_m, int& tile_n) {
   const int q = nb >> 3, r = nb & 7, xcd = b & 7;
   const int logical = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   const int g = (p.group_m > 0 && p.group_m < p.tiles_m) ? p.group_m : p.tiles_m;
@@ -27,6 +26,10 @@ __device__ __forceinline__ void conv_tile_coords(const ConvArgs& p, int& tile_m,
   const int gsz = min(g, p.tiles_m - m_first);
   tile_n = in_grp / gsz;
   tile_m = m_first + (in_grp - tile_n * gsz);
+}
+
+__device__ __forceinline__ void conv_tile_coords(const ConvArgs& p, int& tile_m, int& tile_n) {
+  conv_tile_coords(p, (int)blockIdx.x, (int)gridDim.x, tile_m, tile_n);
 }
 
 typedef float conv_f32x4 __attribute__((ext_vector_type(4)));

@@ -833,6 +833,10 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
     // buffer addressing: 32-bit byte offsets from the tensor bases
     DEVA_REQUIRE(a.in0_span < (1ll << 29) && a.in1_span < (1ll << 29),
                  "deva_conv2d: k-quad weights need inputs below 2 GiB (32-bit buffer offsets)");
+    if (a.gate) {  // the re-run behind a split launch: a persistent kernel (what it costs is its dispatch)
+      const int rc = launch_conv_q4_gated(a, st);
+      if (rc >= 0) return rc;
+    }
     return launch_conv_q4(a, st);
   }
   // Tile choice (all tiles run 32-deep K steps):
