@@ -852,9 +852,15 @@ def extra_lines(net, device, cfg, args):
     gate1080 = 'tests/test_gpu_g_fullsize.py::test_1080p_detections_10k_bank_against_oracle'
     SPLIT_DTYPE = 'f32 via 3x f16 split, f32 acc (value encoder, mask decoder); f32 elsewhere'
     SPLIT_GATE = ('tests/test_gpu_a_conv.py::test_conv_split_matches_cpu (the fp32 cases at the fp32 bound 2e-5) + '
-                  'test_conv_split_is_fp32_accurate (against fp64) + tests/test_gpu_e_network.py::'
-                  'test_f16_split_lockstep_teacher_forced (480p, 1080p; fp32 bounds) + test_f16_split_e2e_against_reference_golden '
-                  '+ the whole -m gpu suite under DEVA_TEST_F16_SPLIT=1 (profiles/r05/tests_split/)')
+                  'test_conv_split_is_fp32_accurate (against fp64) + tests/test_gpu_e_network.py::test_480p_lockstep_teacher_forced / '
+                  'test_1080p_lockstep_teacher_forced [f16_split] (fp32 bounds, one oracle pass with the fp32 build) + '
+                  'test_f16_split_e2e_against_reference_golden[f16_split-five_obj]; free-running at bench size under the superset '
+                  'mode: the gates of the key_encoder lines')
+    SPLIT_ALL_GATE = ('the conv tests of --f16_split + tests/test_gpu_e_network.py::test_480p_lockstep_teacher_forced / '
+                      'test_1080p_lockstep_teacher_forced [f16_split+key_encoder] + test_f16_split_e2e_against_reference_golden'
+                      '[f16_split+key_encoder-*] + test_f16_split_480p_five_objects_against_oracle + tests/test_gpu_g_fullsize.py::'
+                      'test_1080p_eight_segment_detections_against_oracle[f16_split+key_encoder] + test_4k_lockstep '
+                      '[f16_split+key_encoder] -- all in the default -m gpu suite, fp32 bounds')
     SPLIT_ALL_DTYPE = 'f32 via 3x f16 split, f32 acc (key encoder, value encoder, mask decoder); f32 elsewhere'
     _split, _split_all = [], []
 
@@ -898,7 +904,7 @@ def extra_lines(net, device, cfg, args):
              'BASELINE configs[2] as SURVEY.md 8d defines it: tracker-consistent detections with 8 segments '
              '(re-detections that match and merge, 2 new objects per detection in a new bucket, objects unseen twice '
              'purged), online setting, no object cap',
-             'tests/test_gpu_g_fullsize.py::test_1080p_eight_segment_detections_against_oracle (8 segments, 14 live objects '
+             'tests/test_gpu_g_fullsize.py::test_1080p_eight_segment_detections_against_oracle[fp32] (8 segments, 14 live objects '
              'at 1080p, the same generator) + tests/test_gpu_e_network.py::test_consistent_detection_clip_against_reference_golden',
              'state_at_end'),
         line('propagation FPS @1080p, --amp (8-segment detections merged every 5th frame, ~10 live objects, 10k-token '
@@ -928,16 +934,16 @@ def extra_lines(net, device, cfg, args):
         line('propagation FPS @480p, --f16_split --f16_split_key_encoder (5 objects, working memory only)',
              lambda: run_480p_headline(split_all_net(), device, cfg, args), args.steps, args.warmup,
              'the headline clip and loop with the key encoder on the split kernels too (second level of the opt-in)',
-             SPLIT_GATE, 'state_at_end', dtype=SPLIT_ALL_DTYPE),
+             SPLIT_ALL_GATE, 'state_at_end', dtype=SPLIT_ALL_DTYPE),
         line('propagation FPS @1080p, --f16_split --f16_split_key_encoder (1 object, 10k-token long-term bank)',
              lambda: run_1080p(split_all_net(), device, steps=25, warmup=6, detections=False, conv_roofline=True), 25, 6,
-             'the north-star target line with the key encoder on the split kernels too', SPLIT_GATE, 'state_at_end',
+             'the north-star target line with the key encoder on the split kernels too', SPLIT_ALL_GATE, 'state_at_end',
              dtype=SPLIT_ALL_DTYPE, target_fps=30.0),
         line('propagation FPS @1080p, --f16_split --f16_split_key_encoder (8-segment detections merged every 5th frame, ~10 live '
              'objects, 10k-token long-term bank)',
              lambda: run_1080p_segments(split_all_net(), device, steps=25, warmup=6, segments=8, conv_roofline=True), 25, 6,
              'BASELINE configs[2] (the 8-segment clip above) with the key encoder on the split kernels too (second level of the '
-             'opt-in: the memory read\'s inputs then move by fp32 round-off)', SPLIT_GATE, 'state_at_end',
+             'opt-in: the memory read\'s inputs then move by fp32 round-off)', SPLIT_ALL_GATE, 'state_at_end',
              dtype=SPLIT_ALL_DTYPE, target_fps=30.0),
         line('propagation FPS @4K (1 object, 50k-token long-term bank), one GPU',
              lambda: run_long4k(net, device, steps=20, warmup=5, seed=11, shard=None, dist=None)[:2], 20, 5,

@@ -46,7 +46,7 @@ def peaky_network(peaky_state_dict):
     return net.to(dev()).eval()
 
 
-def _scenario_against_golden(tag, network_, P, sc, golden_outs, stride=2):
+def _scenario_against_golden(tag, network_, P, sc, golden_outs, stride=2, with_noisy=True):
     """a scenario of tests/scenarios.py: the HIP run, then the CPU oracle under `TieFollowing` of the HIP run's
     reads (the reference given the same decisions at measured fp32 near-ties), the reference's stored outputs as
     the clean reference and the oracle on 1e-6-perturbed frames as the noise floor"""
@@ -60,12 +60,16 @@ def _scenario_against_golden(tag, network_, P, sc, golden_outs, stride=2):
     tf.check()
     assert not tf.queue
     gen = torch.Generator().manual_seed(0)
-    noisy, _ = scenarios.run_scenario(lambda cfg: O.OracleCore(P, cfg), dict(sc),
-                                      perturb=lambda img: img * (1 + 1e-6 * torch.randn(img.shape, generator=gen)))
+    # (the reference's own drift under a 1e-6 input perturbation is a property of the reference: reported by the fp32 run
+    # of a clip, not again by the runs of the same clip under --f16_split*)
+    noisy = None
+    if with_noisy:
+        noisy, _ = scenarios.run_scenario(lambda cfg: O.OracleCore(P, cfg), dict(sc),
+                                          perturb=lambda img: img * (1 + 1e-6 * torch.randn(img.shape, generator=gen)))
     drift = _Drift(tag, stride=stride)
     for t, p in enumerate(outs):
         drift.add(p[:, ::stride, ::stride], following[t][:, ::stride, ::stride], golden_outs[t],
-                  noisy[t][:, ::stride, ::stride], frame=t, adopted_so_far=adopted_at[t])
+                  None if noisy is None else noisy[t][:, ::stride, ::stride], frame=t, adopted_so_far=adopted_at[t])
     report = drift.finish()
     print(f'{tag}:', json.dumps({k: float(f'{v:.3g}') for k, v in report.items()}))
     return outs, core
@@ -253,12 +257,51 @@ def test_bank_prep_cache_is_bit_identical_over_memory_frames(network):
     assert all(torch.equal(a, b) for a, b in zip(outs[True], outs[False]))
 
 
-def test_480p_lockstep_teacher_forced(network, recipe_state_dict):
-    """Every stage of every frame at full 480x864 size on IDENTICAL inputs (tests/lockstep.py)."""
+@pytest.fixture(scope='module')
+def split_network(recipe_state_dict):
+    """the network with --f16_split: value encoder and mask decoder on the hi/lo fp16 split kernels"""
+    from deva.model.network import DEVA
+    net = DEVA(dict(synth.base_config(), f16_split=True))
+    net.load_weights(recipe_state_dict[0])
+    return net.to(dev()).eval()
+
+
+@pytest.fixture(scope='module')
+def split_all_network(recipe_state_dict):
+    """--f16_split --f16_split_key_encoder: the key encoder on the split kernels too (the mode behind bench.py's
+    `fps_*_f16_split_key_encoder` lines; it moves the memory read's inputs by fp32 round-off)"""
+    from deva.model.network import DEVA
+    net = DEVA(dict(synth.base_config(), f16_split=True, f16_split_key_encoder=True))
+    net.load_weights(recipe_state_dict[0])
+    return net.to(dev()).eval()
+
+
+SPLIT_MODES = ('f16_split', 'f16_split+key_encoder')
+
+
+def _builds(network, split_network, split_all_network):
+    """the three builds of the recipe weights a lock-step pass holds against ONE oracle pass"""
+    return {'fp32': network, 'f16_split': split_network, 'f16_split+key_encoder': split_all_network}
+
+
+def _lockstep_all(tag, nets, P, H, W, no, frames):
+    """fp32, --f16_split and --f16_split --f16_split_key_encoder teacher-forced on the SAME oracle pass with the SAME
+    bounds (2e-4 relative per stage, 1e-3 on logits and probabilities: tests/lockstep.py); no split convolution may
+    have fallen back to the fp32 kernels (recipe activations sit far inside the fp16 range)"""
     import lockstep
-    P, _ = recipe_state_dict
-    worst = lockstep.run(network, P, 480, 864, 2, 7, dev())
-    print('lockstep 480p worst relative errors:', json.dumps({k: float(f'{v:.2e}') for k, v in worst.items()}))
+    from deva.hip import ops
+    before = ops.split_fallbacks(dev())
+    worst = lockstep.run(nets, P, H, W, no, frames, dev())
+    for build, w in worst.items():
+        print(f'lockstep {tag} [{build}] worst relative errors:', json.dumps({k: float(f'{v:.2e}') for k, v in w.items()}))
+    assert ops.split_fallbacks(dev()) == before
+    return worst
+
+
+def test_480p_lockstep_teacher_forced(network, split_network, split_all_network, recipe_state_dict):
+    """Every stage of every frame at full 480x864 size on IDENTICAL inputs (tests/lockstep.py), for the three builds:
+    fp32 (the parity target) and the two levels of the fp32-ACCURATE split (csrc/conv_f16.hip, PREC 2) under the fp32 bounds"""
+    _lockstep_all('480p', _builds(network, split_network, split_all_network), recipe_state_dict[0], 480, 864, 3, 7)
 
 
 def test_top_k_48_lockstep_teacher_forced(network, recipe_state_dict):
@@ -314,54 +357,33 @@ def test_amp_lockstep_teacher_forced(recipe_state_dict):
     assert float((pr16 - pr32).abs().max()) <= 2e-2
 
 
-@pytest.fixture(scope='module')
-def split_network(recipe_state_dict):
-    """the network with --f16_split: value encoder and mask decoder on the hi/lo fp16 split kernels"""
-    from deva.model.network import DEVA
-    net = DEVA(dict(synth.base_config(), f16_split=True))
-    net.load_weights(recipe_state_dict[0])
-    return net.to(dev()).eval()
-
-
-def test_f16_split_lockstep_teacher_forced(split_network, recipe_state_dict):
-    """--f16_split: fp32-ACCURATE convolutions on the f16 matrix pipes in the value encoder and the mask decoder
-    (csrc/conv_f16.hip, PREC 2).  Every stage of every frame teacher-forced against the FP32 oracle with the bounds of
-    the fp32 lock-step (2e-4 relative per stage, 1e-3 on logits and probabilities) at 480p and at 1080p; no
-    convolution may have fallen back to the fp32 kernels (recipe activations sit far inside the fp16 range)."""
-    import lockstep
-    from deva.hip import ops
-    P, _ = recipe_state_dict
-    before = ops.split_fallbacks(dev())
-    worst = lockstep.run(split_network, P, 480, 864, 3, 6, dev())
-    print('f16_split lockstep 480p worst relative errors:', json.dumps({k: float(f'{v:.2e}') for k, v in worst.items()}))
-    worst = lockstep.run(split_network, P, 1088, 1920, 1, 2, dev())
-    print('f16_split lockstep 1080p worst relative errors:', json.dumps({k: float(f'{v:.2e}') for k, v in worst.items()}))
-    assert ops.split_fallbacks(dev()) == before
-
-
-@pytest.mark.parametrize('name', ['lt_evict', 'five_obj'])
-def test_f16_split_e2e_against_reference_golden(split_network, golden_dir, recipe_state_dict, name):
-    """free-running clips of the reference's goldens under --f16_split, same gate as the fp32 run"""
+@pytest.mark.parametrize('mode,name', [('f16_split', 'five_obj'), ('f16_split+key_encoder', 'five_obj'),
+                                       ('f16_split+key_encoder', 'lt_evict')])
+def test_f16_split_e2e_against_reference_golden(split_network, split_all_network, golden_dir, recipe_state_dict, mode, name):
+    """free-running clips of the reference's goldens under --f16_split (value encoder + mask decoder) and under
+    --f16_split --f16_split_key_encoder (the key encoder too: the memory read's inputs move), same gate as the fp32 run"""
+    net = split_network if mode == 'f16_split' else split_all_network
     sc = scenarios.E2E[name]
     g = np.load(os.path.join(golden_dir, f'e2e_{name}.npz'))
     n = len(g['nchan'])
-    outs, _ = _scenario_against_golden(f'f16_split {name}', split_network, recipe_state_dict[0], sc,
-                                       [torch.from_numpy(g[f'prob_sub_{t}']) for t in range(n)])
+    outs, _ = _scenario_against_golden(f'{mode} {name}', net, recipe_state_dict[0], sc,
+                                       [torch.from_numpy(g[f'prob_sub_{t}']) for t in range(n)], with_noisy=False)
     assert [p.shape[0] for p in outs] == g['nchan'].tolist()
 
 
-def test_f16_split_480p_five_objects_against_oracle(split_network, recipe_state_dict):
-    """BASELINE configs[1] size, free-running against the tie-following oracle, under --f16_split"""
-    _five_objects_480p('f16_split 480p/5obj', split_network, recipe_state_dict[0], with_clean=False)
+def test_f16_split_480p_five_objects_against_oracle(split_all_network, recipe_state_dict):
+    """BASELINE configs[1] size, free-running against the tie-following oracle, under --f16_split --f16_split_key_encoder
+    (every split kernel the plain --f16_split clip runs, plus the key encoder's)"""
+    from deva.hip import ops
+    before = ops.split_fallbacks(dev())
+    _five_objects_480p('f16_split+key_encoder 480p/5obj', split_all_network, recipe_state_dict[0], with_clean=False)
+    assert ops.split_fallbacks(dev()) == before
 
 
-def test_1080p_lockstep_teacher_forced(network, recipe_state_dict):
-    """The same at BASELINE's 1080p size (1088x1920 padded, 8 160 queries), one object, 3 frames:
-    the CPU oracle needs a few seconds per frame there, so the clip is short."""
-    import lockstep
-    P, _ = recipe_state_dict
-    worst = lockstep.run(network, P, 1088, 1920, 1, 3, dev())
-    print('lockstep 1080p worst relative errors:', json.dumps({k: float(f'{v:.2e}') for k, v in worst.items()}))
+def test_1080p_lockstep_teacher_forced(network, split_network, split_all_network, recipe_state_dict):
+    """The same at BASELINE's 1080p size (1088x1920 padded, 8 160 queries), one object, 3 frames, the three builds on one
+    oracle pass: the CPU oracle needs a few seconds per frame there, so the clip is short."""
+    _lockstep_all('1080p', _builds(network, split_network, split_all_network), recipe_state_dict[0], 1088, 1920, 1, 3)
 
 
 def test_detection_clip_against_reference_golden(network, golden_dir):

@@ -1536,18 +1536,6 @@ __global__ __launch_bounds__(256) void affinity_pf_prep_kernel(const PfBank b, c
   for (int kb = 0; kb < PF_KB; ++kb) *reinterpret_cast<h8*>(dst + kb * 1024) = out[kb];
 }
 
-// a read on cached bank operands: the state image of the prepared-bank buffer -> the scratch's state block (flag = the bank's own)
-__global__ __launch_bounds__(64) void affinity_pf_restore_kernel(const PfState* __restrict__ keep, PfState* __restrict__ st) {
-  const int lane = threadIdx.x;
-  st->mu[lane] = keep->mu[lane];
-  if (lane == 0) {
-    st->flag = st->bank_flag = keep->bank_flag;
-    st->max_p = keep->max_p;
-    st->max_q = keep->max_q;
-    st->max_m = keep->max_m;
-  }
-}
-
 struct PfArgs {
   const uint8_t* bq16;  // [ceil(hw/32)][9][64][8 halfs] query operands (affinity_pf_query_kernel)
   const uint8_t* a16;
@@ -1619,19 +1607,35 @@ __device__ __forceinline__ void pf_query_operand(const float* __restrict__ qk, c
 // one wave per 32 queries: the fp16 query operands of both passes, computed ONCE per read (every (range, pass) wave
 // used to rebuild them: 64 strided loads and the scale logic per query group, which at ~20 tiles per wave cost as
 // much as the tiles).  Layout like the bank operand: [query group][9 K-blocks][64 lanes][8 halfs].
+// `src`: where the bank's state is read from -- the scratch's own block (`st`, just written by the prep kernel) or, on a read
+// of cached bank operands, the image in the prepared-bank buffer, which workgroup 0 then copies to the scratch for the
+// kernels that follow (round 5 had a one-wave launch of its own for that copy).  A bad query does not touch st->flag here
+// (workgroup 0 may be writing it): every query group leaves its mark in qbad[group], which the check kernel -- the next
+// writer of the flag, ahead of all its readers -- folds in.
 __global__ __launch_bounds__(256) void affinity_pf_query_kernel(const float* __restrict__ qk, const float* __restrict__ qe,
-                                                                 int hw, PfState* st, uint8_t* __restrict__ bq16,
-                                                                 float* __restrict__ eq) {
+                                                                 int hw, const PfState* __restrict__ src, PfState* st,
+                                                                 uint8_t* __restrict__ bq16, float* __restrict__ eq,
+                                                                 uint32_t* __restrict__ qbad) {
   const int lane = threadIdx.x & 63;
   const int group = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (src != st && blockIdx.x == 0 && threadIdx.x < 64) {
+    st->mu[lane] = src->mu[lane];
+    if (lane == 0) {
+      st->flag = st->bank_flag = src->bank_flag;
+      st->max_p = src->max_p;
+      st->max_q = src->max_q;
+      st->max_m = src->max_m;
+    }
+  }
   const int q0 = group * QT;
   if (q0 >= hw) return;
   const int l31 = lane & 31, half = lane >> 5;
   h8 bq[PF_KB];
   bool bad;
   float e_q;
-  pf_query_operand(qk, qe, hw, min(q0 + l31, hw - 1), half, st, bq, &bad, &e_q);
-  if (__builtin_amdgcn_ballot_w64(bad && q0 + l31 < hw) && lane == 0) atomicOr(&st->flag, 2u);
+  pf_query_operand(qk, qe, hw, min(q0 + l31, hw - 1), half, src, bq, &bad, &e_q);
+  const bool any_bad = __builtin_amdgcn_ballot_w64(bad && q0 + l31 < hw) != 0;
+  if (lane == 0) qbad[group] = any_bad ? 1u : 0u;
   if (half == 0 && q0 + l31 < hw) eq[q0 + l31] = e_q;
   uint8_t* dst = bq16 + (int64_t)group * PF_TILE_BYTES + lane * 16;
 #pragma unroll
@@ -1812,16 +1816,18 @@ __global__ __launch_bounds__(256) void affinity_pf_tau_kernel(const float* __res
 // at entry; raised from inside it, the flag let earlier workgroups' usage additions stand and the fp32 fall-back
 // counted those queries twice).
 __global__ __launch_bounds__(256) void affinity_pf_check_kernel(const uint32_t* __restrict__ cand_cnt, int hw, int k,
-                                                                int n_sub, PfState* st) {
+                                                                int n_sub, const uint32_t* __restrict__ qbad, PfState* st) {
   const int q = blockIdx.x * 256 + threadIdx.x;
-  bool bad = false;
+  bool bad = false, bad_query = false;
   if (q < hw) {
     const uint32_t* c = cand_cnt + (int64_t)q * n_sub;
     uint32_t total = 0u;
     for (int i = 0; i < n_sub; ++i) total += c[i] < (uint32_t)PF_SUB ? c[i] : (uint32_t)PF_SUB;
     bad = total > (uint32_t)PF_RESC_MAX || total < (uint32_t)k;
+    bad_query = qbad[q / QT] != 0u;  // a negative / non-finite selection or key in the query's group (affinity_pf_query_kernel)
   }
-  if (__builtin_amdgcn_ballot_w64(bad) && (threadIdx.x & 63) == 0) atomicOr(&st->flag, 8u);
+  const uint32_t bits = (__builtin_amdgcn_ballot_w64(bad) ? 8u : 0u) | (__builtin_amdgcn_ballot_w64(bad_query) ? 2u : 0u);
+  if (bits && (threadIdx.x & 63) == 0) atomicOr(&st->flag, bits);
 }
 
 struct PfRescoreArgs {
@@ -2532,17 +2538,19 @@ extern "C" int deva_affinity_read_prepared(const float* key_long, const float* s
     // n_work as the read that filled the buffer) skips the three bank kernels
     uint8_t* const a16 = bank_prep ? reinterpret_cast<uint8_t*>(bank_prep) + 512 : base + L.off_a16;
     PfState* const keep = bank_prep ? reinterpret_cast<PfState*>(bank_prep) : nullptr;
-    if (keep && bank_prep_valid) {
-      hipLaunchKernelGGL(affinity_pf_restore_kernel, dim3(1), dim3(64), 0, st, keep, state);
-    } else {
+    const bool cached = keep && bank_prep_valid;
+    if (!cached) {
       hipLaunchKernelGGL(affinity_pf_mean_kernel, dim3(PF_STAT_BLOCKS), dim3(256), 0, st, b, sums);
       hipLaunchKernelGGL(affinity_pf_stats_kernel, dim3(PF_STAT_BLOCKS), dim3(256), 0, st, b, sums, stat_part, state->mu);
       const int n_pad = L.tiles * TOKT;
       hipLaunchKernelGGL(affinity_pf_prep_kernel, dim3((unsigned)ceil_div((int64_t)n_pad * 2, 256)), dim3(256), 0, st, b,
                          stat_part, state, keep, n_pad, a16);
     }
-    hipLaunchKernelGGL(affinity_pf_query_kernel, dim3((unsigned)ceil_div(hw, 4 * QT)), dim3(256), 0, st, qk, qe, hw, state,
-                       base + L.off_bq16, reinterpret_cast<float*>(base + L.off_eq));
+    // (the channel sums are dead once the prep kernel has run: their block holds the query groups' bad-input marks)
+    uint32_t* const qbad = reinterpret_cast<uint32_t*>(sums);
+    DEVA_REQUIRE(ceil_div(hw, QT) <= PF_STAT_BLOCKS * CK, "deva_affinity_read: frame too large for the pre-filter's scratch");
+    hipLaunchKernelGGL(affinity_pf_query_kernel, dim3((unsigned)ceil_div(hw, 4 * QT)), dim3(256), 0, st, qk, qe, hw,
+                       cached ? keep : state, state, base + L.off_bq16, reinterpret_cast<float*>(base + L.off_eq), qbad);
     PfArgs a;
     a.bq16 = base + L.off_bq16;
     a.a16 = a16;
@@ -2573,7 +2581,7 @@ extern "C" int deva_affinity_read_prepared(const float* key_long, const float* s
       hipLaunchKernelGGL((affinity_pf_pass_kernel<1, 1>), grid, dim3(PF_QW * 64), 0, st, a);
     }
     hipLaunchKernelGGL(affinity_pf_check_kernel, dim3((unsigned)ceil_div(hw, 256)), dim3(256), 0, st, a.cand_cnt, hw, k,
-                       L.splits * 2, state);
+                       L.splits * 2, qbad, state);
     PfRescoreArgs r;
     r.bank = b;
     r.qk = qk;
