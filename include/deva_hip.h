@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DEVA_HIP_ABI_VERSION 7
+#define DEVA_HIP_ABI_VERSION 8
 
 int deva_hip_version(void);
 const char* deva_hip_last_error(void);
@@ -141,6 +141,23 @@ int64_t deva_conv_pack_f16(const float* w_oihw, uint16_t* out, int cout, int cin
 int64_t deva_conv_pack_split(const float* w_oihw, uint16_t* out, int cout, int cin, int kh, int kw, int* cout_pad,
                              int* scale_log2);
 
+/* The 7x7 stride-2 pad-3 stems (resnet.py:117-122 conv1 + bn1 (+ relu) of the key encoder; big_modules.py:58-61,103-107
+ * conv1 + bn1 of the value encoder over cat(image, mask)) as a direct convolution on the f16 matrix pipes with the hi / lo
+ * operand split of amp == 2 above (same error model; opt-in: --f16_split runs the value encoder's stem on it,
+ * --f16_split_key_encoder the key encoder's).  in0 [1 or batch][c0 = 3][H][W] (in0_batch_stride 0 broadcasts the image
+ * over the objects), in1 [batch][c1 = 0 or 1][H][W] (the object masks) or NULL; H, W even; out [batch][64][H/2][W/2]
+ * = act(conv + bias), act = ReLU when relu != 0.  planes / w32 / scale_log2: from deva_stem_pack (DEVICE copies).
+ * An input beyond the fp16 range (|x| > 65504, non-finite) does not saturate: the workgroup that meets one recomputes its
+ * tile in fp32 from w32 and sets *flag (a device int the caller has zeroed; may be NULL) -- no second launch. */
+int deva_stem7x7(const float* in0, int64_t in0_batch_stride, int c0, const float* in1, int64_t in1_batch_stride, int c1,
+                 int batch, int height, int width, const uint16_t* planes, const float* w32, int scale_log2,
+                 const float* bias, int relu, float* out, int32_t* flag, void* stream);
+/* weights of a stem (HOST pointers, model load): w_oihw [64][cin][7][7] with BatchNorm folded, cin = 3 or 4 ->
+ * planes: cin*8*2*64*8 uint16 (hi / lo fp16 of w * 2^e; k = ((c*4 + dy/2)*2 + dy%2)*8 + dx, element (k, plane, m) at
+ * (((k/8)*2 + plane)*64 + m)*8 + k%8, taps dy = 7 / dx = 7 zero), w32: cin*49*64 floats ([(c*7 + dy)*7 + dx][m]).
+ * Returns the number of uint16 elements of planes (planes == NULL: size query; *scale_log2 is set either way), -1 on error. */
+int64_t deva_stem_pack(const float* w_oihw, int cin, uint16_t* planes, float* w32, int* scale_log2);
+
 /* Host-side packing of one convolution's weights (HOST pointers; model load, not the frame path):
  * w_oihw [cout][cin][kh][kw] (BatchNorm already folded) -> out in the layout named by *k_layout / *cout_pad
  * (32-channel slabs when kh*kw > 1 and cin % 32 == 0, tap-major otherwise; k-quad interleaved when want_q4 != 0
@@ -151,6 +168,12 @@ int64_t deva_conv_pack(const float* w_oihw, float* out, int cout, int cin, int k
 
 /* ------------------------------------------------------------------------------------------
  * Pooling / resampling / pointwise blocks */
+
+/* Zero padding of the last two dimensions (tensor_utils.py:7-22 pad_divide_by -> F.pad): in [planes][height][width] ->
+ * out [planes][out_height][out_width] with the input at (top, left), zeros elsewhere; elements of 1, 4 or 8 bytes (uint8
+ * / fp32 / int64 masks: bits are moved).  One launch instead of ATen's fill + copy. */
+int deva_pad2d(const void* in, void* out, int elem_bytes, int64_t planes, int height, int width, int top, int left,
+               int out_height, int out_width, void* stream);
 
 /* nn.MaxPool2d(3, stride 2, pad 1) (resnet.py:122), optional fused ReLU after the pool
  * (MaskEncoder order, big_modules.py:107-110).  in [planes][H][W] -> out [planes][OH][OW]. */
@@ -322,6 +345,9 @@ int deva_affinity_read_flag(const uint64_t* scratch, void* stream);
 /* test / tuning hook (synchronises): out[5] = {fall-back flag, largest candidate sub-list, largest candidate count of a
  * query, mean candidates per query x 1000, token ranges} of the last pre-filtered read on `scratch` */
 int deva_affinity_read_stats(const uint64_t* scratch, int n_total, int hw, int k, int64_t* out, void* stream);
+
+/* Usage counters of freshly appended tokens (kv_memory_store.py:93-95): use[i] = 0, life[i] = 1e-7 for i < count. */
+int deva_usage_init(float* use, float* life, int count, void* stream);
 
 /* KeyValueMemoryStore.update_bucket_usage (kv_memory_store.py:118-125) for one segment:
  * use[i] += usage_fix[offset+i] * 2^-40 (if use != NULL), life[i] += 1 (if life != NULL), and

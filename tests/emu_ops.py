@@ -105,6 +105,36 @@ def conv2d(pc, x0, x1=None, *, stride=1, pad=0, relu_in=False, residual=None, ac
     return y
 
 
+_real_pack_stem = real.pack_stem
+
+
+def pack_stem(weight, bias=None, bn=None, device=None):
+    return _real_pack_stem(weight, bias, bn, None)  # (deva_stem_pack is host code)
+
+
+def stem7x7(ps, image, masks=None, relu=False):
+    # contract of deva_stem7x7: the fp32 convolution over cat(image broadcast, masks) (to fp32 round-off); the fall-back
+    # statistic counts calls with an input beyond the fp16 range
+    batch = image.shape[0] if masks is None else masks.shape[0]
+    x = image.expand(batch, -1, -1, -1)
+    if masks is not None:
+        x = torch.cat([x, masks], 1)
+    if not bool((x.abs() <= 65504.0).all()):
+        _SPLIT_FALLBACKS[0] += 1
+    w = ps.w32.t().reshape(64, ps.cin, 7, 7)
+    y = F.conv2d(x, w, ps.bias, stride=2, padding=3)
+    return F.relu(y) if relu else y
+
+
+def pad2d(x, pad):
+    return F.pad(x, pad)
+
+
+def usage_init(use, life):
+    use.zero_()
+    life.fill_(1e-7)
+
+
 def maxpool3x3s2(x, relu_after=False):
     y = F.max_pool2d(x, 3, 2, 1)
     return F.relu(y) if relu_after else y

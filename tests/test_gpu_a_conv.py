@@ -339,6 +339,58 @@ def test_conv_split_fallback_walks_every_tile(k, cin, cout, relu_in):
     assert torch.equal(got, f32)
 
 
+# the 7x7 stride-2 stems on the f16 matrix pipes (csrc/conv_stem.hip): against fp64 like the split convolutions above, and
+# against the fp32 kernels' own result for the same layer (image part + mask part, the form the fp32 graph runs)
+@pytest.mark.parametrize('cin,batch,H,W,relu,in_scale', [
+    (3, 1, 96, 128, True, 1.0), (4, 3, 80, 112, False, 1.0), (4, 1, 16, 16, False, 1.0), (3, 1, 480, 864, True, 2.5),
+    (4, 5, 480, 864, False, 1.0), (4, 2, 1088, 1920, False, 1.0), (3, 1, 272, 4 * 130, True, 0.05)])
+def test_stem7x7_is_fp32_accurate(cin, batch, H, W, relu, in_scale):
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(cin * 1000 + H + batch)
+    w = rand(g, 64, cin, 7, 7, scale=(2.0 / (cin * 49))**0.5)
+    w.view(-1)[::5] *= 1e-3
+    bn = (torch.rand(64, generator=g) + 0.5, rand(g, 64, scale=0.1), rand(g, 64, scale=0.1), torch.rand(64, generator=g) + 0.5, 1e-5)
+    ps = ops.pack_stem(w, None, bn, dev())
+    pc = ops.pack_conv(w, None, bn)
+    image = rand(g, 1, 3, H, W, scale=in_scale)
+    masks = torch.rand(batch, 1, H, W, generator=g) if cin == 4 else None
+    x = image.expand(batch, -1, -1, -1) if masks is None else torch.cat([image.expand(batch, -1, -1, -1), masks], 1)
+    want = F.conv2d(x.double(), emu_ops._unpack(pc).double(), pc.bias.double(), stride=2, padding=3)
+    want = F.relu(want) if relu else want
+    before = ops.split_fallbacks(dev())
+    got = ops.stem7x7(ps, to_dev(image), to_dev(masks), relu=relu)
+    f32 = ops.conv2d(to_dev(pc), to_dev(x.contiguous()), stride=2, pad=3, act=ops.ACT_RELU if relu else ops.ACT_NONE)
+    torch.cuda.synchronize()
+    assert tuple(got.shape) == (batch, 64, H // 2, W // 2) and not torch.isnan(got).any()
+    scale = max(1e-30, want.abs().max().item())
+    e_stem = (got.double().cpu() - want).abs().max().item() / scale
+    e_f32 = (f32.double().cpu() - want).abs().max().item() / scale
+    print(f'stem {cin}ch x{batch} {H}x{W}: max err / |ref|max against fp64: stem kernel {e_stem:.3e}, fp32 kernels {e_f32:.3e}')
+    assert e_stem <= 2.0 * e_f32 + 1e-6, (e_stem, e_f32)
+    assert ops.split_fallbacks(dev()) == before
+
+
+@pytest.mark.parametrize('poison', [7.0e4, float('inf')], ids=['70000', 'inf'])
+def test_stem7x7_recomputes_a_tile_beyond_the_fp16_range(poison):
+    """an input beyond +-65504: the workgroup that meets it recomputes ITS tile with fp32 FMAs inside the kernel (no second
+    launch) and the call is counted; everywhere the result is the fp32 convolution's"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(5)
+    w = rand(g, 64, 4, 7, 7, scale=0.1)
+    ps, pc = ops.pack_stem(w, rand(g, 64, scale=0.1), None, dev()), ops.pack_conv(w, None, None)
+    image, masks = rand(g, 1, 3, 64, 160), torch.rand(2, 1, 64, 160, generator=g)
+    masks[1, 0, 40, 100] = poison
+    x = torch.cat([image.expand(2, -1, -1, -1), masks], 1)
+    want = F.conv2d(x, emu_ops._unpack(pc), ps.bias.cpu(), stride=2, padding=3)
+    before = ops.split_fallbacks(dev())
+    got = ops.stem7x7(ps, to_dev(image), to_dev(masks)).cpu()
+    torch.cuda.synchronize()
+    assert ops.split_fallbacks(dev()) == before + 1
+    assert torch.equal(got.isfinite(), want.isfinite())
+    fin = want.isfinite()
+    assert (got[fin] - want[fin]).abs().max().item() <= 2e-5 * max(1.0, want[fin].abs().max().item())
+
+
 def test_conv_split_in_place_residual_takes_the_fp32_kernels():
     """out aliasing the residual (an in-place residual add) with split=True: the fp32 re-run behind a split launch would
     read the residual after `out` was written, so such a call must run the fp32 kernels alone -- also when an input is

@@ -118,3 +118,20 @@ def test_input_head(h, w, size, aa):
     border = padded.clone()
     border[:, 1:padded.shape[1] - 2, 3:padded.shape[2] - 4] = 0
     assert (border == 0).all()
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.int64, torch.uint8])
+@pytest.mark.parametrize('shape,pad', [((3, 480, 854), (5, 5, 0, 0)), ((1080, 1920), (0, 0, 4, 4)), ((2, 3, 37, 51), (6, 7, 5, 6))])
+def test_pad2d_matches_f_pad(dtype, shape, pad):
+    """deva_pad2d (one launch) against F.pad with zeros: bit-identical; the path of tensor_utils.pad_divide_by"""
+    import torch.nn.functional as F
+    from deva.utils.tensor_utils import pad_divide_by
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(*shape, generator=g) * 50).to(dtype)
+    got = ops.pad2d(to_dev(x), pad)
+    torch.cuda.synchronize()
+    assert got.dtype == dtype and torch.equal(got.cpu(), F.pad(x, pad))
+    via, p = pad_divide_by(to_dev(x), 16)
+    ref, p_ref = pad_divide_by(x, 16)
+    assert p == p_ref and torch.equal(via.cpu(), ref)
+

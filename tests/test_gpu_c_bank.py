@@ -146,3 +146,15 @@ def test_index_mask_resize_argmax_lut(c, h, w, size):
         assert margin.max().item() <= 1e-6, f'{int(diff.sum())} labels differ with a decisive margin'
     if size is None:  # no table: plain argmax, ties -> channel 0
         assert int(ops.index_mask(to_dev(prob)).cpu()[:3, :5].abs().sum()) == 0
+
+
+def test_usage_init():
+    use = torch.full((5000,), 3.0, device=dev())
+    life = torch.full((5000,), 4.0, device=dev())
+    ops.usage_init(use[100:4100], life[100:4100])
+    torch.cuda.synchronize()
+    want_u, want_l = torch.full((5000,), 3.0), torch.full((5000,), 4.0)
+    want_u[100:4100] = 0.0
+    want_l[100:4100] = 1e-7
+    assert torch.equal(use.cpu(), want_u) and torch.equal(life.cpu(), want_l)
+

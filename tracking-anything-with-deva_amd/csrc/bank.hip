@@ -199,6 +199,21 @@ static int launch_transpose(const float* src, float* dst, int rows, int cols, vo
   return 0;
 }
 
+// usage counters of freshly appended tokens (kv_memory_store.py:93-95: use_count = 0, life_count = 1e-7)
+__global__ void usage_init_kernel(float* __restrict__ use, float* __restrict__ life, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    use[i] = 0.0f;
+    life[i] = 1e-7f;
+  }
+}
+
+extern "C" int deva_usage_init(float* use, float* life, int count, void* stream) {
+  DEVA_REQUIRE(use && life && count > 0, "deva_usage_init: bad args");
+  hipLaunchKernelGGL(usage_init_kernel, dim3((unsigned)ceil_div(count, 256)), dim3(256), 0, (hipStream_t)stream, use, life, count);
+  return check_launch("deva_usage_init");
+}
+
 extern "C" int deva_bank_append(const float* src, float* arena, int64_t dst_row0, int channels, int count,
                                 void* stream) {
   DEVA_REQUIRE(src && arena && dst_row0 >= 0 && channels > 0 && count > 0, "deva_bank_append: bad args");

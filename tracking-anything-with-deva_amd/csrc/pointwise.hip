@@ -15,6 +15,23 @@ inline dim3 grid_for(int64_t n) {
   return dim3((unsigned)b);
 }
 
+// ------------------------------------------------------------------ zero padding of the last two dimensions
+// (tensor_utils.py:7-22 pad_divide_by -> F.pad: a fill and a copy launch per frame in ATen).  T = the element as an integer
+// of its size: the kernel moves bits.
+template <typename T>
+__global__ void pad2d_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t total, int H, int W, int top, int left,
+                             int OH, int OW) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ow = (int)(i % OW);
+    const int64_t t = i / OW;
+    const int oh = (int)(t % OH);
+    const int64_t plane = t / OH;
+    const int ih = oh - top, iw = ow - left;
+    const bool inside = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+    out[i] = inside ? in[(plane * H + ih) * W + iw] : (T)0;
+  }
+}
+
 // ------------------------------------------------------------------ max pool 3x3 / s2 / p1
 __global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t total,
                                     int H, int W, int OH, int OW, int relu_after) {
@@ -449,6 +466,30 @@ __global__ void input_head_kernel(const HeadArgs p) {
 }  // namespace deva
 
 using namespace deva;
+
+extern "C" int deva_pad2d(const void* in, void* out, int elem_bytes, int64_t planes, int height, int width, int top, int left,
+                          int out_height, int out_width, void* stream) {
+  DEVA_REQUIRE(in && out && planes > 0 && height > 0 && width > 0 && top >= 0 && left >= 0 && out_height >= height + top &&
+                   out_width >= width + left, "deva_pad2d: bad args");
+  const int64_t total = planes * out_height * out_width;
+  switch (elem_bytes) {
+    case 1:
+      hipLaunchKernelGGL(pad2d_kernel<uint8_t>, grid_for(total), dim3(TPB), 0, (hipStream_t)stream, (const uint8_t*)in,
+                         (uint8_t*)out, total, height, width, top, left, out_height, out_width);
+      break;
+    case 4:
+      hipLaunchKernelGGL(pad2d_kernel<uint32_t>, grid_for(total), dim3(TPB), 0, (hipStream_t)stream, (const uint32_t*)in,
+                         (uint32_t*)out, total, height, width, top, left, out_height, out_width);
+      break;
+    case 8:
+      hipLaunchKernelGGL(pad2d_kernel<uint64_t>, grid_for(total), dim3(TPB), 0, (hipStream_t)stream, (const uint64_t*)in,
+                         (uint64_t*)out, total, height, width, top, left, out_height, out_width);
+      break;
+    default:
+      DEVA_REQUIRE(false, "deva_pad2d: elements of 1, 4 or 8 bytes");
+  }
+  return check_launch("deva_pad2d");
+}
 
 extern "C" int deva_maxpool3x3s2(const float* in, float* out, int64_t planes, int height, int width,
                                  int relu_after, void* stream) {

@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdeva_hip.so')
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQUARE_PLUS_ONE = 0, 1, 2, 3
 KLAYOUT_TAP_MAJOR, KLAYOUT_CHUNK32 = 0, 1
@@ -57,6 +57,11 @@ SIGNATURES = {
     'deva_cbam_mlp': (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
     'deva_cbam_channel_pool': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'deva_cbam_apply': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'deva_stem7x7': (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
+                             c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'deva_stem_pack': (c_int64, [c_void_p, c_int, c_void_p, c_void_p, POINTER(c_int)]),
+    'deva_pad2d': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'deva_usage_init': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     'deva_gru_update': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'deva_affinity_topk': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                    c_int, c_int, c_int, c_void_p, c_void_p]),

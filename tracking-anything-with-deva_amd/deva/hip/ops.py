@@ -13,7 +13,7 @@ import torch
 from . import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQUARE_PLUS_ONE, KLAYOUT_CHUNK32, KLAYOUT_Q4, KLAYOUT_TAP_MAJOR,
                ConvDesc, DevaHipError, check, lib)
 
-__all__ = ['PackedConv', 'pack_conv', 'conv2d', 'split_fallbacks', 'maxpool3x3s2', 'upsample2x_add', 'area_downsample',
+__all__ = ['PackedConv', 'pack_conv', 'conv2d', 'split_fallbacks', 'PackedStem', 'pack_stem', 'stem7x7', 'pad2d', 'usage_init', 'maxpool3x3s2', 'upsample2x_add', 'area_downsample',
            'aggregate', 'softmax_channels', 'upsample4x_softmax', 'cbam', 'gru_update',
            'affinity_topk', 'BankPrep', 'affinity_dense', 'affinity_candidates', 'affinity_merge', 'usage_update', 'readout_sparse', 'bank_append', 'bank_gather_rows',
            'bank_export', 'rank', 'rank_select', 'evict_select', 'similarity_dense', 'softmax_columns',
@@ -348,6 +348,89 @@ def conv2d(pc: PackedConv, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, 
 
 
 # ------------------------------------------------------------------------------------------ pointwise
+@dataclass
+class PackedStem:
+    """weights of a 7x7 stride-2 stem for deva_stem7x7 (csrc/conv_stem.hip): hi / lo fp16 planes of w * 2^scale_log2 in the
+    kernel's K order, the fp32 weights of its in-kernel fall-back, the folded bias"""
+    planes: torch.Tensor   # int16 view of the uint16 planes, [cin*8*2*64*8]
+    w32: torch.Tensor      # [cin*49, 64]
+    bias: Optional[torch.Tensor]
+    cin: int
+    scale_log2: int
+
+
+def pack_stem(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None, device=None) -> PackedStem:
+    """[64][cin = 3 | 4][7][7] (+ eval-mode BatchNorm, folded like pack_conv) -> PackedStem through deva_stem_pack"""
+    import ctypes
+    w = weight.detach().to(torch.float32).cpu()
+    cout, cin, kh, kw = w.shape
+    if (cout, kh, kw) != (64, 7, 7) or cin not in (3, 4):
+        raise DevaHipError(f'pack_stem: 64 x (3|4) x 7 x 7 weights expected, got {tuple(w.shape)}')
+    b = None if bias is None else bias.detach().to(torch.float32).cpu()
+    if bn is not None:
+        gamma, beta, mean, var, eps = bn
+        scale = gamma.detach().float().cpu() / torch.sqrt(var.detach().float().cpu() + eps)
+        w = w * scale.view(-1, 1, 1, 1)
+        shift = beta.detach().float().cpu() - mean.detach().float().cpu() * scale
+        b = shift if b is None else b * scale + shift
+    w = w.contiguous()
+    L = lib()
+    e = ctypes.c_int(0)
+    n = L.deva_stem_pack(w.data_ptr(), cin, None, None, ctypes.byref(e))
+    if n < 0:
+        raise DevaHipError(f'deva_stem_pack failed: {L.deva_hip_last_error().decode()}')
+    planes = torch.zeros(n, dtype=torch.int16)
+    w32 = torch.zeros(cin * 49, 64, dtype=torch.float32)
+    if L.deva_stem_pack(w.data_ptr(), cin, planes.data_ptr(), w32.data_ptr(), ctypes.byref(e)) != n:
+        raise DevaHipError(f'deva_stem_pack failed: {L.deva_hip_last_error().decode()}')
+    if device is not None:
+        planes, w32, b = planes.to(device), w32.to(device), None if b is None else b.to(device)
+    return PackedStem(planes, w32, None if b is None else b.contiguous(), cin, int(e.value))
+
+
+def stem7x7(ps: PackedStem, image: torch.Tensor, masks: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
+    """act(conv7x7 stride 2 pad 3 over cat(image broadcast, masks) + bias): image [1 or B,3,H,W], masks [B,1,H,W] | None
+    -> [B,64,H/2,W/2]; fp32-accurate on the f16 matrix pipes (deva_stem7x7), inputs beyond the fp16 range recomputed in fp32
+    inside the kernel (counted by `split_fallbacks`)"""
+    c1 = 0 if masks is None else masks.shape[1]
+    if image.shape[1] + c1 != ps.cin:
+        raise DevaHipError(f'stem7x7: {image.shape[1]}+{c1} input channels, weights expect {ps.cin}')
+    batch = image.shape[0] if masks is None else masks.shape[0]
+    if image.shape[0] not in (1, batch):
+        raise DevaHipError('stem7x7: the image batch must be 1 or equal to the masks\'')
+    h, w = image.shape[-2:]
+    if masks is not None and tuple(masks.shape[-2:]) != (h, w):
+        raise DevaHipError('stem7x7: image / mask size mismatch')
+    in0, bs0 = _batched(image, 'image')
+    in1, bs1 = (None, 0) if masks is None else _batched(masks, 'masks')
+    out = _alloc((batch, 64, h // 2, w // 2), image.device)
+    check(lib().deva_stem7x7(in0, bs0, image.shape[1], in1, bs1, c1, batch, h, w, _p(ps.planes, torch.int16), _p(ps.w32),
+                             ps.scale_log2, _p(ps.bias), int(relu), _p(out), _split_flag(image.device), _stream()),
+          'deva_stem7x7')
+    return out
+
+
+def pad2d(x: torch.Tensor, pad: Tuple[int, int, int, int]) -> torch.Tensor:
+    """F.pad(x, (left, right, top, bottom)) with zeros on the last two dimensions, one launch (deva_pad2d); fp32 results
+    carry the guard bands of `_alloc`"""
+    left, right, top, bottom = pad
+    h, w = x.shape[-2:]
+    oh, ow = h + top + bottom, w + left + right
+    if not x.is_cuda or not x.is_contiguous() or x.element_size() not in (1, 4, 8):
+        raise DevaHipError('pad2d: a contiguous HIP tensor with 1-, 4- or 8-byte elements expected')
+    shape = (*x.shape[:-2], oh, ow)
+    out = _alloc(shape, x.device) if x.dtype == torch.float32 else torch.empty(shape, dtype=x.dtype, device=x.device)
+    planes = x.numel() // (h * w)
+    check(lib().deva_pad2d(x.data_ptr(), out.data_ptr(), x.element_size(), planes, h, w, top, left, oh, ow, _stream()),
+          'deva_pad2d')
+    return out
+
+
+def usage_init(use: torch.Tensor, life: torch.Tensor) -> None:
+    """use[:] = 0, life[:] = 1e-7 (the counters of freshly appended tokens), one launch"""
+    check(lib().deva_usage_init(_p(use), _p(life), use.numel(), _stream()), 'deva_usage_init')
+
+
 def maxpool3x3s2(x: torch.Tensor, relu_after: bool = False) -> torch.Tensor:
     b, c, h, w = x.shape
     out = _alloc((b, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1), x.device)

@@ -217,8 +217,7 @@ class KeyValueMemoryStore:
             if self.save_usage:
                 use = bk.use.ensure(bk.n + n_new, bk.n)
                 life = bk.life.ensure(bk.n + n_new, bk.n)
-                use[bk.n:bk.n + n_new].zero_()
-                life[bk.n:bk.n + n_new].fill_(1e-7)  # kv_memory_store.py:93-95
+                ops.usage_init(use[bk.n:bk.n + n_new], life[bk.n:bk.n + n_new])  # 0 and 1e-7 (kv_memory_store.py:93-95)
             if self._vshard is not None:
                 if bk.lrow is None or bk.lrow.numel() < bk.n + n_new:
                     grown = torch.full((max(_MIN_ROWS, 2 * (bk.n + n_new)),), -1, dtype=torch.int32, device=device)

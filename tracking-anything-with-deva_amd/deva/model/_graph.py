@@ -153,6 +153,13 @@ class CompiledGraph:
                          ('mask_encoder.conv1', 3)):
             if base + '.weight' in sd:
                 self.split[base] = self._split_pack(base, cx)
+        # the 7x7 stride-2 stems under --f16_split*: a direct convolution on the f16 matrix pipes (csrc/conv_stem.hip) instead
+        # of the scalar-gather fp32 kernel (3 / 4 input channels give the implicit GEMM nothing to tile); the value encoder's
+        # reads cat(image, mask) directly, like the reference (big_modules.py:103-107), instead of image part + mask part
+        self.stems: Dict[str, ops.PackedStem] = {}
+        for base in ('pixel_encoder.conv1', 'mask_encoder.conv1'):
+            if self._split_of(base):
+                self.stems[base] = ops.pack_stem(sd[base + '.weight'], sd.get(base + '.bias'), self._bn_after(base), device)
         # the two 1x1 projections of the key encoder read the same feature map: one launch with their output
         # channels side by side (big_modules.py:42-51 runs them one after the other)
         w1, w2 = sd['pixel_encoder.proj1.weight'], sd['pixel_encoder.proj2.weight']
@@ -258,7 +265,10 @@ class CompiledGraph:
     def encode_image(self, image):
         c = self.convs
         pe = 'pixel_encoder'
-        x = self._conv(pe + '.conv1', image, stride=2, pad=3, act=ACT_RELU)
+        if (pe + '.conv1') in self.stems:
+            x = ops.stem7x7(self.stems[pe + '.conv1'], image, None, relu=True)
+        else:
+            x = self._conv(pe + '.conv1', image, stride=2, pad=3, act=ACT_RELU)
         x = ops.maxpool3x3s2(x)
         f4 = self._stage(pe + '.res2', x, 3, 1, self._bottleneck)
         f8 = self._stage(pe + '.layer2', f4, 4, 2, self._bottleneck)
@@ -276,7 +286,10 @@ class CompiledGraph:
         """image [1,3,H,W]; masks [no,1,H,W]; sensory [no,C,h,w] -> value [no,C,h,w], sensory'"""
         c = self.convs
         me = 'mask_encoder'
-        g = self._conv_shared_x(me + '.conv1', image, masks, stride=2, pad=3)
+        if (me + '.conv1') in self.stems:
+            g = ops.stem7x7(self.stems[me + '.conv1'], image, masks)
+        else:
+            g = self._conv_shared_x(me + '.conv1', image, masks, stride=2, pad=3)
         g = ops.maxpool3x3s2(g, relu_after=True)
         g = self._stage(me + '.layer1', g, 2, 1, self._basic)
         g = self._stage(me + '.layer2', g, 2, 2, self._basic)
