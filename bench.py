@@ -248,7 +248,9 @@ def conv_roofline_report(ct, frames):
     the f16 peak (their event pairs include the gated fp32 launch that follows every split launch); fp32 kernels
     against the fp32 matrix peak"""
     sp = ct.split_by_precision()
-    out = {'method': 'HIP events around every deva_conv2d launch of an un-synchronised replay (bench.py:ConvTimer)'}
+    out = {'method': 'HIP events around every deva_conv2d launch of an un-synchronised replay (bench.py:ConvTimer)',
+           # every operand of every deva_conv2d launch once (the stems of --f16_split* run deva_stem7x7: not in this sum)
+           'algorithmic_bytes_per_frame': sum(r[4] for r in ct.records) / frames}
     for name, (fl, ms, n) in sp.items():
         if n == 0:
             continue
@@ -992,7 +994,7 @@ def compact_line(result):
         r = result['roofline']
         out = {k: r[k] for k in ROOFLINE_KEYS if k in r}
         out['kernel'] = 'conv_mfma_kernel / conv_igemm_kernel (fp32 MFMA implicit GEMM)'
-        out.update({k: v for k, v in r.items() if k.startswith(('affinity_', 'f16_split_frac_of_f16_peak_'))
+        out.update({k: v for k, v in r.items() if k.startswith(('affinity_', 'f16_split_frac_of_f16_peak_', 'f16_split_traffic_'))
                     and not isinstance(v, (dict, list, str))})
         p = r.get('sustained_mfma_probe')
         if isinstance(p, dict) and 'random_operands_tflops' in p:
@@ -1252,6 +1254,18 @@ def main():
                         if cr and 'f16_split' in key:
                             result['roofline'][key.replace('fps_', 'f16_split_fp32_equiv_tflops_')] = round(cr['fp32_equivalent_tflops'], 1)
                             result['roofline'][key.replace('fps_', 'f16_split_frac_of_f16_peak_')] = round(cr['frac_of_f16_mfma_peak'], 3)
+                        if key == 'fps_1080p_8seg_f16_split_key_encoder':
+                            # HBM counter traffic of this clip's convolution kernels (tools/pmc_split.sh, committed summary)
+                            pmc = os.path.join(ROOT, 'profiles', 'pmc_r06', 'conv_traffic_split.json')
+                            if os.path.exists(pmc):
+                                with open(pmc) as f:
+                                    d = json.load(f)
+                                e['config']['hbm_counter_traffic'] = {
+                                    'hbm_bytes_per_frame': d['hbm_bytes_per_frame'], 'algorithmic_bytes_per_frame': d['algorithmic_bytes_per_frame'],
+                                    'traffic_over_algorithmic': d['traffic_over_algorithmic'], 'source': 'profiles/pmc_r06/conv_traffic_split.json',
+                                    'measured_on_this_build': d.get('conv_source_sha1') == conv_source_sha1()}
+                                if d.get('traffic_over_algorithmic'):
+                                    result['roofline']['f16_split_traffic_over_algorithmic_1080p_8seg_key_encoder'] = round(d['traffic_over_algorithmic'], 3)
                         break
         if isinstance(result.get('affinity'), dict) and 'us_read' in result['affinity']:
             a = result['affinity']

@@ -30,8 +30,9 @@ def main():
         return real_report(ct, frames)
 
     bench.conv_roofline_report = report
+    steps, warmup = int(os.environ.get('DEVA_LINE_STEPS', 25)), int(os.environ.get('DEVA_LINE_WARMUP', 6))  # (PMC passes: fewer)
     if what == '8seg':
-        fps, state = bench.run_1080p_segments(net, device, steps=25, warmup=6, segments=8, conv_roofline=True)
+        fps, state = bench.run_1080p_segments(net, device, steps=steps, warmup=warmup, segments=8, conv_roofline=True)
     elif what == '1080p1':
         fps, state = bench.run_1080p(net, device, steps=25, warmup=6, detections=False, conv_roofline=True)
     else:

@@ -47,6 +47,43 @@ def _conv_sha1():
     return h.hexdigest()
 
 
+def split(prefix, line_json, out):
+    """HBM traffic per frame of the convolution kernels of the 8-segment 1080p clip under --f16_split --f16_split_key_encoder
+    (tools/pmc_split.sh) next to the algorithmic bytes of the same clip (tools/bench_line.py: every operand of every
+    deva_conv2d launch once)"""
+    counters, durations = load(prefix)
+    is_conv = lambda n: n.startswith(('conv_', 'splitk_reduce', 'stem7x7'))
+    frames = max(counters.get('upsample4x_softmax_kernel', {}).get('FETCH_SIZE', [0, 0])[1], 1)  # one decoder pass per propagated frame
+    rd = sum(c['FETCH_SIZE'][0] for n, c in counters.items() if is_conv(n) and 'FETCH_SIZE' in c) * 1024 * 2
+    wr = sum(c['WRITE_SIZE'][0] for n, c in counters.items() if is_conv(n) and 'WRITE_SIZE' in c) * 1024
+    with open(line_json) as f:
+        line = json.load(f)
+    alg = (line.get('state', {}).get('conv_roofline') or {}).get('algorithmic_bytes_per_frame')
+    per_family = {}
+    for n, c in counters.items():
+        if is_conv(n):
+            per_family[n] = {'read_bytes_per_frame': c.get('FETCH_SIZE', [0.0])[0] * 2048 / frames,
+                             'write_bytes_per_frame': c.get('WRITE_SIZE', [0.0])[0] * 1024 / frames,
+                             'dispatches_per_frame': max(v[1] for v in c.values()) / frames}
+    res = {
+        'command': 'DEVA_LINE_STEPS=10 DEVA_LINE_WARMUP=6 python tools/bench_line.py 8seg split_all (8-segment 1080p clip, '
+                   '--f16_split --f16_split_key_encoder; recording pass + warm-up + timed + event-timed replay)',
+        'conv_source_sha1': _conv_sha1(),
+        'frames_in_a_pass': frames,
+        'hbm_read_bytes_per_frame (FETCH_SIZE KiB x 1024 x 2, gfx950 correction)': rd / frames,
+        'hbm_write_bytes_per_frame (WRITE_SIZE KiB x 1024)': wr / frames,
+        'hbm_bytes_per_frame': (rd + wr) / frames,
+        'algorithmic_bytes_per_frame': alg,
+        'traffic_over_algorithmic': ((rd + wr) / frames / alg) if alg else None,
+        'kernels': 'conv_f16_kernel*, stem7x7_kernel*, conv_mfma_kernel* (fp32 layers + the gated re-runs), splitk_reduce_kernel, '
+                   'conv_cout1 kernels',
+        'per_kernel_family': per_family,
+    }
+    with open(out, 'w') as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps({k: v for k, v in res.items() if k != 'per_kernel_family'}, indent=1))
+
+
 def conv(prefix, out):
     counters, durations = load(prefix)
     is_conv = lambda n: n.startswith('conv_') or n.startswith('splitk_reduce')  # conv_mfma, conv_igemm, conv_cout1, conv3x3_cout1_rows
@@ -226,5 +263,7 @@ def clock(probe_prefix, bench_prefix, out):
 if __name__ == '__main__':
     if sys.argv[1] == 'clock':
         clock(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif sys.argv[1] == 'split':
+        split(sys.argv[2], sys.argv[3], sys.argv[4])
     else:
         {'conv': conv, 'aff': aff, 'read': read}[sys.argv[1]](sys.argv[2], sys.argv[3])
