@@ -175,6 +175,12 @@ int64_t deva_conv_pack(const float* w_oihw, float* out, int cout, int cin, int k
 int deva_pad2d(const void* in, void* out, int elem_bytes, int64_t planes, int height, int width, int top, int left,
                int out_height, int out_width, void* stream);
 
+/* The taps of a stride-2 convolution as channels: in [batch][channels][H][W] -> out [batch][k*k*channels][OH][OW],
+ * out[b][t*C + c][oh][ow] = in[b][c][2 oh + dy - pad][2 ow + dx - pad] (zero outside), t = dy*k + dx, k = 1 (pad 0) or 3
+ * (pad 1).  The stride-2 convolutions of the ResNets (resnet.py:46-114) then run as 1x1 stride-1 convolutions over
+ * k*k*channels channels (weights [cout][t*C + c]) on the vector-gather kernels of deva_conv2d. */
+int deva_gather_s2(const float* in, float* out, int batch, int channels, int height, int width, int kernel, void* stream);
+
 /* nn.MaxPool2d(3, stride 2, pad 1) (resnet.py:122), optional fused ReLU after the pool
  * (MaskEncoder order, big_modules.py:107-110).  in [planes][H][W] -> out [planes][OH][OW]. */
 int deva_maxpool3x3s2(const float* in, float* out, int64_t planes, int height, int width,

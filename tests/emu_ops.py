@@ -135,6 +135,14 @@ def usage_init(use, life):
     life.fill_(1e-7)
 
 
+def gather_s2(x, kernel):
+    b, c, h, w = x.shape
+    pad = kernel // 2
+    cols = F.unfold(x, kernel, padding=pad, stride=2)  # [B, C*k*k, L] with channel index c*k*k + t
+    oh, ow = (h + 2 * pad - kernel) // 2 + 1, (w + 2 * pad - kernel) // 2 + 1
+    return cols.view(b, c, kernel * kernel, oh, ow).transpose(1, 2).reshape(b, kernel * kernel * c, oh, ow).contiguous()
+
+
 def maxpool3x3s2(x, relu_after=False):
     y = F.max_pool2d(x, 3, 2, 1)
     return F.relu(y) if relu_after else y

@@ -41,6 +41,42 @@ def test_area_downsample(shape, f):
     _check('area', ops.area_downsample(to_dev(x), f), emu_ops.area_downsample(x, f))
 
 
+@pytest.mark.parametrize('shape,f', [((3, 16, 272, 480), 4), ((2, 8, 120, 216), 4), ((2, 8, 136, 240), 2), ((3, 4, 60, 108), 2),
+                                     ((1, 3, 12, 20), 4), ((2, 2, 8, 12), 2)])
+def test_area_downsample_vector_path_is_bit_identical_to_the_scalar_kernel(shape, f):
+    """factors 2 / 4 on aligned rows run 16-byte loads (2 or 4 outputs per thread); same sums in the same order as the
+    one-output-per-thread kernel, which an unaligned view of the same data still takes"""
+    g = torch.Generator().manual_seed(sum(shape) + f)
+    x = rand(g, *shape)
+    n = x.numel()
+    buf = torch.zeros(n + 8, device=dev())
+    buf[4:4 + n] = x.reshape(-1).to(dev())   # 16-byte aligned view -> vector path
+    buf2 = torch.zeros(n + 8, device=dev())
+    buf2[1:1 + n] = x.reshape(-1).to(dev())  # 4-byte aligned view -> scalar path
+    a = ops.area_downsample(buf[4:4 + n].view(*shape), f)
+    b = ops.area_downsample(buf2[1:1 + n].view(*shape), f)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    _check('area', a, emu_ops.area_downsample(x, f))
+
+
+@pytest.mark.parametrize('k', [1, 3])
+@pytest.mark.parametrize('shape', [(1, 256, 120, 216), (3, 64, 60, 108), (2, 5, 14, 22), (1, 3, 6, 10)])
+def test_gather_s2_is_the_stride2_convolutions_im2col(shape, k):
+    """deva_gather_s2: the taps of a k x k stride-2 convolution as channels (tap-major), exact copies; a 1x1 convolution with
+    the weights in [cout][t*C + c] order over it is the stride-2 convolution (checked on the CPU in fp64)"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(k + sum(shape))
+    x = rand(g, *shape)
+    got = ops.gather_s2(to_dev(x), k)
+    torch.cuda.synchronize()
+    assert torch.equal(got.cpu(), emu_ops.gather_s2(x, k))
+    w = rand(g, 8, shape[1], k, k)
+    ref = F.conv2d(x.double(), w.double(), stride=2, padding=k // 2)
+    via = F.conv2d(got.cpu().double(), w.permute(0, 2, 3, 1).reshape(8, -1, 1, 1).double())
+    assert (via - ref).abs().max().item() <= 1e-9 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize('no', [1, 2, 5])
 def test_aggregate_and_softmax(no):
     g = torch.Generator().manual_seed(4)

@@ -5,7 +5,7 @@
 // Why a kernel of its own: with 3 / 4 input channels the implicit-GEMM machinery has nothing to tile (K = 147 / 196 taps
 // that change source pixel with every k: conv_mfma.hip KIND 3 gathers them one scalar load per element and runs at
 // 29-38 TFLOP/s), while the work is tiny for the matrix pipes and the layer is bound by its 64-channel output stream.
-// Here a workgroup (8 waves) owns 8 output rows x 64 output columns of all 64 channels:
+// Here a workgroup (8 waves; one per CU, walking over the tiles) owns 8 output rows x 64 output columns of all 64 channels:
 //   * the input patch (22 rows x 134 columns per channel) is read ONCE with coalesced row loads, split into hi = fp16(x),
 //     lo = fp16(x - hi) planes and kept in LDS as [plane][channel][row][column] halfs;
 //   * K is ordered (channel, dy pair, dy parity, dx 0..7) with the 8th row / column tap a zero weight: a lane's B
@@ -50,7 +50,7 @@ struct StemArgs {
   float out_scale;
   int relu;
   float* out;           // [batch][64][OH][OW]
-  int tiles_x, tiles_y;
+  int tiles_x, tiles_y, total_tiles;  // total = tiles_x * tiles_y * batch: the workgroups walk over them
   int* flag;
 };
 
@@ -67,32 +67,36 @@ __global__ __launch_bounds__(STEM_THREADS, 1) void stem7x7_kernel(const StemArgs
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
-  const int b = blockIdx.y;
-  const int ty = blockIdx.x / p.tiles_x, tx = blockIdx.x - ty * p.tiles_x;
-  const int r0 = ty * TR, c0 = tx * TC;
 
-  if (tid == 0) s_bad = 0;
-  // ---- weights -> LDS (the fragment layout as packed)
+  // ---- weights -> LDS once per workgroup (the fragment layout as packed); the workgroup then walks over its tiles
   {
     const u32x4* src = reinterpret_cast<const u32x4*>(p.w16);
     u32x4* dst = reinterpret_cast<u32x4*>(s_w);
     constexpr int V = W_HALFS / 8;
     for (int i = tid; i < V; i += STEM_THREADS) dst[i] = src[i];
   }
-  // ---- input patch -> hi / lo planes: pairs of adjacent columns per thread (one 4-byte LDS store per plane); every load
-  // of the thread is issued before the first conversion
-  {
-    const int row_in0 = 2 * r0 - 3, col_in0 = 2 * c0 - 3;
-    constexpr int PAIRS = PCP / 2;  // 68 column pairs per row (the last one is padding)
-    constexpr int TASKS = C * PR * PAIRS;
-    constexpr int ITERS = (TASKS + STEM_THREADS - 1) / STEM_THREADS;
-    float v0[ITERS], v1[ITERS];
+
+  // the input patch of a tile: pairs of adjacent columns per thread (one 4-byte LDS store per plane); the loads of the NEXT
+  // tile are issued before the MFMAs of the current one and land in registers while those run
+  constexpr int PAIRS = PCP / 2;  // 68 column pairs per row (the last one is padding)
+  constexpr int TASKS = C * PR * PAIRS;
+  constexpr int ITERS = (TASKS + STEM_THREADS - 1) / STEM_THREADS;
+  float v0[ITERS], v1[ITERS];
+  const int tiles_per_image = p.tiles_x * p.tiles_y;
+  auto load_patch = [&](int tile) {
+    const int b = tile / tiles_per_image;
+    const int rem = tile - b * tiles_per_image;
+    const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+    const int row_in0 = 2 * ty * TR - 3, col_in0 = 2 * tx * TC - 3;
+    int tv = tid;
+    asm volatile("" : "+v"(tv));  // (opaque per call: the per-task indices are recomputed per tile -- a few VALU instructions --
+                                  // instead of being hoisted out of the tile loop, where they cost 60 spilled registers)
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-      const int t = tid + it * STEM_THREADS;
+      const int t = tv + it * STEM_THREADS;
       const int c = t / (PR * PAIRS);
-      const int rem = t - c * (PR * PAIRS);
-      const int pr = rem / PAIRS, pp = rem - pr * PAIRS;
+      const int r2 = t - c * (PR * PAIRS);
+      const int pr = r2 / PAIRS, pp = r2 - pr * PAIRS;
       const int ih = row_in0 + pr, iw = col_in0 + 2 * pp;
       const float* src = c < p.c0 ? p.in0 + (int64_t)b * p.bs0 + (int64_t)c * p.H * p.W
                                   : p.in1 + (int64_t)b * p.bs1 + (int64_t)(c - p.c0) * p.H * p.W;
@@ -102,108 +106,128 @@ __global__ __launch_bounds__(STEM_THREADS, 1) void stem7x7_kernel(const StemArgs
       v0[it] = ok0 ? src[(int64_t)ih * p.W + iw] : 0.0f;
       v1[it] = ok1 ? src[(int64_t)ih * p.W + iw + 1] : 0.0f;
     }
+  };
+  auto store_patch = [&]() {  // -> hi / lo planes, [c][pr][2 pp] in the order of the tasks
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       const int t = tid + it * STEM_THREADS;
       if (t >= TASKS) break;
       const h2 hi = {(_Float16)v0[it], (_Float16)v1[it]};
       const h2 lo = {(_Float16)(v0[it] - (float)hi[0]), (_Float16)(v1[it] - (float)hi[1])};
-      _Float16* at = s_p + 2 * t;  // (channel, row, pair) in the order of the tasks: [c][pr][2 pp]
+      _Float16* at = s_p + 2 * t;
       *reinterpret_cast<h2*>(at) = hi;
       *reinterpret_cast<h2*>(at + P_PLANE) = lo;
     }
-  }
-  __syncthreads();
+  };
 
-  // ---- MFMAs: wave w = output row r0 + w; column blocks j = 0, 1 (32 columns each), channel blocks i = 0, 1
-  f32x16 acc[2][2];
+  const _Float16* a_rd = s_w + (half * 2 * STEM_COUT + l31) * 8;     // + ((kb*2*2 + plane) * 64 + 32 i) * 8
+  const _Float16* b_rd = s_p + ((2 * wave + half) * PCP + 2 * l31);  // + (c*PR + 2 dyp) * PCP + 64 j, + plane * P_PLANE
+  int tile = blockIdx.x;
+  if (tile < p.total_tiles) load_patch(tile);
+  for (; tile < p.total_tiles; tile += gridDim.x) {
+    const int b = tile / tiles_per_image;
+    const int rem = tile - b * tiles_per_image;
+    const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+    const int r0 = ty * TR, c0 = tx * TC;
+    if (tid == 0) s_bad = 0;
+    store_patch();
+    __syncthreads();
+    if (tile + (int)gridDim.x < p.total_tiles) load_patch(tile + gridDim.x);
+    __builtin_amdgcn_sched_barrier(0);  // (the loads are issued here; their address arithmetic does not drift into the MFMAs)
+
+    // ---- MFMAs: wave w = output row r0 + w; column blocks j = 0, 1 (32 columns each), channel blocks i = 0, 1
+    f32x16 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  const _Float16* a_rd = s_w + (half * 2 * STEM_COUT + l31) * 8;                 // + ((kb*2*2 + plane) * 64 + 32 i) * 8
-  const _Float16* b_rd = s_p + ((2 * wave + half) * PCP + 2 * l31);             // + (c*PR + 2 dyp) * PCP + 64 j, + plane * P_PLANE
-#pragma unroll
-  for (int kb = 0; kb < KB; ++kb) {
-    const int c = kb >> 2, dyp = kb & 3;
-    h8 fa[2][2], fb[2][2];
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) fa[pl][i] = *reinterpret_cast<const h8*>(a_rd + ((kb * 4 + pl) * STEM_COUT + 32 * i) * 8);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const _Float16* q = b_rd + pl * P_PLANE + (c * PR + 2 * dyp) * PCP + 64 * j;
-        u32x4 w;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) w[e] = *reinterpret_cast<const unsigned*>(q + 2 * e);
-        fb[pl][j] = __builtin_bit_cast(h8, w);
-      }
-    }
-#pragma unroll
-    for (int term = 0; term < 3; ++term)  // hi.hi, hi.lo, lo.hi
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[term == 2 ? 1 : 0][i], fb[term == 1 ? 1 : 0][j], acc[i][j], 0, 0, 0);
-  }
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const int c = kb >> 2, dyp = kb & 3;
+      h8 fa[2][2], fb[2][2];
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[pl][i] = *reinterpret_cast<const h8*>(a_rd + ((kb * 4 + pl) * STEM_COUT + 32 * i) * 8);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const _Float16* q = b_rd + pl * P_PLANE + (c * PR + 2 * dyp) * PCP + 64 * j;
+          u32x4 w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w[e] = *reinterpret_cast<const unsigned*>(q + 2 * e);
+          fb[pl][j] = __builtin_bit_cast(h8, w);
+        }
+      }
+#pragma unroll
+      for (int term = 0; term < 3; ++term)  // hi.hi, hi.lo, lo.hi
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[term == 2 ? 1 : 0][i], fb[term == 1 ? 1 : 0][j], acc[i][j], 0, 0, 0);
+      if (kb & 1) __builtin_amdgcn_sched_barrier(0);  // (fragments of at most two K-blocks in flight: the full unroll otherwise spills)
+    }
 
-  bool bad = false;
+    bool bad = false;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) bad |= (__builtin_bit_cast(unsigned, acc[i][j][r]) & 0x7f800000u) == 0x7f800000u;
-  if (__builtin_amdgcn_ballot_w64(bad) && lane == 0) s_bad = 1;
-  __syncthreads();
-  const int oh = r0 + wave;
-  if (s_bad == 0) {
-    if (oh < p.OH) {
+        for (int r = 0; r < 16; ++r) bad |= (__builtin_bit_cast(unsigned, acc[i][j][r]) & 0x7f800000u) == 0x7f800000u;
+    if (__builtin_amdgcn_ballot_w64(bad) && lane == 0) s_bad = 1;
+    __syncthreads();
+    const int oh = r0 + wave;
+    if (s_bad == 0) {
+      if (oh < p.OH) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int ow = c0 + 32 * j + l31;
-        if (ow >= p.OW) continue;
+        for (int j = 0; j < 2; ++j) {
+          const int ow = c0 + 32 * j + l31;
+          if (ow >= p.OW) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-            float v = acc[i][j][r] * p.out_scale + (p.bias ? p.bias[m] : 0.0f);
-            if (p.relu) v = fmaxf(v, 0.0f);
-            p.out[(((int64_t)b * STEM_COUT + m) * p.OH + oh) * p.OW + ow] = v;
+            for (int r = 0; r < 16; ++r) {
+              const int m = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+              float v = acc[i][j][r] * p.out_scale + (p.bias ? p.bias[m] : 0.0f);
+              if (p.relu) v = fmaxf(v, 0.0f);
+              p.out[(((int64_t)b * STEM_COUT + m) * p.OH + oh) * p.OW + ow] = v;
+            }
+        }
+      }
+    } else {
+      // ---- an input of this tile lies beyond the fp16 range: the tile again in plain fp32 (thread = output pixel)
+      if (tid == 0 && p.flag) atomicOr(p.flag, 1);
+      const int ow = c0 + lane;
+      if (oh < p.OH && ow < p.OW) {
+        float out[STEM_COUT];
+#pragma unroll
+        for (int m = 0; m < STEM_COUT; ++m) out[m] = p.bias ? p.bias[m] : 0.0f;
+        for (int c = 0; c < C; ++c) {
+          const float* src = c < p.c0 ? p.in0 + (int64_t)b * p.bs0 + (int64_t)c * p.H * p.W
+                                      : p.in1 + (int64_t)b * p.bs1 + (int64_t)(c - p.c0) * p.H * p.W;
+          for (int dy = 0; dy < 7; ++dy) {
+            const int ih = 2 * oh + dy - 3;
+            for (int dx = 0; dx < 7; ++dx) {
+              const int iw = 2 * ow + dx - 3;
+              const float x = ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? src[(int64_t)ih * p.W + iw] : 0.0f;
+              const float* wk = p.w32 + (int64_t)((c * 7 + dy) * 7 + dx) * STEM_COUT;
+#pragma unroll
+              for (int m = 0; m < STEM_COUT; ++m) out[m] = __builtin_fmaf(x, wk[m], out[m]);
+            }
           }
+        }
+#pragma unroll
+        for (int m = 0; m < STEM_COUT; ++m)
+          p.out[(((int64_t)b * STEM_COUT + m) * p.OH + oh) * p.OW + ow] = p.relu ? fmaxf(out[m], 0.0f) : out[m];
       }
+      // (the prefetched patch is loaded again here so that its registers are free during the 64 accumulators above)
+      if (tile + (int)gridDim.x < p.total_tiles) load_patch(tile + gridDim.x);
     }
-    return;
+    __syncthreads();  // every wave is done with this tile's patch (and with s_bad)
   }
-  // ---- an input of this tile lies beyond the fp16 range: the tile again in plain fp32 (thread = output pixel)
-  if (tid == 0 && p.flag) atomicOr(p.flag, 1);
-  const int ow = c0 + lane;
-  if (oh >= p.OH || ow >= p.OW) return;
-  float out[STEM_COUT];
-#pragma unroll
-  for (int m = 0; m < STEM_COUT; ++m) out[m] = p.bias ? p.bias[m] : 0.0f;
-  for (int c = 0; c < C; ++c) {
-    const float* src = c < p.c0 ? p.in0 + (int64_t)b * p.bs0 + (int64_t)c * p.H * p.W
-                                : p.in1 + (int64_t)b * p.bs1 + (int64_t)(c - p.c0) * p.H * p.W;
-    for (int dy = 0; dy < 7; ++dy) {
-      const int ih = 2 * oh + dy - 3;
-      for (int dx = 0; dx < 7; ++dx) {
-        const int iw = 2 * ow + dx - 3;
-        const float x = ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? src[(int64_t)ih * p.W + iw] : 0.0f;
-        const float* wk = p.w32 + (int64_t)((c * 7 + dy) * 7 + dx) * STEM_COUT;
-#pragma unroll
-        for (int m = 0; m < STEM_COUT; ++m) out[m] = __builtin_fmaf(x, wk[m], out[m]);
-      }
-    }
-  }
-#pragma unroll
-  for (int m = 0; m < STEM_COUT; ++m)
-    p.out[(((int64_t)b * STEM_COUT + m) * p.OH + oh) * p.OW + ow] = p.relu ? fmaxf(out[m], 0.0f) : out[m];
 }
 
 }  // namespace
@@ -272,7 +296,6 @@ extern "C" int deva_stem7x7(const float* in0, int64_t in0_batch_stride, int c0, 
   DEVA_REQUIRE((c0 == 3 && (c1 == 0 || c1 == 1)) && (c1 == 0 || in1), "deva_stem7x7: 3 (+ 1) input channels expected");
   DEVA_REQUIRE(height % 2 == 0 && width % 2 == 0, "deva_stem7x7: even input size expected (frames are padded to x16)");
   DEVA_REQUIRE(scale_log2 >= -120 && scale_log2 <= 120, "deva_stem7x7: scale_log2 out of range");
-  DEVA_REQUIRE(batch <= 65535, "deva_stem7x7: batch too large");
   StemArgs a;
   a.in0 = in0;
   a.in1 = in1;
@@ -293,7 +316,14 @@ extern "C" int deva_stem7x7(const float* in0, int64_t in0_batch_stride, int c0, 
   a.tiles_x = (int)ceil_div(a.OW, TC);
   a.tiles_y = (int)ceil_div(a.OH, TR);
   a.flag = flag;
-  const dim3 grid((unsigned)(a.tiles_x * a.tiles_y), (unsigned)batch);
+  const int64_t total = (int64_t)a.tiles_x * a.tiles_y * batch;
+  DEVA_REQUIRE(total < (1ll << 30), "deva_stem7x7: too many tiles");
+  a.total_tiles = (int)total;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  // one workgroup per CU (112 KB of LDS): persistent, the weights are staged once and the patch loads of the next tile
+  // overlap the MFMAs of the current one
+  const dim3 grid((unsigned)(total < cus ? total : cus));
   if (c0 + c1 == 3) {
     hipLaunchKernelGGL(stem7x7_kernel<3>, grid, dim3(STEM_THREADS), 0, (hipStream_t)stream, a);
   } else {

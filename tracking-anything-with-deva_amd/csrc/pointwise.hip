@@ -32,6 +32,37 @@ __global__ void pad2d_kernel(const T* __restrict__ in, T* __restrict__ out, int6
   }
 }
 
+// ------------------------------------------------------------------ taps of a stride-2 convolution as channels
+// out[b][t*C + c][oh][ow] = in[b][c][2 oh + dy - pad][2 ow + dx - pad] (zero outside), t = dy*K + dx: a K x K stride-2
+// convolution (resnet.py:46-114: conv1 / conv2 / downsample.0 of the first block of layer2, layer3) becomes a 1x1 stride-1
+// convolution over K*K*C channels, which the vector-gather kernels of conv_mfma.hip / conv_f16.hip take (the scalar-gather
+// kind they would otherwise run reaches 50 TFLOP/s).  One thread per (b, c, oh, ow): K*K loads, K*K coalesced stores.
+template <int K>
+__global__ void gather_s2_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t total, int C, int H, int W,
+                                 int OH, int OW) {
+  constexpr int PAD = K / 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ow = (int)(i % OW);
+    int64_t t = i / OW;
+    const int oh = (int)(t % OH);
+    t /= OH;
+    const int c = (int)(t % C);
+    const int64_t b = t / C;
+    const float* src = in + ((b * C + c) * (int64_t)H) * W;
+    float v[K * K];
+#pragma unroll
+    for (int dy = 0; dy < K; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < K; ++dx) {
+        const int ih = 2 * oh + dy - PAD, iw = 2 * ow + dx - PAD;
+        v[dy * K + dx] = ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) ? src[(int64_t)ih * W + iw] : 0.0f;
+      }
+    float* dst = out + ((b * K * K * C + c) * (int64_t)OH + oh) * OW + ow;
+#pragma unroll
+    for (int tap = 0; tap < K * K; ++tap) dst[(int64_t)tap * C * OH * OW] = v[tap];
+  }
+}
+
 // ------------------------------------------------------------------ max pool 3x3 / s2 / p1
 __global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t total,
                                     int H, int W, int OH, int OW, int relu_after) {
@@ -188,6 +219,47 @@ __global__ void area_downsample_kernel(const float* __restrict__ in, float* __re
     for (int dy = 0; dy < f; ++dy)
       for (int dx = 0; dx < f; ++dx) s += src[dy * W + dx];
     out[i] = s / denom;
+  }
+}
+
+// factors 2 and 4 on 16-byte aligned rows: the same sums in the same order from 16-byte loads (a vector-memory
+// instruction costs the same whatever its width: the scalar form issues f*f of them per output, this one f per OPT outputs)
+typedef float pw_f32x4 __attribute__((ext_vector_type(4)));
+typedef float pw_f32x2 __attribute__((ext_vector_type(2)));
+template <int F, int OPT>  // OPT outputs per thread (2 or 4) from OPT * F / 4 16-byte loads per input row
+__global__ void area_downsample_vec_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t total_groups,
+                                           int H, int W) {
+  constexpr int LOADS = OPT * F / 4;
+  static_assert(LOADS >= 1 && LOADS * 4 == OPT * F, "whole 16-byte loads");
+  const int OH = H / F, OW = W / F, GW = OW / OPT;
+  const float denom = (float)(F * F);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total_groups; i += (int64_t)gridDim.x * blockDim.x) {
+    const int gx = (int)(i % GW);
+    const int64_t t = i / GW;
+    const int oy = (int)(t % OH);
+    const int64_t plane = t / OH;
+    const float* src = in + plane * (int64_t)H * W + (int64_t)oy * F * W + gx * OPT * F;
+    pw_f32x4 v[F][LOADS];
+#pragma unroll
+    for (int dy = 0; dy < F; ++dy)
+#pragma unroll
+      for (int l = 0; l < LOADS; ++l) v[dy][l] = *reinterpret_cast<const pw_f32x4*>(src + dy * W + 4 * l);
+    float r[OPT];
+#pragma unroll
+    for (int o = 0; o < OPT; ++o) {
+      float sum = 0.0f;
+#pragma unroll
+      for (int dy = 0; dy < F; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < F; ++dx) sum += v[dy][(o * F + dx) / 4][(o * F + dx) % 4];
+      r[o] = sum / denom;
+    }
+    float* dst = out + (plane * OH + oy) * (int64_t)OW + gx * OPT;
+    if constexpr (OPT == 4) {
+      *reinterpret_cast<pw_f32x4*>(dst) = pw_f32x4{r[0], r[1], r[2], r[3]};
+    } else {
+      *reinterpret_cast<pw_f32x2*>(dst) = pw_f32x2{r[0], r[1]};
+    }
   }
 }
 
@@ -491,6 +563,23 @@ extern "C" int deva_pad2d(const void* in, void* out, int elem_bytes, int64_t pla
   return check_launch("deva_pad2d");
 }
 
+extern "C" int deva_gather_s2(const float* in, float* out, int batch, int channels, int height, int width, int kernel,
+                              void* stream) {
+  DEVA_REQUIRE(in && out && batch > 0 && channels > 0 && height > 0 && width > 0, "deva_gather_s2: bad args");
+  DEVA_REQUIRE(kernel == 1 || kernel == 3, "deva_gather_s2: kernel 1 (pad 0) or 3 (pad 1)");
+  const int pad = kernel / 2;
+  const int OH = (height + 2 * pad - kernel) / 2 + 1, OW = (width + 2 * pad - kernel) / 2 + 1;
+  const int64_t total = (int64_t)batch * channels * OH * OW;
+  if (kernel == 1) {
+    hipLaunchKernelGGL(gather_s2_kernel<1>, grid_for(total), dim3(TPB), 0, (hipStream_t)stream, in, out, total, channels, height,
+                       width, OH, OW);
+  } else {
+    hipLaunchKernelGGL(gather_s2_kernel<3>, grid_for(total), dim3(TPB), 0, (hipStream_t)stream, in, out, total, channels, height,
+                       width, OH, OW);
+  }
+  return check_launch("deva_gather_s2");
+}
+
 extern "C" int deva_maxpool3x3s2(const float* in, float* out, int64_t planes, int height, int width,
                                  int relu_after, void* stream) {
   DEVA_REQUIRE(in && out && planes > 0 && height > 0 && width > 0, "deva_maxpool3x3s2: bad args");
@@ -529,6 +618,21 @@ extern "C" int deva_area_downsample(const float* in, float* out, int64_t planes,
   DEVA_REQUIRE(height % factor == 0 && width % factor == 0, "deva_area_downsample: size %dx%d not divisible by %d",
                height, width, factor);
   const int64_t total = planes * (height / factor) * (width / factor);
+  const bool aligned = (((uintptr_t)in | (uintptr_t)out) & 15) == 0 && width % 4 == 0;
+  const int ow = width / factor;
+#define DEVA_AREA_VEC(F, OPT)                                                                                                \
+  do {                                                                                                                        \
+    hipLaunchKernelGGL((area_downsample_vec_kernel<F, OPT>), grid_for(total / OPT), dim3(TPB), 0, (hipStream_t)stream, in, out, \
+                       total / OPT, height, width);                                                                           \
+    return check_launch("deva_area_downsample");                                                                              \
+  } while (0)
+  if (aligned && (factor == 2 || factor == 4)) {
+    if (factor == 4 && ow % 4 == 0) DEVA_AREA_VEC(4, 4);
+    if (factor == 4 && ow % 2 == 0) DEVA_AREA_VEC(4, 2);
+    if (factor == 2 && ow % 4 == 0) DEVA_AREA_VEC(2, 4);
+    if (factor == 2 && ow % 2 == 0) DEVA_AREA_VEC(2, 2);
+  }
+#undef DEVA_AREA_VEC
   hipLaunchKernelGGL(area_downsample_kernel, grid_for(total), dim3(TPB), 0, (hipStream_t)stream, in, out, total,
                      height, width, factor);
   return check_launch("deva_area_downsample");

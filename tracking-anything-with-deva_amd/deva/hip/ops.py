@@ -13,7 +13,7 @@ import torch
 from . import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQUARE_PLUS_ONE, KLAYOUT_CHUNK32, KLAYOUT_Q4, KLAYOUT_TAP_MAJOR,
                ConvDesc, DevaHipError, check, lib)
 
-__all__ = ['PackedConv', 'pack_conv', 'conv2d', 'split_fallbacks', 'PackedStem', 'pack_stem', 'stem7x7', 'pad2d', 'usage_init', 'maxpool3x3s2', 'upsample2x_add', 'area_downsample',
+__all__ = ['PackedConv', 'pack_conv', 'conv2d', 'split_fallbacks', 'PackedStem', 'pack_stem', 'stem7x7', 'pad2d', 'usage_init', 'gather_s2', 'maxpool3x3s2', 'upsample2x_add', 'area_downsample',
            'aggregate', 'softmax_channels', 'upsample4x_softmax', 'cbam', 'gru_update',
            'affinity_topk', 'BankPrep', 'affinity_dense', 'affinity_candidates', 'affinity_merge', 'usage_update', 'readout_sparse', 'bank_append', 'bank_gather_rows',
            'bank_export', 'rank', 'rank_select', 'evict_select', 'similarity_dense', 'softmax_columns',
@@ -429,6 +429,17 @@ def pad2d(x: torch.Tensor, pad: Tuple[int, int, int, int]) -> torch.Tensor:
 def usage_init(use: torch.Tensor, life: torch.Tensor) -> None:
     """use[:] = 0, life[:] = 1e-7 (the counters of freshly appended tokens), one launch"""
     check(lib().deva_usage_init(_p(use), _p(life), use.numel(), _stream()), 'deva_usage_init')
+
+
+def gather_s2(x: torch.Tensor, kernel: int) -> torch.Tensor:
+    """[B,C,H,W] -> [B,k*k*C,OH,OW]: the taps of a k x k stride-2 convolution (k = 1 pad 0, k = 3 pad 1) as channels,
+    tap-major (deva_gather_s2); a 1x1 convolution with weights [cout][t*C + c] over it is that convolution"""
+    b, c, h, w = x.shape
+    pad = kernel // 2
+    oh, ow = (h + 2 * pad - kernel) // 2 + 1, (w + 2 * pad - kernel) // 2 + 1
+    out = _alloc((b, kernel * kernel * c, oh, ow), x.device)
+    check(lib().deva_gather_s2(_p(x), _p(out), b, c, h, w, kernel, _stream()), 'deva_gather_s2')
+    return out
 
 
 def maxpool3x3s2(x: torch.Tensor, relu_after: bool = False) -> torch.Tensor:

@@ -131,6 +131,7 @@ class CompiledGraph:
         if split_key_encoder and not split:
             raise ValueError('f16_split_key_encoder extends f16_split: set both')
         self.convs: Dict[str, PackedConv] = {}
+        self.s2: Dict[str, PackedConv] = {}  # stride-2 convolutions of the split scopes as 1x1 convolutions over their taps
         self.vecs: Dict[str, torch.Tensor] = {}
         for name in sd:
             if not name.endswith('.weight') or sd[name].dim() != 4:
@@ -176,6 +177,23 @@ class CompiledGraph:
 
     def _split_pack(self, base: str, cx: int) -> Tuple[PackedConv, PackedConv]:
         """(image part without bias, per-object part with the bias) of convolution `base`, BatchNorm folded"""
+        w, b = self._folded(base)
+        return (ops.pack_conv(w[:, :cx].contiguous(), None, None, self.device, amp=self._amp_of(base), split=self._split_of(base)),
+                ops.pack_conv(w[:, cx:].contiguous(), b, None, self.device, amp=self._amp_of(base), split=self._split_of(base)))
+
+    def _conv(self, base: str, *inputs, **kw):
+        """convolution `base` of the value encoder / mask decoder: fp16 operands under --amp, the hi/lo split under
+        --f16_split, where eligible"""
+        if kw.get('stride', 1) == 2 and self._split_of(base) and len(inputs) == 1 and self.convs[base].kh in (1, 3):
+            # the split kernels take stride 1 only, and the scalar-gather fp32 kind a stride-2 layer would run instead
+            # reaches ~50 TFLOP/s: the taps become channels (ops.gather_s2) and the layer a 1x1 convolution over them
+            pc = self._s2_pack(base)
+            kw = {k: v for k, v in kw.items() if k not in ('stride', 'pad')}
+            return ops.conv2d(pc, ops.gather_s2(inputs[0], self.convs[base].kh), split=True, **kw)
+        return ops.conv2d(self.convs[base], *inputs, amp=self._amp_of(base), split=self._split_of(base), **kw)
+
+    def _folded(self, base: str):
+        """(weight [cout][cin][kh][kw], bias | None) of convolution `base` with its BatchNorm folded"""
         w = self.sd[base + '.weight'].detach().float()
         b = self.sd.get(base + '.bias')
         b = None if b is None else b.detach().float()
@@ -186,13 +204,17 @@ class CompiledGraph:
             shift = beta - mean * scale
             w = w * scale.view(-1, 1, 1, 1)
             b = shift if b is None else b * scale + shift
-        return (ops.pack_conv(w[:, :cx].contiguous(), None, None, self.device, amp=self._amp_of(base), split=self._split_of(base)),
-                ops.pack_conv(w[:, cx:].contiguous(), b, None, self.device, amp=self._amp_of(base), split=self._split_of(base)))
+        return w, b
 
-    def _conv(self, base: str, *inputs, **kw):
-        """convolution `base` of the value encoder / mask decoder: fp16 operands under --amp, the hi/lo split under
-        --f16_split, where eligible"""
-        return ops.conv2d(self.convs[base], *inputs, amp=self._amp_of(base), split=self._split_of(base), **kw)
+    def _s2_pack(self, base: str) -> PackedConv:
+        """the weights of stride-2 convolution `base` as a 1x1 convolution over its taps (channel index t*C + c)"""
+        pc = self.s2.get(base)
+        if pc is None:
+            w, b = self._folded(base)
+            cout, cin, kh, kw_ = w.shape
+            w1 = w.permute(0, 2, 3, 1).reshape(cout, kh * kw_ * cin, 1, 1).contiguous()
+            pc = self.s2[base] = ops.pack_conv(w1, b, None, self.device, split=True)
+        return pc
 
     def _conv_shared_x(self, base: str, x, g, **kw):
         """conv over the virtual cat(x broadcast, g): one launch for a single object, otherwise the image
