@@ -24,7 +24,7 @@ Extra objects on the JSON line:
                 `sustained_mfma_probe` = what a register-only fp32 MFMA loop reaches on this box, timed right
                 here (the chip clocks to its power budget: ~0.78 of the data sheet).  `traffic` =
                 HBM bytes per frame of those kernels from the committed rocprofv3 --pmc passes over
-                this same command (profiles/pmc_r05/conv_traffic.json, tools/pmc_bench.sh; bench.py cannot collect PMC
+                this same command (profiles/pmc_r06/conv_traffic.json, tools/pmc_bench.sh; bench.py cannot collect PMC
                 counters itself), next to the algorithmic bytes per frame computed here.
   affinity      the north-star read (similarity -> exact top-k -> softmax -> usage): event-timed at the
                 BASELINE shape (N=10 000 bank, 1080p queries) through deva_affinity_read (fp16 MFMA
@@ -201,11 +201,28 @@ class ConvTimer:
             self.records.append((flops, s, e, sig, nbytes, f16))
             return rc
 
+        def timed_stem(in0, bs0, c0, in1, bs1, c1, batch, height, width, *rest):
+            # deva_stem7x7 (--f16_split*: the 7x7 stride-2 stems on the f16 pipes): counted with the split kernels
+            cin = c0 + c1
+            oh, ow = height // 2, width // 2
+            flops = 2.0 * 64 * cin * 49 * batch * oh * ow
+            nbytes = 4.0 * (c0 * (batch if bs0 else 1) * height * width + c1 * batch * height * width + cin * 49 * 64
+                            + 64 * oh * ow * batch)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            rc = self.real_stem(in0, bs0, c0, in1, bs1, c1, batch, height, width, *rest)
+            e.record()
+            self.records.append((flops, s, e, (cin, 64, 7, 2, batch, oh, ow), nbytes, 2))
+            return rc
+
         self.handle.deva_conv2d = timed
+        self.real_stem = self.handle.deva_stem7x7
+        self.handle.deva_stem7x7 = timed_stem
         return self
 
     def __exit__(self, *a):
         self.handle.deva_conv2d = self.real
+        self.handle.deva_stem7x7 = self.real_stem
         torch.cuda.synchronize()
 
     def summary(self):
@@ -249,7 +266,7 @@ def conv_roofline_report(ct, frames):
     against the fp32 matrix peak"""
     sp = ct.split_by_precision()
     out = {'method': 'HIP events around every deva_conv2d launch of an un-synchronised replay (bench.py:ConvTimer)',
-           # every operand of every deva_conv2d launch once (the stems of --f16_split* run deva_stem7x7: not in this sum)
+           # every operand of every deva_conv2d / deva_stem7x7 launch once
            'algorithmic_bytes_per_frame': sum(r[4] for r in ct.records) / frames}
     for name, (fl, ms, n) in sp.items():
         if n == 0:
@@ -357,7 +374,7 @@ def affinity_microbench(device, n=10000, hw=8160, k=30, iters=20):
 
 def _affinity_counter_ratio(b_alg):
     """HBM counter traffic of one read (committed PMC pass of this round, or the last one) over the algorithmic bytes"""
-    for d in ('pmc_r05', 'pmc_r04', 'pmc_r03'):
+    for d in ('pmc_r06', 'pmc_r05', 'pmc_r04', 'pmc_r03'):
         path = os.path.join(ROOT, 'profiles', d, 'affinity_read.json')
         if os.path.exists(path):
             try:
@@ -953,6 +970,11 @@ def extra_lines(net, device, cfg, args):
              '50 000 tokens',
              'tests/test_gpu_g_fullsize.py::test_4k_free_running_50k_bank_against_oracle + test_4k_lockstep + '
              'test_affinity_at_bench_shapes (every query)', 'bank_tokens_at_end'),
+        line('propagation FPS @4K, --f16_split --f16_split_key_encoder (1 object, 50k-token long-term bank), one GPU',
+             lambda: run_long4k(split_all_net(), device, steps=20, warmup=5, seed=11, shard=None, dist=None)[:2], 20, 5,
+             'BASELINE configs[4] on ONE GPU with the fp32-accurate split kernels in every scope',
+             'tests/test_gpu_g_fullsize.py::test_4k_lockstep [f16_split+key_encoder] (teacher-forced, fp32 bounds; the free-running '
+             '4K gate runs the fp32 build) + the gates of the other key_encoder lines', 'bank_tokens_at_end', dtype=SPLIT_ALL_DTYPE),
     ]
 
 
@@ -1186,7 +1208,7 @@ def main():
             torch.cuda.synchronize()
         # HBM traffic of these kernels per frame, from the committed rocprofv3 --pmc passes over this same
         # command (tools/pmc_bench.sh; FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes)
-        for pmc_dir in ('pmc_r05', 'pmc_r04', 'pmc_r03'):
+        for pmc_dir in ('pmc_r06', 'pmc_r05', 'pmc_r04', 'pmc_r03'):
             pmc = os.path.join(ROOT, 'profiles', pmc_dir, 'conv_traffic.json')
             if not os.path.exists(pmc):
                 continue
@@ -1245,7 +1267,7 @@ def main():
                      ('fps_480p_5obj_f16_split_key_encoder', '@480p, --f16_split --f16_split_key_encoder'),
                      ('fps_1080p_1obj_10k_bank_f16_split_key_encoder', '@1080p, --f16_split --f16_split_key_encoder (1 object'),
                      ('fps_1080p_8seg_f16_split_key_encoder', '@1080p, --f16_split --f16_split_key_encoder (8-segment'),
-                     ('fps_4k_1obj_50k_bank', '@4K'))
+                     ('fps_4k_1obj_50k_bank', '@4K (1 object'), ('fps_4k_1obj_50k_bank_f16_split_key_encoder', '@4K, --f16_split'))
             for key, frag in short:
                 for e in result['also']:
                     if frag in e['metric'] and e.get('value') is not None:

@@ -319,8 +319,11 @@ extern "C" int deva_stem7x7(const float* in0, int64_t in0_batch_stride, int c0, 
   const int64_t total = (int64_t)a.tiles_x * a.tiles_y * batch;
   DEVA_REQUIRE(total < (1ll << 30), "deva_stem7x7: too many tiles");
   a.total_tiles = (int)total;
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  static const int cus = [] {  // (one device type per process: asked once)
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
   // one workgroup per CU (112 KB of LDS): persistent, the weights are staged once and the patch loads of the next tile
   // overlap the MFMAs of the current one
   const dim3 grid((unsigned)(total < cus ? total : cus));
