@@ -202,26 +202,32 @@ __global__ __launch_bounds__(STEM_THREADS, 1) void stem7x7_kernel(const StemArgs
       if (tid == 0 && p.flag) atomicOr(p.flag, 1);
       const int ow = c0 + lane;
       if (oh < p.OH && ow < p.OW) {
-        float out[STEM_COUT];
+#pragma nounroll
+        for (int m0 = 0; m0 < STEM_COUT; m0 += 16) {  // 16 channels at a time: the path is rare, its registers are not
+          float out[16];
 #pragma unroll
-        for (int m = 0; m < STEM_COUT; ++m) out[m] = p.bias ? p.bias[m] : 0.0f;
-        for (int c = 0; c < C; ++c) {
-          const float* src = c < p.c0 ? p.in0 + (int64_t)b * p.bs0 + (int64_t)c * p.H * p.W
-                                      : p.in1 + (int64_t)b * p.bs1 + (int64_t)(c - p.c0) * p.H * p.W;
-          for (int dy = 0; dy < 7; ++dy) {
-            const int ih = 2 * oh + dy - 3;
-            for (int dx = 0; dx < 7; ++dx) {
-              const int iw = 2 * ow + dx - 3;
-              const float x = ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? src[(int64_t)ih * p.W + iw] : 0.0f;
-              const float* wk = p.w32 + (int64_t)((c * 7 + dy) * 7 + dx) * STEM_COUT;
+          for (int m = 0; m < 16; ++m) out[m] = p.bias ? p.bias[m0 + m] : 0.0f;
+#pragma nounroll
+          for (int c = 0; c < C; ++c) {
+            const float* src = c < p.c0 ? p.in0 + (int64_t)b * p.bs0 + (int64_t)c * p.H * p.W
+                                        : p.in1 + (int64_t)b * p.bs1 + (int64_t)(c - p.c0) * p.H * p.W;
+#pragma nounroll
+            for (int dy = 0; dy < 7; ++dy) {
+              const int ih = 2 * oh + dy - 3;
+#pragma nounroll
+              for (int dx = 0; dx < 7; ++dx) {
+                const int iw = 2 * ow + dx - 3;
+                const float x = ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? src[(int64_t)ih * p.W + iw] : 0.0f;
+                const float* wk = p.w32 + (int64_t)((c * 7 + dy) * 7 + dx) * STEM_COUT + m0;
 #pragma unroll
-              for (int m = 0; m < STEM_COUT; ++m) out[m] = __builtin_fmaf(x, wk[m], out[m]);
+                for (int m = 0; m < 16; ++m) out[m] = __builtin_fmaf(x, wk[m], out[m]);
+              }
             }
           }
-        }
 #pragma unroll
-        for (int m = 0; m < STEM_COUT; ++m)
-          p.out[(((int64_t)b * STEM_COUT + m) * p.OH + oh) * p.OW + ow] = p.relu ? fmaxf(out[m], 0.0f) : out[m];
+          for (int m = 0; m < 16; ++m)
+            p.out[(((int64_t)b * STEM_COUT + m0 + m) * p.OH + oh) * p.OW + ow] = p.relu ? fmaxf(out[m], 0.0f) : out[m];
+        }
       }
       // (the prefetched patch is loaded again here so that its registers are free during the 64 accumulators above)
       if (tile + (int)gridDim.x < p.total_tiles) load_patch(tile + gridDim.x);
