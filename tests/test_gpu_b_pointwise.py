@@ -42,7 +42,7 @@ def test_area_downsample(shape, f):
 
 
 @pytest.mark.parametrize('shape,f', [((3, 16, 272, 480), 4), ((2, 8, 120, 216), 4), ((2, 8, 136, 240), 2), ((3, 4, 60, 108), 2),
-                                     ((1, 3, 12, 20), 4), ((2, 2, 8, 12), 2)])
+                                     ((1, 3, 12, 20), 4), ((2, 2, 8, 12), 2), ((5, 480, 864), 16), ((2, 3, 32, 48), 16)])
 def test_area_downsample_vector_path_is_bit_identical_to_the_scalar_kernel(shape, f):
     """factors 2 / 4 on aligned rows run 16-byte loads (2 or 4 outputs per thread); same sums in the same order as the
     one-output-per-thread kernel, which an unaligned view of the same data still takes"""
@@ -110,7 +110,7 @@ def test_upsample4x_softmax(c, h, w):
     _check('up4x_prob_only', prob2, wprob, 2e-6)
 
 
-@pytest.mark.parametrize('b,c,h,w', [(2, 512, 6, 8), (1, 512, 30, 54), (3, 64, 5, 7)])
+@pytest.mark.parametrize('b,c,h,w', [(2, 512, 6, 8), (1, 512, 30, 54), (3, 64, 5, 7), (5, 512, 30, 54), (2, 40, 9, 12)])
 def test_cbam(b, c, h, w):
     g = torch.Generator().manual_seed(6)
     x = rand(g, b, c, h, w)

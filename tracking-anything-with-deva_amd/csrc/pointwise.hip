@@ -222,11 +222,11 @@ __global__ void area_downsample_kernel(const float* __restrict__ in, float* __re
   }
 }
 
-// factors 2 and 4 on 16-byte aligned rows: the same sums in the same order from 16-byte loads (a vector-memory
+// factors 2, 4 and 16 on 16-byte aligned rows: the same sums in the same order from 16-byte loads (a vector-memory
 // instruction costs the same whatever its width: the scalar form issues f*f of them per output, this one f per OPT outputs)
 typedef float pw_f32x4 __attribute__((ext_vector_type(4)));
 typedef float pw_f32x2 __attribute__((ext_vector_type(2)));
-template <int F, int OPT>  // OPT outputs per thread (2 or 4) from OPT * F / 4 16-byte loads per input row
+template <int F, int OPT>  // OPT outputs per thread (1, 2 or 4) from OPT * F / 4 16-byte loads per input row
 __global__ void area_downsample_vec_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t total_groups,
                                            int H, int W) {
   constexpr int LOADS = OPT * F / 4;
@@ -257,8 +257,10 @@ __global__ void area_downsample_vec_kernel(const float* __restrict__ in, float* 
     float* dst = out + (plane * OH + oy) * (int64_t)OW + gx * OPT;
     if constexpr (OPT == 4) {
       *reinterpret_cast<pw_f32x4*>(dst) = pw_f32x4{r[0], r[1], r[2], r[3]};
-    } else {
+    } else if constexpr (OPT == 2) {
       *reinterpret_cast<pw_f32x2*>(dst) = pw_f32x2{r[0], r[1]};
+    } else {
+      dst[0] = r[0];
     }
   }
 }
@@ -372,11 +374,18 @@ __global__ void cbam_mlp_kernel(const float* __restrict__ avg, const float* __re
     vin[C + i] = mx[(int64_t)b * C + i];
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < 2 * hidden; t += blockDim.x) {
-    const int which = t / hidden, j = t % hidden;
-    float s = 0.0f;
-    for (int c = 0; c < C; ++c) s += w1[(int64_t)j * C + c] * vin[which * C + c];
-    hid[t] = fmaxf(s + b1[j], 0.0f);
+  // first layer: one WAVE per hidden unit and input vector -- its 64 lanes read the weight row coalesced and meet in a
+  // shuffle tree (round 5: one thread per unit walked its row alone, 512 strided loads: 21 us for 64 dot products)
+  {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int t = wave; t < 2 * hidden; t += nw) {
+      const int which = t / hidden, j = t % hidden;
+      float s = 0.0f;
+      for (int c = lane; c < C; c += 64) s += w1[(int64_t)j * C + c] * vin[which * C + c];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+      if (lane == 0) hid[t] = fmaxf(s + b1[j], 0.0f);
+    }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -391,13 +400,15 @@ __global__ void cbam_mlp_kernel(const float* __restrict__ avg, const float* __re
   }
 }
 
-// block = 64 pixels x 4 channel groups: each wave reduces a quarter of the channels for 64 consecutive
-// pixels (coalesced 256-B reads), the four partial max / sums meet in LDS
-__global__ __launch_bounds__(256) void cbam_channel_pool_kernel(const float* __restrict__ x,
-                                                                const float* __restrict__ scale,
-                                                                float* __restrict__ pooled, int64_t total, int C,
-                                                                int hw) {
-  __shared__ float s_max[4][64], s_sum[4][64];
+// block = 64 pixels x POOL_CG channel groups: each wave reduces its share of the channels for 64 consecutive pixels
+// (coalesced 256-B reads, POOL_U loads in flight), the partial max / sums meet in LDS in group order.  (Round 5 ran 4 groups
+// with one load in flight: 36 us for 16.6 MB at 480p / 5 objects.)
+constexpr int POOL_CG = 16, POOL_U = 8;
+__global__ __launch_bounds__(64 * POOL_CG) void cbam_channel_pool_kernel(const float* __restrict__ x,
+                                                                         const float* __restrict__ scale,
+                                                                         float* __restrict__ pooled, int64_t total, int C,
+                                                                         int hw) {
+  __shared__ float s_max[POOL_CG][64], s_sum[POOL_CG][64];
   const int px = threadIdx.x & 63, cg = threadIdx.x >> 6;
   const int64_t i = blockIdx.x * 64ll + px;
   const bool ok = i < total;
@@ -406,20 +417,38 @@ __global__ __launch_bounds__(256) void cbam_channel_pool_kernel(const float* __r
   const int64_t b = ii / hw;
   const float* src = x + b * C * hw + p;
   const float* sc = scale + b * C;
-  const int per = (C + 3) / 4;
+  const int per = (C + POOL_CG - 1) / POOL_CG;
   const int c_lo = cg * per, c_hi = min(C, c_lo + per);
   float m = -INFINITY, s = 0.0f;
-  for (int c = c_lo; c < c_hi; ++c) {
-    const float v = src[(int64_t)c * hw] * sc[c];
-    m = fmaxf(m, v);
-    s += v;
+  int c = c_lo;
+  for (; c + POOL_U <= c_hi; c += POOL_U) {
+    float v[POOL_U];
+#pragma unroll
+    for (int u = 0; u < POOL_U; ++u) v[u] = src[(int64_t)(c + u) * hw];
+#pragma unroll
+    for (int u = 0; u < POOL_U; ++u) {
+      const float w = v[u] * sc[c + u];
+      m = fmaxf(m, w);
+      s += w;
+    }
+  }
+  for (; c < c_hi; ++c) {
+    const float w = src[(int64_t)c * hw] * sc[c];
+    m = fmaxf(m, w);
+    s += w;
   }
   s_max[cg][px] = m;
   s_sum[cg][px] = s;
   __syncthreads();
   if (cg == 0 && ok) {
-    pooled[(b * 2 + 0) * hw + p] = fmaxf(fmaxf(s_max[0][px], s_max[1][px]), fmaxf(s_max[2][px], s_max[3][px]));
-    pooled[(b * 2 + 1) * hw + p] = (((s_sum[0][px] + s_sum[1][px]) + s_sum[2][px]) + s_sum[3][px]) / (float)C;
+    float mm = s_max[0][px], ss = s_sum[0][px];
+#pragma unroll
+    for (int g = 1; g < POOL_CG; ++g) {
+      mm = fmaxf(mm, s_max[g][px]);
+      ss += s_sum[g][px];
+    }
+    pooled[(b * 2 + 0) * hw + p] = mm;
+    pooled[(b * 2 + 1) * hw + p] = ss / (float)C;
   }
 }
 
@@ -433,6 +462,24 @@ __global__ void cbam_apply_kernel(const float* __restrict__ x, const float* __re
     const float v = x[i];
     const float r = (v * scale[bc]) * sigmoidf_(gate[b * hw + p]);
     out[i] = v + r;
+  }
+}
+
+// hw % 4 == 0, 16-byte aligned tensors: four pixels per thread (the same arithmetic per element)
+__global__ void cbam_apply_vec_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                      const float* __restrict__ gate, float* __restrict__ out, int64_t total4, int C, int hw) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i * 4;
+    const int p = (int)(e % hw);
+    const int64_t bc = e / hw;
+    const int64_t b = bc / C;
+    const pw_f32x4 v = *reinterpret_cast<const pw_f32x4*>(x + e);
+    const pw_f32x4 g = *reinterpret_cast<const pw_f32x4*>(gate + b * hw + p);
+    const float sc = scale[bc];
+    pw_f32x4 r;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) r[u] = v[u] + (v[u] * sc) * sigmoidf_(g[u]);
+    *reinterpret_cast<pw_f32x4*>(out + e) = r;
   }
 }
 
@@ -626,6 +673,7 @@ extern "C" int deva_area_downsample(const float* in, float* out, int64_t planes,
                        total / OPT, height, width);                                                                           \
     return check_launch("deva_area_downsample");                                                                              \
   } while (0)
+  if (aligned && factor == 16) DEVA_AREA_VEC(16, 1);  // (the last mask at 1/16: 64 16-byte loads per output instead of 256 scalar ones)
   if (aligned && (factor == 2 || factor == 4)) {
     if (factor == 4 && ow % 4 == 0) DEVA_AREA_VEC(4, 4);
     if (factor == 4 && ow % 2 == 0) DEVA_AREA_VEC(4, 2);
@@ -691,7 +739,7 @@ extern "C" int deva_cbam_channel_pool(const float* x, const float* scale, float*
                                       int hw, void* stream) {
   DEVA_REQUIRE(x && scale && pooled && batch > 0 && channels > 0 && hw > 0, "deva_cbam_channel_pool: bad args");
   const int64_t total = (int64_t)batch * hw;
-  hipLaunchKernelGGL(cbam_channel_pool_kernel, dim3((unsigned)ceil_div(total, 64)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(cbam_channel_pool_kernel, dim3((unsigned)ceil_div(total, 64)), dim3(64 * POOL_CG), 0, (hipStream_t)stream,
                      x, scale, pooled, total, channels, hw);
   return check_launch("deva_cbam_channel_pool");
 }
@@ -700,6 +748,11 @@ extern "C" int deva_cbam_apply(const float* x, const float* scale, const float* 
                                int channels, int hw, void* stream) {
   DEVA_REQUIRE(x && scale && gate && out && batch > 0 && channels > 0 && hw > 0, "deva_cbam_apply: bad args");
   const int64_t total = (int64_t)batch * channels * hw;
+  if (hw % 4 == 0 && (((uintptr_t)x | (uintptr_t)gate | (uintptr_t)out) & 15) == 0) {
+    hipLaunchKernelGGL(cbam_apply_vec_kernel, grid_for(total / 4), dim3(TPB), 0, (hipStream_t)stream, x, scale, gate, out,
+                       total / 4, channels, hw);
+    return check_launch("deva_cbam_apply");
+  }
   hipLaunchKernelGGL(cbam_apply_kernel, grid_for(total), dim3(TPB), 0, (hipStream_t)stream, x, scale, gate, out,
                      total, channels, hw);
   return check_launch("deva_cbam_apply");
