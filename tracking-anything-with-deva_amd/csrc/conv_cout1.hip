@@ -200,9 +200,133 @@ __global__ __launch_bounds__(256) void conv3x3_cout1_rows_kernel(const Cout1Args
   }
 }
 
+// The same on TWO output rows per thread (OH even): rows oh-1 .. oh+2 are read once for the outputs of rows oh and oh+1
+// -- 8 loads per channel for two rows instead of 12, and every input row passes the L2 twice instead of three times (the
+// kernel moves 3 TB/s of algorithmic bytes; what binds it is the L2 traffic behind them).  Per output the channel order and
+// the tap order are those of the one-row kernel: bit-identical results.
+__global__ __launch_bounds__(256) void conv3x3_cout1_rows2_kernel(const Cout1Args p) {
+  __shared__ f32x4 red[4][2][64];
+  const int lane = threadIdx.x & 63;
+  const int cg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int owq = p.OW >> 2, oh2n = p.OH >> 1;
+  const int strips = (p.n_total / p.OHW) * oh2n * owq;  // (batch, row pair, pixel quad)
+  int blk;
+  {
+    const int nb = gridDim.x, bi = blockIdx.x;
+    const int q = nb >> 3, r = nb & 7, xcd = bi & 7;
+    blk = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bi >> 3);
+  }
+  const int sidx = blk * 64 + lane;
+  const bool s_ok = sidx < strips;
+  const int si = s_ok ? sidx : 0;
+  const int b = si / (oh2n * owq);
+  const int rem = si - b * (oh2n * owq);
+  const int oh = 2 * (rem / owq), ow = 4 * (rem % owq);
+  const int pix = oh * p.OW + ow;
+  const float* src0 = p.in0 + (int64_t)b * p.bs0 + pix;
+  const float* src1 = (p.in1 ? p.in1 + (int64_t)b * p.bs1 : p.in0) + pix;
+  const bool left = ow > 0, right = ow + 4 < p.W;
+  const bool up = oh > 0, down = oh + 2 < p.H;
+  f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+
+  extern __shared__ float wsm[];
+  for (int i = threadIdx.x; i < p.ctot * 9; i += 256) {
+    const int c = i / 9, t = i - c * 9;
+    const int k = (p.k_layout == DEVA_KLAYOUT_CHUNK32) ? (((c >> 5) * 9 + t) * 32 + (c & 31)) : (t * p.ctot + c);
+    wsm[i] = p.w[(int64_t)k * p.cout_pad];
+  }
+  __syncthreads();
+  const float u = up ? 1.0f : 0.0f, d = down ? 1.0f : 0.0f;
+  const int o_up = up ? -p.W : 0, o_dn = down ? 2 * p.W : p.W;  // (clamped reads of rows that do not exist: their taps are zeroed)
+
+  constexpr int U = 3;  // channels in flight per thread: 24 independent 16-B loads
+  for (int c0 = cg; c0 < p.ctot; c0 += 4 * U) {
+    f32x4 a[U][4], e[U][4];
+    bool live[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const int c = c0 + 4 * q;
+      live[q] = c < p.ctot;
+      const int cc = live[q] ? c : cg;
+      const float* sp = (cc < p.c0) ? (src0 + (int64_t)cc * p.HW) : (src1 + (int64_t)(cc - p.c0) * p.HW);
+      const int offs[4] = {o_up, 0, p.W, o_dn};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        a[q][r] = *reinterpret_cast<const f32x4_u*>(sp + offs[r] - 1);  // ow-1 .. ow+2
+        e[q][r] = *reinterpret_cast<const f32x4_u*>(sp + offs[r] + 3);  // ow+3 .. ow+6 (the last two are not used)
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const int c = live[q] ? c0 + 4 * q : cg;
+      const float lv = live[q] ? 1.0f : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        f32x4 x = a[q][r], y = e[q][r];
+        if (p.relu_in) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) x[i] = fmaxf(x[i], 0.0f);
+          y[0] = fmaxf(y[0], 0.0f);
+          y[1] = fmaxf(y[1], 0.0f);
+        }
+        const float x0 = left ? x[0] : 0.0f, x5 = right ? y[1] : 0.0f;
+        if (r < 3) {  // tap row r of output row oh (its rows: oh-1, oh, oh+1)
+          const float rs = (r == 0 ? u : 1.0f) * lv;
+          const float w0 = wsm[c * 9 + 3 * r] * rs, w1 = wsm[c * 9 + 3 * r + 1] * rs, w2 = wsm[c * 9 + 3 * r + 2] * rs;
+          acc0[0] += w0 * x0 + w1 * x[1] + w2 * x[2];
+          acc0[1] += w0 * x[1] + w1 * x[2] + w2 * x[3];
+          acc0[2] += w0 * x[2] + w1 * x[3] + w2 * y[0];
+          acc0[3] += w0 * x[3] + w1 * y[0] + w2 * x5;
+        }
+        if (r > 0) {  // tap row r-1 of output row oh+1 (its rows: oh, oh+1, oh+2)
+          const int t = r - 1;
+          const float rs = (t == 2 ? d : 1.0f) * lv;
+          const float w0 = wsm[c * 9 + 3 * t] * rs, w1 = wsm[c * 9 + 3 * t + 1] * rs, w2 = wsm[c * 9 + 3 * t + 2] * rs;
+          acc1[0] += w0 * x0 + w1 * x[1] + w2 * x[2];
+          acc1[1] += w0 * x[1] + w1 * x[2] + w2 * x[3];
+          acc1[2] += w0 * x[2] + w1 * x[3] + w2 * y[0];
+          acc1[3] += w0 * x[3] + w1 * y[0] + w2 * x5;
+        }
+      }
+    }
+  }
+  red[cg][0][lane] = acc0;
+  red[cg][1][lane] = acc1;
+  __syncthreads();
+  if (cg == 0 && s_ok) {
+#pragma unroll
+    for (int row = 0; row < 2; ++row) {
+      f32x4 v = ((red[0][row][lane] + red[1][row][lane]) + red[2][row][lane]) + red[3][row][lane];
+      const int px = pix + row * p.OW;
+      const f32x4 r = p.res ? *reinterpret_cast<const f32x4*>(p.res + (int64_t)b * p.res_bs + px) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float x = v[i];
+        if (p.bias) x += p.bias[0];
+        if (p.res) x += r[i];
+        if (p.act == DEVA_ACT_RELU) {
+          x = fmaxf(x, 0.0f);
+        } else if (p.act == DEVA_ACT_SIGMOID) {
+          x = sigmoidf_(x);
+        } else if (p.act == DEVA_ACT_SQUARE_PLUS_ONE) {
+          x = x * x + 1.0f;
+        }
+        v[i] = x;
+      }
+      *reinterpret_cast<f32x4*>(p.out + (int64_t)b * p.OHW + px) = v;
+    }
+  }
+}
+
 }  // namespace
 
 int launch_conv3x3_cout1_rows(const Cout1Args& a, hipStream_t st) {
+  if (a.OH % 2 == 0) {
+    const int strips = (a.n_total / a.OHW) * (a.OH / 2) * (a.OW / 4);
+    hipLaunchKernelGGL(conv3x3_cout1_rows2_kernel, dim3((unsigned)ceil_div(strips, 64)), dim3(256),
+                       sizeof(float) * 9 * (size_t)a.ctot, st, a);
+    return check_launch("deva_conv2d(cout=1, 3x3 rows)");
+  }
   const int strips = a.n_total / 4;
   hipLaunchKernelGGL(conv3x3_cout1_rows_kernel, dim3((unsigned)ceil_div(strips, 64)), dim3(256),
                      sizeof(float) * 9 * (size_t)a.ctot, st, a);

@@ -557,7 +557,12 @@ int launch_conv_f16(const ConvArgs& a, hipStream_t st) {
     // stream), so fewer LDS bytes per MFMA buy nothing.
     // (few tiles but a long K loop -- the 512 -> 512 3x3 image part of the fusers at 30x54: 52 tiles, 144 steps -- also takes
     // the 128x128 tile: its split-K fills the chip, 45 against 72 us on 64x64 tiles)
-    if (a.cout >= 128 && (blocks128 >= 64 || (blocks128 >= 32 && a.K >= 128 * 32))) return launch_tile_f16<128, 128, 2, 4, 4, 32, 2>(a, kind, st);
+    // ... unless the 128x128 tiles would leave a quarter or more of the CUs without a workgroup where 64x64 tiles give every
+    // CU one (the batch-1 layers of the key encoder at 1/16 of a 1080p frame: 128 tiles of 128x128)
+    const int64_t blocks64 = ceil_div(a.cout, 64) * ceil_div(a.n_total, 64);
+    const bool half_empty = blocks128 >= 64 && blocks128 < 192 && blocks64 >= 256;
+    if (a.cout >= 128 && !half_empty && (blocks128 >= 64 || (blocks128 >= 32 && a.K >= 128 * 32)))
+      return launch_tile_f16<128, 128, 2, 4, 4, 32, 2>(a, kind, st);
     return launch_tile_f16<64, 64, 2, 2, 2, 32, 2>(a, kind, st);
   }
   if (a.cout >= 128 && blocks128 >= 64) return launch_tile_f16<128, 128, 2, 4, 4, 64, 1>(a, kind, st);
