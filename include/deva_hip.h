@@ -191,6 +191,12 @@ int deva_maxpool3x3s2(const float* in, float* out, int64_t planes, int height, i
  * (modules.py:88-92): out = skip[c] + up(in[b][c]); skip is [C][2h][2w] or NULL. */
 int deva_upsample2x_add(const float* in, const float* skip, float* out, int batch, int channels,
                         int height, int width, void* stream);
+/* The same, and area_downsample(in, 2) of the INPUT from the same pass: ds2 [batch][channels][height/2][width/2] (height,
+ * width even).  The decoder reads p8 once for the x2 up-sampling towards p4 (big_modules.py:164-201) and once more for the
+ * 1/16 copy the sensory update takes (modules.py:121-151: downsample_groups(g[1], ratio=1/2)); this entry serves both.
+ * ds2 is bit-identical to deva_area_downsample(in, ..., 2). */
+int deva_upsample2x_add_ds2(const float* in, const float* skip, float* out, float* ds2, int batch, int channels, int height,
+                            int width, void* stream);
 
 /* F.interpolate(mode='area') for an integer shrink factor (network.py:117,
  * group_modules.py:33-38): mean over factor x factor boxes.  in [planes][H][W]. */

@@ -126,6 +126,10 @@ def stem7x7(ps, image, masks=None, relu=False):
     return F.relu(y) if relu else y
 
 
+def upsample2x_add_ds2(x, skip):
+    return upsample2x_add(x, skip), area_downsample(x, 2)
+
+
 def pad2d(x, pad):
     return F.pad(x, pad)
 

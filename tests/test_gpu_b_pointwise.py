@@ -35,6 +35,18 @@ def test_upsample2x_add(shape, with_skip):
     _check('up2x', ops.upsample2x_add(to_dev(x), to_dev(skip)), emu_ops.upsample2x_add(x, skip))
 
 
+@pytest.mark.parametrize('shape', [(2, 16, 60, 108), (11, 8, 136, 240), (1, 3, 6, 10), (2, 2, 4, 6)])
+def test_upsample2x_add_ds2_is_both_kernels_in_one_pass(shape):
+    """deva_upsample2x_add_ds2: the x2 up-sampling + skip AND area_downsample(x, 2) of the input from the same loads --
+    bit-identical to the two separate launches"""
+    g = torch.Generator().manual_seed(sum(shape))
+    x = to_dev(rand(g, *shape))
+    skip = to_dev(rand(g, 1, shape[1], 2 * shape[2], 2 * shape[3]))
+    up, ds = ops.upsample2x_add_ds2(x, skip)
+    torch.cuda.synchronize()
+    assert torch.equal(up, ops.upsample2x_add(x, skip)) and torch.equal(ds, ops.area_downsample(x, 2))
+
+
 @pytest.mark.parametrize('shape,f', [((2, 5, 32, 48), 16), ((3, 7, 8, 12), 2), ((2, 1, 8, 12), 4), ((1, 2, 3, 3), 1)])
 def test_area_downsample(shape, f):
     x = rand(torch.Generator().manual_seed(3), *shape)

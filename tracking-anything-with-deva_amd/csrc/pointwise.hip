@@ -169,8 +169,12 @@ __global__ void upsample2x_add_kernel(const float* __restrict__ in, const float*
 // dimension; the one-pixel kernel above spends its time in two 64-bit divisions per output), one 16-byte load of the
 // skip tensor and one 16-byte store; the eight input values (2 rows x columns 2j-1 .. 2j+2) come from L1/L2.  Same
 // per-pixel arithmetic as upsample2x_add_kernel (lerp_index / bilerp): bit-identical results.
+// ds2 (optional, h and w even): the 2x2 box means of `in` -- area_downsample(in, 2), the decoder's p8 -> 1/16 for the sensory
+// update (modules.py:121-151) -- written by the threads whose two input rows and inner two columns ARE such a box (output
+// rows 4R + 1): no extra loads, the same sum in the same order as area_downsample_kernel, and one pass over `in` less.
 __global__ __launch_bounds__(256) void upsample2x_add_quad_kernel(const float* __restrict__ in, const float* __restrict__ skip,
-                                                                  float* __restrict__ out, int C, int h, int w) {
+                                                                  float* __restrict__ out, float* __restrict__ ds2, int C,
+                                                                  int h, int w) {
   const int OH = 2 * h, OW = 2 * w, QW = OW >> 2;
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q >= OH * QW) return;
@@ -183,6 +187,14 @@ __global__ __launch_bounds__(256) void upsample2x_add_quad_kernel(const float* _
   const int xa = max(2 * j - 1, 0), xb = 2 * j, xc = 2 * j + 1, xd = min(2 * j + 2, w - 1);
   const float a0 = r0[xa], b0 = r0[xb], c0 = r0[xc], d0 = r0[xd];
   const float a1 = r1[xa], b1 = r1[xb], c1 = r1[xc], d1 = r1[xd];
+  if (ds2 && (oy & 3) == 1) {  // rows ly.i0 = 2R, ly.i1 = 2R + 1 with R = oy / 4; columns 2j, 2j + 1
+    float sum = 0.0f;
+    sum += b0;
+    sum += c0;
+    sum += b1;
+    sum += c1;
+    ds2[((int64_t)plane * (h >> 1) + (oy >> 2)) * (w >> 1) + j] = sum / 4.0f;
+  }
   float v[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -642,21 +654,35 @@ extern "C" int deva_maxpool3x3s2(const float* in, float* out, int64_t planes, in
   return check_launch("deva_maxpool3x3s2");
 }
 
-extern "C" int deva_upsample2x_add(const float* in, const float* skip, float* out, int batch, int channels,
-                                   int height, int width, void* stream) {
-  DEVA_REQUIRE(in && out && batch > 0 && channels > 0 && height > 0 && width > 0, "deva_upsample2x_add: bad args");
+static int upsample2x_add_impl(const float* in, const float* skip, float* out, float* ds2, int batch, int channels, int height,
+                               int width, void* stream, const char* what) {
   const int64_t total = (int64_t)batch * channels * height * 2 * width * 2;
   const int64_t planes = (int64_t)batch * channels;
   const bool aligned = (((uintptr_t)out | (uintptr_t)skip) & 15) == 0;  // 16-byte rows: OW % 4 == 0 and aligned bases
-  if (width % 2 == 0 && width >= 2 && planes <= 65535 && aligned) {
+  if (width % 2 == 0 && width >= 2 && planes <= 65535 && aligned && (!ds2 || height % 2 == 0)) {
     const int quads = height * 2 * (width * 2 / 4);
     hipLaunchKernelGGL(upsample2x_add_quad_kernel, dim3((unsigned)ceil_div(quads, 256), (unsigned)planes), dim3(256), 0,
-                       (hipStream_t)stream, in, skip, out, channels, height, width);
-    return check_launch("deva_upsample2x_add");
+                       (hipStream_t)stream, in, skip, out, ds2, channels, height, width);
+    return check_launch(what);
   }
   hipLaunchKernelGGL(upsample2x_add_kernel, grid_for(total), dim3(TPB), 0, (hipStream_t)stream, in, skip, out,
                      total, channels, height, width);
-  return check_launch("deva_upsample2x_add");
+  if (check_launch(what)) return 1;
+  if (ds2) return deva_area_downsample(in, ds2, planes, height, width, 2, stream);  // (shapes the quad kernel does not take)
+  return 0;
+}
+
+extern "C" int deva_upsample2x_add(const float* in, const float* skip, float* out, int batch, int channels,
+                                   int height, int width, void* stream) {
+  DEVA_REQUIRE(in && out && batch > 0 && channels > 0 && height > 0 && width > 0, "deva_upsample2x_add: bad args");
+  return upsample2x_add_impl(in, skip, out, nullptr, batch, channels, height, width, stream, "deva_upsample2x_add");
+}
+
+extern "C" int deva_upsample2x_add_ds2(const float* in, const float* skip, float* out, float* ds2, int batch, int channels,
+                                       int height, int width, void* stream) {
+  DEVA_REQUIRE(in && out && ds2 && batch > 0 && channels > 0 && height > 0 && width > 0, "deva_upsample2x_add_ds2: bad args");
+  DEVA_REQUIRE(height % 2 == 0 && width % 2 == 0, "deva_upsample2x_add_ds2: even input size expected");
+  return upsample2x_add_impl(in, skip, out, ds2, batch, channels, height, width, stream, "deva_upsample2x_add_ds2");
 }
 
 extern "C" int deva_area_downsample(const float* in, float* out, int64_t planes, int height, int width,

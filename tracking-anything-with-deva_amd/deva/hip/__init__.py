@@ -62,6 +62,7 @@ SIGNATURES = {
     'deva_stem_pack': (c_int64, [c_void_p, c_int, c_void_p, c_void_p, POINTER(c_int)]),
     'deva_pad2d': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'deva_usage_init': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    'deva_upsample2x_add_ds2': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'deva_gather_s2': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'deva_gru_update': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'deva_affinity_topk': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,

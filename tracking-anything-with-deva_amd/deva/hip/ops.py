@@ -13,7 +13,7 @@ import torch
 from . import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQUARE_PLUS_ONE, KLAYOUT_CHUNK32, KLAYOUT_Q4, KLAYOUT_TAP_MAJOR,
                ConvDesc, DevaHipError, check, lib)
 
-__all__ = ['PackedConv', 'pack_conv', 'conv2d', 'split_fallbacks', 'PackedStem', 'pack_stem', 'stem7x7', 'pad2d', 'usage_init', 'gather_s2', 'maxpool3x3s2', 'upsample2x_add', 'area_downsample',
+__all__ = ['PackedConv', 'pack_conv', 'conv2d', 'split_fallbacks', 'PackedStem', 'pack_stem', 'stem7x7', 'pad2d', 'usage_init', 'gather_s2', 'maxpool3x3s2', 'upsample2x_add', 'upsample2x_add_ds2', 'area_downsample',
            'aggregate', 'softmax_channels', 'upsample4x_softmax', 'cbam', 'gru_update',
            'affinity_topk', 'BankPrep', 'affinity_dense', 'affinity_candidates', 'affinity_merge', 'usage_update', 'readout_sparse', 'bank_append', 'bank_gather_rows',
            'bank_export', 'rank', 'rank_select', 'evict_select', 'similarity_dense', 'softmax_columns',
@@ -457,6 +457,19 @@ def upsample2x_add(x: torch.Tensor, skip: Optional[torch.Tensor]) -> torch.Tenso
     out = _alloc((b, c, 2 * h, 2 * w), x.device)
     check(lib().deva_upsample2x_add(_p(x), _p(skip), _p(out), b, c, h, w, _stream()), 'deva_upsample2x_add')
     return out
+
+
+def upsample2x_add_ds2(x: torch.Tensor, skip: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(upsample2x_add(x, skip), area_downsample(x, 2)) from one pass over x (deva_upsample2x_add_ds2); x [B,C,h,w], h, w even"""
+    b, c, h, w = x.shape
+    if skip is not None and tuple(skip.shape[-3:]) != (c, 2 * h, 2 * w):
+        raise DevaHipError('upsample2x_add_ds2: skip shape mismatch')
+    if h % 2 or w % 2:
+        raise DevaHipError('upsample2x_add_ds2: even input size expected')
+    out = _alloc((b, c, 2 * h, 2 * w), x.device)
+    ds2 = _alloc((b, c, h // 2, w // 2), x.device)
+    check(lib().deva_upsample2x_add_ds2(_p(x), _p(skip), _p(out), _p(ds2), b, c, h, w, _stream()), 'deva_upsample2x_add_ds2')
+    return out, ds2
 
 
 def area_downsample(x: torch.Tensor, factor: int) -> torch.Tensor:

@@ -321,9 +321,10 @@ class CompiledGraph:
             sensory = self._gru(me + '.sensory_update.transform', value, sensory)
         return value, sensory
 
-    def decode_masks(self, ms_features, readout, sensory, last_mask16):
-        """readout/sensory [no,C,h,w]; last_mask16 [no,1,h,w] -> decoder pyramid p16, p8, p4 and the object
-        logits [no,1,4h,4w] (everything `segment` returns except the new sensory state)"""
+    def decode_masks(self, ms_features, readout, sensory, last_mask16, want_p8_ds: bool = False):
+        """readout/sensory [no,C,h,w]; last_mask16 [no,1,h,w] -> decoder pyramid p16, p8, p4, the object logits
+        [no,1,4h,4w] (everything `segment` returns except the new sensory state) and, with want_p8_ds, p8 at 1/16 for
+        `sensory_update` (None otherwise)"""
         c = self.convs
         md = 'mask_decoder'
         f16, f8, f4 = ms_features
@@ -332,22 +333,29 @@ class CompiledGraph:
         p16 = self._conv(md + '.sensory_compress', sensory, last_mask16, residual=readout)
         p16 = self._fusion(md + '.fuser', f16, p16)
         p8 = self._res_block(md + '.up_16_8.out_conv', ops.upsample2x_add(p16, d8))
-        p4 = self._res_block(md + '.up_8_4.out_conv', ops.upsample2x_add(p8, d4))
+        if want_p8_ds and p8.shape[-2] % 2 == 0 and p8.shape[-1] % 2 == 0:
+            # the sensory update takes p8 at 1/16 (modules.py:121-151): written by the pass that up-samples p8 anyway
+            up, p8_ds = ops.upsample2x_add_ds2(p8, d4)
+        else:
+            up, p8_ds = ops.upsample2x_add(p8, d4), None
+        p4 = self._res_block(md + '.up_8_4.out_conv', up)
         logits = self._conv(md + '.pred', p4, pad=1, relu_in=True)
-        return p16, p8, p4, logits
+        return p16, p8, p4, logits, p8_ds
 
-    def sensory_update(self, p16, p8, p4, logits, sensory):
+    def sensory_update(self, p16, p8, p4, logits, sensory, p8_ds=None):
         """the decoder's GRU update of the sensory memory (modules.py:121-151): needed by the NEXT frame only"""
         c = self.convs
         su = 'mask_decoder.sensory_update'
         g = self._conv(su + '.g16_conv', p16)
-        g = self._conv(su + '.g8_conv', ops.area_downsample(p8, 2), residual=g)
+        if p8_ds is None:  # (decode_masks(want_p8_ds=True) makes it in its x2 up-sampling pass)
+            p8_ds = ops.area_downsample(p8, 2)
+        g = self._conv(su + '.g8_conv', p8_ds, residual=g)
         g = self._conv(su + '.g4_conv', ops.area_downsample(p4, 4), ops.area_downsample(logits, 4), residual=g)
         return self._gru(su + '.transform', g, sensory)
 
     def decode(self, ms_features, readout, sensory, last_mask16, update_sensory: bool):
         """readout/sensory [no,C,h,w]; last_mask16 [no,1,h,w] -> sensory', object logits [no,1,4h,4w]"""
-        p16, p8, p4, logits = self.decode_masks(ms_features, readout, sensory, last_mask16)
+        p16, p8, p4, logits, p8_ds = self.decode_masks(ms_features, readout, sensory, last_mask16, want_p8_ds=update_sensory)
         if update_sensory:
-            sensory = self.sensory_update(p16, p8, p4, logits, sensory)
+            sensory = self.sensory_update(p16, p8, p4, logits, sensory, p8_ds)
         return sensory, logits
