@@ -26,7 +26,7 @@ def test_maxpool(shape, relu):
     _check('maxpool', ops.maxpool3x3s2(to_dev(x), relu), emu_ops.maxpool3x3s2(x, relu), 0)
 
 
-@pytest.mark.parametrize('shape', [(2, 16, 6, 8), (1, 3, 1, 1), (3, 5, 7, 9)])
+@pytest.mark.parametrize('shape', [(2, 16, 6, 8), (1, 3, 1, 1), (3, 5, 7, 9), (2, 4, 5, 4), (1, 2, 3, 6), (3, 8, 68, 120), (1, 2, 1, 4)])
 @pytest.mark.parametrize('with_skip', [False, True])
 def test_upsample2x_add(shape, with_skip):
     g = torch.Generator().manual_seed(2)

@@ -165,55 +165,69 @@ __global__ void upsample2x_add_kernel(const float* __restrict__ in, const float*
   }
 }
 
-// Four consecutive output pixels of a row per thread (OW % 4 == 0): 32-bit index arithmetic (the plane is a grid
-// dimension; the one-pixel kernel above spends its time in two 64-bit divisions per output), one 16-byte load of the
-// skip tensor and one 16-byte store; the eight input values (2 rows x columns 2j-1 .. 2j+2) come from L1/L2.  Same
-// per-pixel arithmetic as upsample2x_add_kernel (lerp_index / bilerp): bit-identical results.
+// Two output rows x four consecutive output pixels per thread (w even, w >= 4): output rows 2P - 1 and 2P interpolate
+// between the SAME two input rows (P - 1, P), and their eight inputs (columns 2j - 1 .. 2j + 2 of both rows) are two
+// 16-byte loads -- 6 vector-memory instructions per 2 x 16 bytes of output (two loads, two skip loads, two stores) where the
+// one-row form of round 4 issued 10 per 16 bytes (eight scalar loads): that kernel ran at 2.7 TB/s at 1080p / 11 objects,
+// bound by the CU's address path (a vector-memory instruction costs the same whatever its width).  The column window is
+// shifted inside the row at both ends (no read outside the row) and the clamped neighbours are picked from it.  Same
+// per-pixel arithmetic as upsample2x_add_kernel (lerp_index weights, top / bottom order): bit-identical results.
 // ds2 (optional, h and w even): the 2x2 box means of `in` -- area_downsample(in, 2), the decoder's p8 -> 1/16 for the sensory
-// update (modules.py:121-151) -- written by the threads whose two input rows and inner two columns ARE such a box (output
-// rows 4R + 1): no extra loads, the same sum in the same order as area_downsample_kernel, and one pass over `in` less.
+// update (modules.py:121-151) -- written by the threads whose two input rows and inner two columns ARE such a box (odd P):
+// no extra loads, the same sum in the same order as area_downsample_kernel, and one pass over `in` less.
+typedef float up_f32x4 __attribute__((ext_vector_type(4)));
+typedef up_f32x4 up_f32x4_u __attribute__((aligned(4)));
 __global__ __launch_bounds__(256) void upsample2x_add_quad_kernel(const float* __restrict__ in, const float* __restrict__ skip,
                                                                   float* __restrict__ out, float* __restrict__ ds2, int C,
                                                                   int h, int w) {
   const int OH = 2 * h, OW = 2 * w, QW = OW >> 2;
   const int q = blockIdx.x * 256 + threadIdx.x;
-  if (q >= OH * QW) return;
+  if (q >= (h + 1) * QW) return;
   const int plane = blockIdx.y;  // b*C + c
-  const int oy = q / QW, j = q - oy * QW;
+  const int P = q / QW, j = q - P * QW;
   const float* src = in + (int64_t)plane * h * w;
-  const Lerp ly = lerp_index(oy, 0.5f, h);
-  const float* r0 = src + ly.i0 * w;
-  const float* r1 = src + ly.i1 * w;
-  const int xa = max(2 * j - 1, 0), xb = 2 * j, xc = 2 * j + 1, xd = min(2 * j + 2, w - 1);
-  const float a0 = r0[xa], b0 = r0[xb], c0 = r0[xc], d0 = r0[xd];
-  const float a1 = r1[xa], b1 = r1[xb], c1 = r1[xc], d1 = r1[xd];
-  if (ds2 && (oy & 3) == 1) {  // rows ly.i0 = 2R, ly.i1 = 2R + 1 with R = oy / 4; columns 2j, 2j + 1
+  // the rows lerp_index names for output rows 2P - 1 and 2P (identical for both; row 0 pairs with row 1 for output row 0)
+  const int rowA = P == 0 ? 0 : P - 1, rowB = P == 0 ? min(1, h - 1) : min(P, h - 1);
+  const int base = min(max(2 * j - 1, 0), w - 4);
+  const up_f32x4 va = *reinterpret_cast<const up_f32x4_u*>(src + rowA * w + base);
+  const up_f32x4 vb = *reinterpret_cast<const up_f32x4_u*>(src + rowB * w + base);
+  const int o = (2 * j - 1) - base;  // -1 at the left edge (column -1 clamps to 0), +1 at the right edge (column w clamps to w - 1)
+  const float a0 = o > 0 ? va[1] : va[0], b0 = o < 0 ? va[0] : (o > 0 ? va[2] : va[1]);
+  const float c0 = o < 0 ? va[1] : (o > 0 ? va[3] : va[2]), d0 = o < 0 ? va[2] : va[3];
+  const float a1 = o > 0 ? vb[1] : vb[0], b1 = o < 0 ? vb[0] : (o > 0 ? vb[2] : vb[1]);
+  const float c1 = o < 0 ? vb[1] : (o > 0 ? vb[3] : vb[2]), d1 = o < 0 ? vb[2] : vb[3];
+  if (ds2 && (P & 1)) {  // rows 2R, 2R + 1 with R = P / 2; columns 2j, 2j + 1
     float sum = 0.0f;
     sum += b0;
     sum += c0;
     sum += b1;
     sum += c1;
-    ds2[((int64_t)plane * (h >> 1) + (oy >> 2)) * (w >> 1) + j] = sum / 4.0f;
+    ds2[((int64_t)plane * (h >> 1) + (P >> 1)) * (w >> 1) + j] = sum / 4.0f;
   }
-  float v[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const Lerp lx = lerp_index(4 * j + e, 0.5f, w);
-    // columns of the four outputs: (2j-1, 2j), (2j, 2j+1), (2j, 2j+1), (2j+1, 2j+2) -- clamped like lerp_index clamps
-    const float t0 = e == 0 ? a0 : (e == 3 ? c0 : b0), t1 = e == 0 ? b0 : (e == 3 ? d0 : c0);
-    const float u0 = e == 0 ? a1 : (e == 3 ? c1 : b1), u1 = e == 0 ? b1 : (e == 3 ? d1 : c1);
-    const float top = lx.w0 * t0 + lx.w1 * t1;
-    const float bot = lx.w0 * u0 + lx.w1 * u1;
-    v[e] = ly.w0 * top + ly.w1 * bot;
+  for (int row = 0; row < 2; ++row) {
+    const int oy = 2 * P - 1 + row;
+    if (oy < 0 || oy >= OH) continue;
+    const Lerp ly = lerp_index(oy, 0.5f, h);
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const Lerp lx = lerp_index(4 * j + e, 0.5f, w);
+      // columns of the four outputs: (2j-1, 2j), (2j, 2j+1), (2j, 2j+1), (2j+1, 2j+2) -- clamped like lerp_index clamps
+      const float t0 = e == 0 ? a0 : (e == 3 ? c0 : b0), t1 = e == 0 ? b0 : (e == 3 ? d0 : c0);
+      const float u0 = e == 0 ? a1 : (e == 3 ? c1 : b1), u1 = e == 0 ? b1 : (e == 3 ? d1 : c1);
+      const float top = lx.w0 * t0 + lx.w1 * t1;
+      const float bot = lx.w0 * u0 + lx.w1 * u1;
+      v[e] = ly.w0 * top + ly.w1 * bot;
+    }
+    const int64_t ofs = ((int64_t)plane * OH + oy) * OW + 4 * j;
+    up_f32x4 r = {v[0], v[1], v[2], v[3]};
+    if (skip) {
+      const up_f32x4 sk = *reinterpret_cast<const up_f32x4*>(skip + ((int64_t)(plane % C) * OH + oy) * OW + 4 * j);
+      r = up_f32x4{sk[0] + v[0], sk[1] + v[1], sk[2] + v[2], sk[3] + v[3]};
+    }
+    *reinterpret_cast<up_f32x4*>(out + ofs) = r;
   }
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  const int64_t o = ((int64_t)plane * OH + oy) * OW + 4 * j;
-  f4 r = {v[0], v[1], v[2], v[3]};
-  if (skip) {
-    const f4 sk = *reinterpret_cast<const f4*>(skip + ((int64_t)(plane % C) * OH + oy) * OW + 4 * j);
-    r = f4{sk[0] + v[0], sk[1] + v[1], sk[2] + v[2], sk[3] + v[3]};
-  }
-  *reinterpret_cast<f4*>(out + o) = r;
 }
 
 // ------------------------------------------------------------------ area downsample (integer factor)
@@ -372,7 +386,11 @@ __global__ void global_avgmax_kernel(const float* __restrict__ x, float* __restr
   }
 }
 
-// one block per batch item; scale = sigmoid(mlp(avg) + mlp(max))
+// one block per batch item; scale = sigmoid(mlp(avg) + mlp(max)).  The block is alone on its CU and the whole kernel is a
+// chain of dependent latencies, so both layers put all their loads in flight at once: layer 1 runs four threads per hidden
+// unit and input vector (each streams a quarter of the weight row with 16-byte loads, the partial sums meet in two
+// shuffles), layer 2 reads its `hidden` weights per output channel with 16-byte loads.  (C % 16 == 0, hidden % 4 == 0 and
+// 2 * hidden * 4 <= blockDim; other shapes take the plain loops.)
 __global__ void cbam_mlp_kernel(const float* __restrict__ avg, const float* __restrict__ mx,
                                 const float* __restrict__ w1, const float* __restrict__ b1,
                                 const float* __restrict__ w2, const float* __restrict__ b2,
@@ -386,26 +404,51 @@ __global__ void cbam_mlp_kernel(const float* __restrict__ avg, const float* __re
     vin[C + i] = mx[(int64_t)b * C + i];
   }
   __syncthreads();
-  // first layer: one WAVE per hidden unit and input vector -- its 64 lanes read the weight row coalesced and meet in a
-  // shuffle tree (round 5: one thread per unit walked its row alone, 512 strided loads: 21 us for 64 dot products)
-  {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int t = wave; t < 2 * hidden; t += nw) {
+  const bool fast = (C % 16 == 0) && (hidden % 4 == 0) && (2 * hidden * 4 <= (int)blockDim.x) &&
+                    ((((uintptr_t)w1 | (uintptr_t)w2) & 15) == 0);
+  if (fast) {
+    const int t = threadIdx.x >> 2, part = threadIdx.x & 3;  // unit-and-vector t, quarter `part` of the channels
+    float s = 0.0f;
+    if (t < 2 * hidden) {
+      const int which = t / hidden, j = t % hidden;
+      const int quarter = C / 4;
+      const pw_f32x4* wr = reinterpret_cast<const pw_f32x4*>(w1 + (int64_t)j * C + part * quarter);
+      const float* xv = vin + which * C + part * quarter;
+      for (int i = 0; i < quarter / 4; ++i) {
+        const pw_f32x4 w = wr[i];
+        s += w[0] * xv[4 * i] + w[1] * xv[4 * i + 1] + w[2] * xv[4 * i + 2] + w[3] * xv[4 * i + 3];
+      }
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    if (t < 2 * hidden && part == 0) hid[t] = fmaxf(s + b1[t % hidden], 0.0f);
+  } else {
+    for (int t = threadIdx.x; t < 2 * hidden; t += blockDim.x) {
       const int which = t / hidden, j = t % hidden;
       float s = 0.0f;
-      for (int c = lane; c < C; c += 64) s += w1[(int64_t)j * C + c] * vin[which * C + c];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-      if (lane == 0) hid[t] = fmaxf(s + b1[j], 0.0f);
+      for (int c = 0; c < C; ++c) s += w1[(int64_t)j * C + c] * vin[which * C + c];
+      hid[t] = fmaxf(s + b1[j], 0.0f);
     }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float sa = 0.0f, sm_ = 0.0f;
-    for (int j = 0; j < hidden; ++j) {
-      const float w = w2[(int64_t)c * hidden + j];
-      sa += w * hid[j];
-      sm_ += w * hid[hidden + j];
+    if (fast) {
+      const pw_f32x4* wr = reinterpret_cast<const pw_f32x4*>(w2 + (int64_t)c * hidden);
+      for (int j4 = 0; j4 < hidden / 4; ++j4) {
+        const pw_f32x4 w = wr[j4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          sa += w[u] * hid[4 * j4 + u];
+          sm_ += w[u] * hid[hidden + 4 * j4 + u];
+        }
+      }
+    } else {
+      for (int j = 0; j < hidden; ++j) {
+        const float w = w2[(int64_t)c * hidden + j];
+        sa += w * hid[j];
+        sm_ += w * hid[hidden + j];
+      }
     }
     const float att = (sa + b2[c]) + (sm_ + b2[c]);
     scale[(int64_t)b * C + c] = sigmoidf_(att);
@@ -659,8 +702,8 @@ static int upsample2x_add_impl(const float* in, const float* skip, float* out, f
   const int64_t total = (int64_t)batch * channels * height * 2 * width * 2;
   const int64_t planes = (int64_t)batch * channels;
   const bool aligned = (((uintptr_t)out | (uintptr_t)skip) & 15) == 0;  // 16-byte rows: OW % 4 == 0 and aligned bases
-  if (width % 2 == 0 && width >= 2 && planes <= 65535 && aligned && (!ds2 || height % 2 == 0)) {
-    const int quads = height * 2 * (width * 2 / 4);
+  if (width % 2 == 0 && width >= 4 && planes <= 65535 && aligned && (!ds2 || height % 2 == 0)) {
+    const int quads = (height + 1) * (width * 2 / 4);  // (row pair, pixel quad): output rows 2P - 1 and 2P, P = 0 .. height
     hipLaunchKernelGGL(upsample2x_add_quad_kernel, dim3((unsigned)ceil_div(quads, 256), (unsigned)planes), dim3(256), 0,
                        (hipStream_t)stream, in, skip, out, ds2, channels, height, width);
     return check_launch(what);
