@@ -554,6 +554,29 @@ __global__ void gru_update_kernel(const float* __restrict__ values, const float*
   }
 }
 
+// hw % 4 == 0 and 16-byte aligned tensors: four elements per thread (the same arithmetic per element)
+__global__ void gru_update_vec_kernel(const float* __restrict__ values, const float* __restrict__ h,
+                                      float* __restrict__ new_h, int64_t total4, int C, int hw) {
+  const int64_t chw = (int64_t)C * hw;
+  for (int64_t i4 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i4 < total4; i4 += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = i4 * 4;
+    const int64_t b = i / chw;
+    const int64_t r = i - b * chw;
+    const float* v = values + b * 3 * chw + r;
+    const pw_f32x4 vf = *reinterpret_cast<const pw_f32x4*>(v), vu = *reinterpret_cast<const pw_f32x4*>(v + chw);
+    const pw_f32x4 vn = *reinterpret_cast<const pw_f32x4*>(v + 2 * chw), hv = *reinterpret_cast<const pw_f32x4*>(h + i);
+    pw_f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float f = sigmoidf_(vf[e]);
+      const float u = sigmoidf_(vu[e]);
+      const float n = tanhf(vn[e]);
+      o[e] = f * hv[e] * (1.0f - u) + u * n;
+    }
+    *reinterpret_cast<pw_f32x4*>(new_h + i) = o;
+  }
+}
+
 // ------------------------------------------------------------------ input head
 // uint8 HWC frame -> normalised fp32 CHW at the network's input size, in one pass
 // (deva/inference/data/video_reader.py:139-144 = ToTensor + Normalize + Resize(antialias=True);
@@ -831,6 +854,11 @@ extern "C" int deva_gru_update(const float* values, const float* h, float* new_h
                                void* stream) {
   DEVA_REQUIRE(values && h && new_h && batch > 0 && channels > 0 && hw > 0, "deva_gru_update: bad args");
   const int64_t total = (int64_t)batch * channels * hw;
+  if (hw % 4 == 0 && (((uintptr_t)values | (uintptr_t)h | (uintptr_t)new_h) & 15) == 0) {
+    hipLaunchKernelGGL(gru_update_vec_kernel, grid_for(total / 4), dim3(TPB), 0, (hipStream_t)stream, values, h, new_h,
+                       total / 4, channels, hw);
+    return check_launch("deva_gru_update");
+  }
   hipLaunchKernelGGL(gru_update_kernel, grid_for(total), dim3(TPB), 0, (hipStream_t)stream, values, h, new_h, total,
                      channels, hw);
   return check_launch("deva_gru_update");
