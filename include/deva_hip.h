@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DEVA_HIP_ABI_VERSION 8
+#define DEVA_HIP_ABI_VERSION 9
 
 int deva_hip_version(void);
 const char* deva_hip_last_error(void);
@@ -128,6 +128,14 @@ typedef struct deva_conv_desc {
    * (513 = 512 + 1, 257 = 256 + 1: a partial last K step). */
   int32_t split_scale_log2;
   int32_t* split_flag;
+  /* optional: the weights of a 3x3 / stride 1 / pad 1 layer transformed for Winograd F(2x2, 3x3) by deva_conv_pack_wino
+   * (NULL: the direct kernels).  With amp == 0, even height / width (>= 4), c0 and c1 multiples of 8 and enough 2x2 output
+   * tiles to fill the chip, the layer runs csrc/conv_wino.hip: 16 instead of 36 multiply-adds per input channel and 2x2
+   * outputs on the fp32 matrix pipes, transforms with constants 0, +-1, +-1/2 in fp32 -- the arithmetic of the reference's
+   * nn.Conv2d (big_modules.py:54-212, modules.py:81-169) to ~2x the direct kernels' round-off (5e-7 of the output range on
+   * the network's layer shapes; the same 2e-5 gate in tests/test_gpu_a_conv.py).  Everything else runs the direct kernels
+   * on `weight`. */
+  const float* weight_wino;
 } deva_conv_desc;
 
 int deva_conv2d(const deva_conv_desc* desc, void* stream);
@@ -157,6 +165,12 @@ int deva_stem7x7(const float* in0, int64_t in0_batch_stride, int c0, const float
  * (((k/8)*2 + plane)*64 + m)*8 + k%8, taps dy = 7 / dx = 7 zero), w32: cin*49*64 floats ([(c*7 + dy)*7 + dx][m]).
  * Returns the number of uint16 elements of planes (planes == NULL: size query; *scale_log2 is set either way), -1 on error. */
 int64_t deva_stem_pack(const float* w_oihw, int cin, uint16_t* planes, float* w32, int* scale_log2);
+
+/* Winograd-transformed weights (HOST pointers, model load): w_oihw [cout][cin][3][3] (BatchNorm folded), cin % 8 == 0 ->
+ * U = G g G^T computed in fp64 and rounded once, element (c, p = 4 i + l, m) at ((((c/8)*16 + p)*2 + c%2)*cout_pad64 + m)*4 +
+ * (c%8)/2 with cout padded to a multiple of 64 (zeros).  Returns the number of floats (out == NULL: size query), -1 when
+ * the layer is not eligible (cin % 8 != 0) or on bad arguments. */
+int64_t deva_conv_pack_wino(const float* w_oihw, float* out, int cout, int cin);
 
 /* Host-side packing of one convolution's weights (HOST pointers; model load, not the frame path):
  * w_oihw [cout][cin][kh][kw] (BatchNorm already folded) -> out in the layout named by *k_layout / *cout_pad

@@ -20,8 +20,8 @@ def require_hip(device, what):  # the emulation runs on the CPU
     return None
 
 
-def pack_conv(weight, bias=None, bn=None, device=None, amp=False, split=False):
-    return _real_pack_conv(weight, bias, bn, None, amp, split)
+def pack_conv(weight, bias=None, bn=None, device=None, amp=False, split=False, wino=False):
+    return _real_pack_conv(weight, bias, bn, None, amp, split, wino)  # (the Winograd contract is the fp32 convolution itself)
 
 
 def _unpack(pc: PackedConv):

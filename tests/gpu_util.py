@@ -33,7 +33,8 @@ def to_dev(x):
     if isinstance(x, ops.PackedConv):
         return ops.PackedConv(x.weight.to(dev()), None if x.bias is None else x.bias.to(dev()), x.cin, x.cout,
                               x.cout_pad, x.kh, x.kw, x.k_layout, None if x.weight_f16 is None else x.weight_f16.to(dev()),
-                              None if x.weight_split is None else x.weight_split.to(dev()), x.split_scale_log2)
+                              None if x.weight_split is None else x.weight_split.to(dev()), x.split_scale_log2,
+                              None if x.weight_wino is None else x.weight_wino.to(dev()))
     if isinstance(x, dict):
         return {k: to_dev(v) for k, v in x.items()}
     if isinstance(x, (list, tuple)):

@@ -1,5 +1,6 @@
 """deva_conv2d (implicit-GEMM fp32 MFMA) against F.conv2d on the CPU: every geometry the network
 uses plus ragged / tiny / padded edge cases.  Tolerance: fp32 accumulation-order noise only."""
+import os
 import zlib
 
 import pytest
@@ -337,6 +338,62 @@ def test_conv_split_fallback_walks_every_tile(k, cin, cout, relu_in):
     torch.cuda.synchronize()
     assert ops.split_fallbacks(dev()) == before + 1
     assert torch.equal(got, f32)
+
+
+# fp32 Winograd F(2x2, 3x3) (csrc/conv_wino.hip): the SAME 2e-5 bound as the direct kernels against the same CPU convolution, and
+# against fp64 an error of the fp32 class (measured ~2x the direct kernels').  The library takes the path only for layers with
+# >= 192 workgroups of 64 channels x 64 tiles, so the shapes are sized for that.
+# (name, c0, c1, cout, batch, H, W, bcast0, relu_in, residual, act, bias)
+WINO_CASES = [
+    ('wino_plain', 64, 0, 128, 2, 96, 128, False, False, 'none', ops.ACT_NONE, True),
+    ('wino_relu_res', 256, 0, 256, 2, 60, 108, False, True, 'full', ops.ACT_NONE, True),
+    ('wino_cat_bcast', 32, 40, 192, 3, 64, 96, True, False, 'none', ops.ACT_RELU, True),
+    ('wino_ragged_cout_bcast_res', 24, 0, 200, 4, 50, 76, False, True, 'bcast', ops.ACT_SIGMOID, False),
+    ('wino_gru_shape', 512, 512, 1536, 2, 30, 54, False, False, 'none', ops.ACT_NONE, True),
+    ('wino_narrow', 16, 0, 128, 200, 34, 4, False, False, 'full', ops.ACT_SQUARE_PLUS_ONE, True),
+    ('wino_ragged_tiles', 64, 0, 192, 7, 46, 62, False, True, 'none', ops.ACT_RELU, True),
+]
+
+
+@pytest.mark.parametrize('case', WINO_CASES, ids=[c[0] for c in WINO_CASES])
+def test_conv_wino_matches_cpu(case):
+    name, c0, c1, cout, batch, H, W, bcast0, relu_in, res, act, bias = case
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 100000)
+    cin = c0 + c1
+    w = rand(g, cout, cin, 3, 3, scale=(2.0 / (cin * 9))**0.5)
+    b = rand(g, cout, scale=0.1) if bias else None
+    pc = ops.pack_conv(w, b, None, wino=True)
+    pc_direct = ops.pack_conv(w, b, None)
+    assert pc.weight_wino is not None
+    x0 = rand(g, 1 if bcast0 else batch, c0, H, W)
+    x1 = rand(g, batch, c1, H, W) if c1 else None
+    residual = rand(g, batch if res == 'full' else 1, cout, H, W) if res != 'none' else None
+    want = emu_ops.conv2d(pc_direct, x0, x1, pad=1, relu_in=relu_in, residual=residual, act=act)
+    want64 = _conv64(pc_direct, x0, x1, 1, 1, relu_in, residual, act)
+    got = ops.conv2d(to_dev(pc), _guarded(x0), _guarded(x1), pad=1, relu_in=relu_in, residual=to_dev(residual), act=act)
+    direct = ops.conv2d(to_dev(pc_direct), _guarded(x0), _guarded(x1), pad=1, relu_in=relu_in, residual=to_dev(residual), act=act)
+    torch.cuda.synchronize()
+    assert not torch.isnan(got).any(), f'{name}: guard-band values leaked into the result'
+    if os.environ.get('DEVA_TEST_DRYRUN') != '1':  # (the emulated ops have one convolution)
+        assert not torch.equal(got, direct), f'{name}: the Winograd kernel did not run (bit-identical to the direct kernels)'
+    scale = max(1.0, want.abs().max().item())
+    err = max_err(got, want)
+    e_w = (got.double().cpu() - want64).abs().max().item() / max(1e-30, want64.abs().max().item())
+    e_d = (direct.double().cpu() - want64).abs().max().item() / max(1e-30, want64.abs().max().item())
+    print(f'{name}: max abs err {err:.3e} (|ref|max {scale:.3e}); against fp64 / |ref|max: Winograd {e_w:.3e}, direct kernels {e_d:.3e}')
+    assert err <= 2e-5 * scale, (name, err)
+    assert e_w <= 8.0 * e_d + 1e-6, (name, e_w, e_d)
+
+
+def test_conv_wino_small_layers_stay_on_the_direct_kernels():
+    """fewer than 192 workgroups of 64 channels x 64 tiles (the batch-1 layers of a 480p frame): the library ignores the
+    transformed weights -- bit-identical to the call without them; so do odd map sizes"""
+    g = torch.Generator().manual_seed(8)
+    w = rand(g, 64, 64, 3, 3, scale=0.05)
+    pc, pcd = to_dev(ops.pack_conv(w, None, None, wino=True)), to_dev(ops.pack_conv(w, None, None))
+    for shape in ((1, 64, 30, 54), (4, 64, 31, 54), (64, 64, 30, 53)):
+        x = _guarded(rand(g, *shape))
+        assert torch.equal(ops.conv2d(pc, x, pad=1), ops.conv2d(pcd, x, pad=1)), shape
 
 
 # the 7x7 stride-2 stems on the f16 matrix pipes (csrc/conv_stem.hip): against fp64 like the split convolutions above, and

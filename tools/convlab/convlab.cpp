@@ -102,6 +102,7 @@ typedef int64_t (*pack_fn)(const float*, float*, int, int, int, int, int, int*, 
 typedef const char* (*err_fn)(void);
 typedef int64_t (*pack16_fn)(const float*, uint16_t*, int, int, int, int, int*);
 typedef int64_t (*packsp_fn)(const float*, uint16_t*, int, int, int, int, int*, int*);
+typedef int64_t (*packwi_fn)(const float*, float*, int, int);
 
 struct Lib {
   std::string path;
@@ -111,6 +112,7 @@ struct Lib {
   err_fn err;
   pack16_fn pack16;  // optional: deva_conv_pack_f16 (amp path)
   packsp_fn packsp;  // optional: deva_conv_pack_split (fp32-accurate hi/lo split on the f16 pipes)
+  packwi_fn packwi;  // optional: deva_conv_pack_wino (fp32 Winograd F(2x2, 3x3))
 };
 
 static constexpr int64_t kGuard = 8192;  // like deva/hip/ops.py:_alloc
@@ -135,7 +137,7 @@ int main(int argc, char** argv) {
   std::string libs = "tracking-anything-with-deva_amd/deva/hip/libdeva_hip.so";
   std::string only, set = "frame480", shapes;
   int iters = 20;
-  bool check = false, csv = false, stamps = false, amp = false, split = false, overflow = false, zero_in = false;
+  bool check = false, csv = false, stamps = false, amp = false, split = false, overflow = false, zero_in = false, wino = false;
   int keepalive_ms = 0;
   int rounds = 1;
   double warm_ms = 15.0, time_ms = 20.0;
@@ -151,6 +153,7 @@ int main(int argc, char** argv) {
     else if (a == "--csv") csv = true;
     else if (a == "--stamps") stamps = true;
     else if (a == "--amp") amp = true;  // fp16 operands on every library but the first (which stays the fp32 reference)
+    else if (a == "--wino") wino = true;  // fp32 Winograd on every library but the first
     else if (a == "--split") split = true;  // hi/lo fp16 split (fp32-accurate) on every library but the first
     else if (a == "--zero_in") zero_in = true;  // all-zero activations (power probe: operand switching activity)
     else if (a == "--overflow") overflow = true;  // one input element beyond the fp16 range: the split path must fall back
@@ -194,6 +197,7 @@ int main(int argc, char** argv) {
     l.err = (err_fn)dlsym(l.h, "deva_hip_last_error");
     l.pack16 = (pack16_fn)dlsym(l.h, "deva_conv_pack_f16");
     l.packsp = (packsp_fn)dlsym(l.h, "deva_conv_pack_split");
+    l.packwi = (packwi_fn)dlsym(l.h, "deva_conv_pack_wino");
     if (!l.conv) { fprintf(stderr, "%s: no deva_conv2d\n", l.path.c_str()); return 1; }
     L.push_back(l);
     p = q + 1;
@@ -329,6 +333,16 @@ int main(int argc, char** argv) {
           d.amp = 2;
           d.split_scale_log2 = e;
           d.split_flag = (int32_t*)dev_alloc_guarded(4, keep);  // zeroed
+        }
+      }
+      if (wino && li > 0 && l.packwi && ly.k == 3 && ly.stride == 1) {
+        const int64_t nw = l.packwi(h_w.data(), nullptr, ly.cout, cin);
+        if (nw > 0) {
+          std::vector<float> ww(nw);
+          l.packwi(h_w.data(), ww.data(), ly.cout, cin);
+          float* d_ww = dev_alloc_guarded(nw, keep);
+          HIP_OK(hipMemcpy(d_ww, ww.data(), nw * 4, hipMemcpyHostToDevice));
+          d.weight_wino = d_ww;
         }
       }
       int rc = 0;

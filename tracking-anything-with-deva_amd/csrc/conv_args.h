@@ -82,6 +82,9 @@ int launch_conv_q4(const ConvArgs& a, hipStream_t st);
 // conv_mfma.hip: the gated fp32 re-run behind a split launch as a persistent kernel (<= 1 024 workgroups whatever the
 // layer's size); -1 = shape not covered, launch the regular kernels with the gate
 int launch_conv_q4_gated(const ConvArgs& a, hipStream_t st);
+// conv_wino.hip: Winograd F(2x2, 3x3) on the fp32 matrix pipes for 3x3 / stride 1 / pad 1 layers whose transformed weights the
+// caller supplies (deva_conv_desc.weight_wino); -1 = shape not eligible, run the direct kernels
+int launch_conv_wino(const ConvArgs& a, const float* u, hipStream_t st);
 // conv_f16.hip: fp16-operand kernels (opt-in amp path, a.prec == 1) and the hi/lo split kernels (a.prec == 2: fp32-accurate
 // on the f16 matrix pipes); -1 = shape not eligible, run the fp32 kernels
 int launch_conv_f16(const ConvArgs& a, hipStream_t st);

@@ -793,6 +793,10 @@ extern "C" int deva_conv2d(const deva_conv_desc* d, void* stream) {
     if (rows3x3) return launch_conv3x3_cout1_rows(c, st);
     return launch_conv_cout1(c, st);
   }
+  if (d->weight_wino && !a.w16 && a.cout > 1) {  // fp32 Winograd F(2x2, 3x3): big 3x3 stride-1 layers only (conv_wino.hip)
+    const int rc = launch_conv_wino(a, d->weight_wino, st);
+    if (rc >= 0) return rc;
+  }
   if (a.w16 && a.cout > 1 && a.in0_span < (1ll << 29) && a.in1_span < (1ll << 29)) {
     // opt-in f16 matrix pipes (fp16 operands, or the fp32-accurate hi/lo split): eligible shapes only, everything else
     // -- and inputs too large for 32-bit buffer offsets -- stays on the fp32 kernels

@@ -1,0 +1,378 @@
+// 3x3 / stride 1 / pad 1 convolutions as Winograd F(2x2, 3x3) on the fp32 matrix pipes (v_mfma_f32_32x32x2_f32).
+//
+// Why: the fp32 MFMA runs at 1/16 of the f16 rate and is THE bound of the fp32 frame (the five big 3x3 layers of the
+// decoder / value encoder are 76 % of the 480p / 5-object frame at 0.86 - 0.87 of the matrix peak: nothing left to
+// schedule).  F(2x2, 3x3) computes a 2x2 output tile from 16 instead of 36 multiply-adds per input channel: 2.25x fewer
+// MFMAs, with transforms whose constants are 0, +-1, +-1/2 (error against fp64 ~2x the direct kernel's: 5e-7 of the output
+// range on the layer shapes of the network, bound 2e-5 in tests/test_gpu_a_conv.py).  Unlike on the f16 pipes (DESIGN.md
+// section 8) the transform is cheap here: ~100 VALU cycles per 1 024 MFMA cycles.
+//
+//   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A        per (output channel, 2x2 tile); g 3x3, d the 4x4 input patch
+//
+// GEMM view: 16 independent GEMMs (one per transform position p = 4 i + l), M = cout, N = tiles (batch-major, row-major
+// inside an image), K = input channels.  A workgroup = 4 waves = 64 output channels x 64 tiles; a wave holds the SIXTEEN
+// 32x32 accumulators of its 32 channels x 32 tiles (256 registers: one wave per SIMD).  K advances in steps of 8 channels:
+//   * transformed weights U (deva_conv_pack_wino: [c/8][p][c%2][cout_pad][c%8/2], i.e. the four k values a lane feeds to the
+//     four MFMAs of a position are one 16-byte read) go global -> LDS as they are;
+//   * activations: thread (tile, channel pair) loads the 4x4 patch of its tile for two channels (four unaligned 16-byte
+//     loads each from guard-banded inputs, zeroed outside the image), applies ReLU-on-load and B^T d B in registers
+//     (32 additions per channel) and writes the 16 transformed values into the same fragment layout;
+//   * per position: two ds_read_b128 (A, B) + four MFMAs; both tiles are double-buffered, the loads of step s+1 are in flight
+//     under the MFMAs of step s.
+// Output stage: the 16 position sums of a (channel, tile) pair sit in ONE lane (same register index of the 16 accumulators):
+// A^T M A is 24 additions in registers, then bias / residual / activation and two 8-byte stores per output channel.
+#include <cstdlib>
+#include <type_traits>
+
+#include "conv_args.h"
+
+namespace deva {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef f32x4 f32x4_u __attribute__((aligned(4)));
+
+constexpr int WM = 64, WN = 64;  // output channels x tiles of a workgroup
+constexpr int KC = 8;            // channels per K step
+constexpr int TILE_FLOATS = 16 * 2 * 64 * 4;  // one operand tile of a K step: [p][k parity][row / column][4]
+
+struct WinoArgs {
+  const float* in0;
+  const float* in1;
+  int64_t bs0, bs1;
+  int c0, ctot;
+  int H, W;
+  int tiles_x, tiles_per_img, n_tiles;  // 2x2 output tiles
+  const float* u;  // transformed weights
+  const float* bias;
+  int cout, cout_pad;
+  int relu_in;
+  const float* res;
+  int64_t res_bs;
+  int act;
+  float* out;
+  int blocks_m;
+  int ablate;  // `make PROBES=1` builds only (DEVA_WINO_ABLATE): timing runs with parts of the K loop switched off
+};
+
+#ifdef DEVA_CONV_PROBES  // timing-only ablations (results are wrong): 1 activation transform + stores, 2 weight stores, 4 global loads, 8 barrier, 16 fragment reads
+#define WINO_ABL(bit) (p.ablate & (bit))
+#else
+#define WINO_ABL(bit) false
+#endif
+
+__global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoArgs p) {
+  __shared__ __attribute__((aligned(16))) float sA[2][TILE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float sB[2][TILE_FLOATS];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;  // 32 channels x 32 tiles of the wave
+  // cout blocks fastest: the workgroups that share an activation tile run side by side
+  const int block_m = blockIdx.x % p.blocks_m, block_n = blockIdx.x / p.blocks_m;
+  const int m0 = block_m * WM, n0 = block_n * WN;
+
+  // ---- activation staging: thread = (tile st, channel pair sm): channels 8 s + 2 sm, 8 s + 2 sm + 1
+  const int sm = tid & 3, st = tid >> 2;
+  int64_t s_off0, s_off1;  // element offsets of the patch's first row (clamped) and first column inside in0 / in1 (channel 0)
+  unsigned rmask = 0;      // validity of the four patch rows
+  bool lcol = true, rcol = true;  // patch columns 0 / 3 inside the image (columns 1, 2 always are)
+  int y0;
+  {
+    const int n = min(n0 + st, p.n_tiles - 1);
+    const int b = n / p.tiles_per_img;
+    const int r = n - b * p.tiles_per_img;
+    const int ty = r / p.tiles_x, tx = r - ty * p.tiles_x;
+    y0 = 2 * ty - 1;
+    const int x0 = 2 * tx - 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rmask |= ((unsigned)(y0 + i) < (unsigned)p.H) ? (1u << i) : 0u;
+    lcol = x0 >= 0;
+    rcol = x0 + 3 < p.W;
+    // the 16-byte window starts at column x0 whatever it is: the inputs are guard-banded (ConvArgs::vec_ok), so the element
+    // left of a row's first / right of its last is readable -- it belongs to the neighbouring row and is zeroed below
+    s_off0 = (int64_t)b * p.bs0 + x0;
+    s_off1 = (int64_t)b * p.bs1 + x0;
+  }
+  // interior waves (every tile of the wave has its whole patch inside the image) skip the edge selects
+  const bool edge = __builtin_amdgcn_ballot_w64(rmask != 0xfu || !lcol || !rcol) != 0;
+  const int64_t HW = (int64_t)p.H * p.W;
+  // thread-constant 32-bit element offsets of the eight patch loads (channel of the pair, patch row) and of the weight chunk:
+  // a K step only moves the wave-uniform bases (no per-load address arithmetic in the loop)
+  int poff[2][4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) poff[h][i] = (int)((int64_t)(2 * sm + h) * HW + (int64_t)min(max(y0 + i, 0), p.H - 1) * p.W);
+  const int aoff = ((tid >> 6) * p.cout_pad + (tid & 63)) * 4;  // chunk t; chunk t + 256 i is 4 i segments further
+  const int astride = 4 * p.cout_pad * 4;
+
+  f32x16 acc[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+
+  const int ksteps = p.ctot / KC;
+  // staged operands, TWO sets: the loads of step s + 2 are issued while step s computes and step s + 1's set is written to
+  // LDS (one wave per SIMD: a load that is not back when its data is wanted stalls the matrix pipe, nobody else runs)
+  f32x4 ra[2][8];      // weight tile: 8 x 16 bytes per thread
+  f32x4 rb[2][2][4];   // activation patches: 2 channels x 4 rows
+
+  auto load_step = [&](int s, auto setc) {
+    constexpr int SET = decltype(setc)::value;
+    if (WINO_ABL(4)) return;
+    // weights: 32 segments (p, k parity) of 64 channels x 16 bytes; thread t copies chunks t, t + 256, ...
+    const float* ub = p.u + ((int64_t)s * 32 * p.cout_pad + m0) * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ra[SET][i] = *reinterpret_cast<const f32x4*>(ub + aoff + i * astride);
+    const int c = s * KC;  // (a step never straddles the two sources: c0 % 8 == 0)
+    const float* src = (c < p.c0) ? p.in0 + s_off0 + (int64_t)c * HW : p.in1 + s_off1 + (int64_t)(c - p.c0) * HW;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rb[SET][h][i] = *reinterpret_cast<const f32x4_u*>(src + poff[h][i]);
+  };
+  auto store_a = [&](int buf, auto setc) {
+    constexpr int SET = decltype(setc)::value;
+    if (WINO_ABL(2)) return;
+    float* a = sA[buf];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(a + (tid + 256 * i) * 4) = ra[SET][i];
+  };
+  // channel h of the thread's pair: B^T d B of its patch -> the 16 positions of the activation tile
+  auto store_b = [&](int buf, int h, auto setc) {
+    constexpr int SET = decltype(setc)::value;
+    if (WINO_ABL(1)) return;
+    float* bdst = sB[buf];
+    // the patch d[i][j]: zero outside the image (edge waves only), ReLU on load
+    float d[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4 v = rb[SET][h][i];
+      if (edge) {
+        const bool rok = (rmask >> i) & 1u;
+        v[0] = (rok && lcol) ? v[0] : 0.0f;
+        v[1] = rok ? v[1] : 0.0f;
+        v[2] = rok ? v[2] : 0.0f;
+        v[3] = (rok && rcol) ? v[3] : 0.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[i][j] = p.relu_in ? fmaxf(v[j], 0.0f) : v[j];
+    }
+    // B^T d B on pairs of columns (v_pk_add_f32): rows first, then columns
+    f32x2 w[4][2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const f32x2 d0 = {d[0][2 * jj], d[0][2 * jj + 1]}, d1 = {d[1][2 * jj], d[1][2 * jj + 1]};
+      const f32x2 d2 = {d[2][2 * jj], d[2][2 * jj + 1]}, d3 = {d[3][2 * jj], d[3][2 * jj + 1]};
+      w[0][jj] = d0 - d2;
+      w[1][jj] = d1 + d2;
+      w[2][jj] = d2 - d1;
+      w[3][jj] = d1 - d3;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float w0 = w[i][0][0], w1 = w[i][0][1], w2 = w[i][1][0], w3 = w[i][1][1];
+      const f32x2 lo = f32x2{w0, w1} + f32x2{-w2, w2};  // (w0 - w2, w1 + w2)
+      const f32x2 hi = f32x2{w2, w1} - f32x2{w1, w3};   // (w2 - w1, w1 - w3)
+      // position q = 4 i + l at [(q*2 + h)*64 + tile][sm]
+      bdst[(((4 * i + 0) * 2 + h) * 64 + st) * 4 + sm] = lo[0];
+      bdst[(((4 * i + 1) * 2 + h) * 64 + st) * 4 + sm] = lo[1];
+      bdst[(((4 * i + 2) * 2 + h) * 64 + st) * 4 + sm] = hi[0];
+      bdst[(((4 * i + 3) * 2 + h) * 64 + st) * 4 + sm] = hi[1];
+    }
+  };
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  load_step(0, S0{});
+  store_a(0, S0{});
+  store_b(0, 0, S0{});
+  store_b(0, 1, S0{});
+  if (ksteps > 1) load_step(1, S1{});
+  __syncthreads();
+  // One wave per SIMD: nothing but this wave's own instruction stream hides a latency.  Four positions at a time (consecutive
+  // MFMAs never share an accumulator); the fragments of the next four are read while the 16 MFMAs of the current four run;
+  // the set staged for step s + 1 (loaded during step s - 1) is transformed and written behind the first three groups; the
+  // loads of step s + 2 go out at the top of step s into the other set.
+  f32x4 fa[2][4], fb[2][4];
+  auto step = [&](int s, auto setc) {  // SET = the register set that holds step s + 1 (loaded during step s - 1)
+    constexpr int SET = decltype(setc)::value;
+    using Sx = std::integral_constant<int, SET>;
+    using Sy = std::integral_constant<int, SET ^ 1>;
+    const int buf = s & 1;
+    const bool more = s + 1 < ksteps;
+    const float* a_rd = sA[buf] + (half * 64 + wm * 32 + l31) * 4;
+    const float* b_rd = sB[buf] + (half * 64 + wn * 32 + l31) * 4;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      fa[0][qq] = *reinterpret_cast<const f32x4*>(a_rd + qq * 2 * 64 * 4);
+      fb[0][qq] = *reinterpret_cast<const f32x4*>(b_rd + qq * 2 * 64 * 4);
+    }
+    if (s + 2 < ksteps) load_step(s + 2, Sy{});  // (the other set: written to LDS during step s - 1)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (g + 1 < 4 && !WINO_ABL(16)) {
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          fa[(g + 1) & 1][qq] = *reinterpret_cast<const f32x4*>(a_rd + (4 * (g + 1) + qq) * 2 * 64 * 4);
+          fb[(g + 1) & 1][qq] = *reinterpret_cast<const f32x4*>(b_rd + (4 * (g + 1) + qq) * 2 * 64 * 4);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+          acc[4 * g + qq] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][qq][e], fb[g & 1][qq][e], acc[4 * g + qq], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
+        if (g == 0) store_a(buf ^ 1, Sx{});
+        if (g == 1) store_b(buf ^ 1, 0, Sx{});
+        if (g == 2) store_b(buf ^ 1, 1, Sx{});
+      }
+    }
+    if (!WINO_ABL(8)) __syncthreads();
+  };
+  {
+    int s = 0;
+    for (; s + 2 <= ksteps; s += 2) {
+      step(s, S1{});
+      step(s + 1, S0{});
+    }
+    if (s < ksteps) step(s, S1{});
+  }
+
+  // ---- output stage: Y = A^T M A per (channel, tile), bias / residual / activation, two 8-byte stores per channel
+  const int n = n0 + wn * 32 + l31;
+  if (n >= p.n_tiles) return;
+  const int b = n / p.tiles_per_img;
+  const int rr = n - b * p.tiles_per_img;
+  const int ty = rr / p.tiles_x, tx = rr - ty * p.tiles_x;
+  const int64_t pix = (int64_t)(2 * ty) * p.W + 2 * tx;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (m >= p.cout) continue;
+    float t0[4], t1[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      t0[l] = acc[0 + l][r] + acc[4 + l][r] + acc[8 + l][r];
+      t1[l] = acc[4 + l][r] - acc[8 + l][r] - acc[12 + l][r];
+    }
+    float y[2][2];
+    y[0][0] = t0[0] + t0[1] + t0[2];
+    y[0][1] = t0[1] - t0[2] - t0[3];
+    y[1][0] = t1[0] + t1[1] + t1[2];
+    y[1][1] = t1[1] - t1[2] - t1[3];
+    const float bv = p.bias ? p.bias[m] : 0.0f;
+    const int64_t o = ((int64_t)b * p.cout + m) * HW + pix;
+    const int64_t ro = (int64_t)b * p.res_bs + (int64_t)m * HW + pix;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      f32x2 v = {y[a][0] + bv, y[a][1] + bv};
+      if (p.res) {
+        const f32x2 rv = *reinterpret_cast<const f32x2*>(p.res + ro + (int64_t)a * p.W);
+        v[0] += rv[0];
+        v[1] += rv[1];
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        float x = v[e];
+        if (p.act == DEVA_ACT_RELU) {
+          x = fmaxf(x, 0.0f);
+        } else if (p.act == DEVA_ACT_SIGMOID) {
+          x = sigmoidf_(x);
+        } else if (p.act == DEVA_ACT_SQUARE_PLUS_ONE) {
+          x = x * x + 1.0f;
+        }
+        v[e] = x;
+      }
+      *reinterpret_cast<f32x2*>(p.out + o + (int64_t)a * p.W) = v;
+    }
+  }
+}
+
+}  // namespace
+
+// -> 0 launched, 1 launch error, -1 not eligible (the caller runs the direct kernels)
+int launch_conv_wino(const ConvArgs& a, const float* u, hipStream_t st) {
+  if (!u || !a.vec_ok || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || (a.H & 1) || (a.W & 1) || a.W < 4) return -1;
+  if (a.c0 % KC || a.ctot % KC || a.cout < 32) return -1;
+  if (a.in0_span >= (1ll << 31) || a.in1_span >= (1ll << 31)) return -1;  // 32-bit element offsets inside a source
+  WinoArgs p;
+  p.in0 = a.in0;
+  p.in1 = a.in1 ? a.in1 : a.in0;
+  p.bs0 = a.bs0;
+  p.bs1 = a.bs1;
+  p.c0 = a.c0;
+  p.ctot = a.ctot;
+  p.H = a.H;
+  p.W = a.W;
+  p.tiles_x = a.W / 2;
+  p.tiles_per_img = (a.H / 2) * (a.W / 2);
+  const int batch = a.n_total / a.OHW;
+  p.n_tiles = batch * p.tiles_per_img;
+  p.u = u;
+  p.bias = a.bias;
+  p.cout = a.cout;
+  p.cout_pad = (a.cout + 63) / 64 * 64;
+  p.relu_in = a.relu_in;
+  p.res = a.res;
+  p.res_bs = a.res_bs;
+  p.act = a.act;
+  p.out = a.out;
+  p.blocks_m = p.cout_pad / WM;
+  p.ablate = 0;
+#ifdef DEVA_CONV_PROBES
+  {
+    static const int abl = [] {
+      const char* e = getenv("DEVA_WINO_ABLATE");
+      return e ? atoi(e) : 0;
+    }();
+    p.ablate = abl;
+  }
+#endif
+  const int64_t blocks = (int64_t)p.blocks_m * ceil_div(p.n_tiles, WN);
+  if (blocks < 192) return -1;  // one workgroup per CU at a time: fewer than that and the direct kernels' split-K wins
+  hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+  return check_launch("deva_conv2d (Winograd F(2x2, 3x3))");
+}
+
+}  // namespace deva
+
+// Host-side weight transform (model load): w_oihw [cout][cin][3][3] (BatchNorm folded), cin % 8 == 0 -> U = G g G^T in the
+// layout the kernel stages: element (c, p = 4 i + l, m) at ((((c/8)*16 + p)*2 + c%2)*cout_pad64 + m)*4 + (c%8)/2, cout padded
+// to a multiple of 64 with zeros; computed in fp64, rounded once.  Returns the number of floats (out == NULL: size query), -1 when
+// the layer is not eligible.
+extern "C" int64_t deva_conv_pack_wino(const float* w_oihw, float* out, int cout, int cin) {
+  using namespace deva;
+  if (!w_oihw || cout <= 0 || cin <= 0) {
+    set_error("deva_conv_pack_wino: bad arguments");
+    return -1;
+  }
+  if (cin % 8) return -1;
+  const int cout_pad = (cout + 63) / 64 * 64;
+  const int64_t elems = (int64_t)(cin / 8) * 16 * 2 * cout_pad * 4;
+  if (!out) return elems;
+  for (int64_t i = 0; i < elems; ++i) out[i] = 0.0f;
+  static const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+  for (int m = 0; m < cout; ++m)
+    for (int c = 0; c < cin; ++c) {
+      const float* g = w_oihw + ((int64_t)m * cin + c) * 9;
+      double t[4][3];
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 3; ++j) t[i][j] = G[i][0] * g[0 * 3 + j] + G[i][1] * g[1 * 3 + j] + G[i][2] * g[2 * 3 + j];
+      for (int i = 0; i < 4; ++i)
+        for (int l = 0; l < 4; ++l) {
+          const double u = t[i][0] * G[l][0] + t[i][1] * G[l][1] + t[i][2] * G[l][2];
+          const int q = 4 * i + l;
+          out[((((int64_t)(c / 8) * 16 + q) * 2 + (c & 1)) * cout_pad + m) * 4 + (c % 8) / 2] = (float)u;
+        }
+    }
+  return elems;
+}

@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdeva_hip.so')
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQUARE_PLUS_ONE = 0, 1, 2, 3
 KLAYOUT_TAP_MAJOR, KLAYOUT_CHUNK32 = 0, 1
@@ -36,6 +36,7 @@ class ConvDesc(Structure):
         ('workspace', c_void_p), ('workspace_elems', c_int64),
         ('weight_f16', c_void_p), ('amp', c_int32),
         ('split_scale_log2', c_int32), ('split_flag', c_void_p),
+        ('weight_wino', c_void_p),
     ]
 
 
@@ -46,6 +47,7 @@ SIGNATURES = {
     'deva_conv2d': (c_int, [POINTER(ConvDesc), c_void_p]),
     'deva_conv_pack_f16': (c_int64, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int)]),
     'deva_conv_pack_split': (c_int64, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    'deva_conv_pack_wino': (c_int64, [c_void_p, c_void_p, c_int, c_int]),
     'deva_conv_pack': (c_int64, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     'deva_maxpool3x3s2': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     'deva_upsample2x_add': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

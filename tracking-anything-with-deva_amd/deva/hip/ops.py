@@ -85,6 +85,8 @@ class PackedConv:
     # (None: the layer stays on the fp32 kernels)
     weight_split: Optional[torch.Tensor] = None
     split_scale_log2: int = 0
+    # fp32 Winograd F(2x2, 3x3) (csrc/conv_wino.hip): the weights transformed by deva_conv_pack_wino (None: the direct kernels)
+    weight_wino: Optional[torch.Tensor] = None
 
 
 def pack_f16(w: torch.Tensor) -> Optional[torch.Tensor]:
@@ -134,8 +136,25 @@ def pack_split(w: torch.Tensor) -> Tuple[Optional[torch.Tensor], int]:
     return planes.contiguous().reshape(-1), e
 
 
+def pack_wino(w: torch.Tensor) -> Optional[torch.Tensor]:
+    """[cout][cin][3][3] fp32 (BatchNorm folded) -> the Winograd-transformed weights of deva_conv_pack_wino (None when the
+    layer is not eligible: another kernel size, cin % 8 != 0)"""
+    cout, cin, kh, kw = w.shape
+    if (kh, kw) != (3, 3) or cin % 8:
+        return None
+    w = w.detach().to(torch.float32).cpu().contiguous()
+    L = lib()
+    n = L.deva_conv_pack_wino(w.data_ptr(), None, cout, cin)
+    if n <= 0:
+        return None
+    out = torch.empty(n, dtype=torch.float32)
+    if L.deva_conv_pack_wino(w.data_ptr(), out.data_ptr(), cout, cin) != n:
+        raise DevaHipError(f'deva_conv_pack_wino failed: {L.deva_hip_last_error().decode()}')
+    return out
+
+
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None,
-              device=None, amp: bool = False, split: bool = False) -> PackedConv:
+              device=None, amp: bool = False, split: bool = False, wino: bool = False) -> PackedConv:
     """One-time weight preparation (model load, not the frame path): fold an eval-mode BatchNorm
     `bn = (gamma, beta, running_mean, running_var, eps)` into the convolution and repack
     [cout][cin][kh][kw] -> [kh*kw*cin][cout_pad]."""
@@ -165,13 +184,15 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
         layout |= KLAYOUT_Q4
     w16 = pack_f16(w) if amp else None
     wsp, e = pack_split(w) if split else (None, 0)
+    wwi = pack_wino(w) if wino else None
     if device is not None:
         packed = packed.to(device)
         b = None if b is None else b.to(device)
         w16 = None if w16 is None else w16.to(device)
         wsp = None if wsp is None else wsp.to(device)
+        wwi = None if wwi is None else wwi.to(device)
     return PackedConv(packed.contiguous(), None if b is None else b.contiguous(), cin, cout, cout_pad, kh, kw,
-                      layout, w16, wsp, e)
+                      layout, w16, wsp, e, wwi)
 
 
 GUARD = 8192  # floats of readable slack on both sides of every tensor this module allocates
@@ -343,6 +364,8 @@ def conv2d(pc: PackedConv, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, 
         d.split_scale_log2, d.split_flag = pc.split_scale_log2, _split_flag(out.device)
     else:
         d.weight_f16, d.amp = None, 0
+    # fp32 Winograd for the layers packed with it (taken by the library only where it pays: big 3x3 stride-1 layers)
+    d.weight_wino = _p(pc.weight_wino, name='Winograd weight') if (pc.weight_wino is not None and d.amp == 0) else None
     check(lib().deva_conv2d(d, _stream()), 'deva_conv2d')
     return out
 

@@ -113,9 +113,13 @@ class CompiledGraph:
     # same two: 90 % of the frame's flop at 5 objects); the key encoder and the key projection stay on the fp32 kernels
     # whose FMA order the affinity tests pin, so the inputs of the memory read's top-k do not move by a bit
     SPLIT_SCOPES = AMP_SCOPES
+    # modules whose 3x3 stride-1 convolutions carry Winograd-transformed weights on the plain fp32 path (csrc/conv_wino.hip:
+    # F(2x2, 3x3), 2.25x fewer MFMAs, ~2x the direct kernels' round-off; the library takes it for the big layers only): the same
+    # two scopes -- the key encoder and the key projection keep the direct kernels' arithmetic under the memory read's top-k
+    WINO_SCOPES = AMP_SCOPES
 
     def __init__(self, sd: Dict[str, torch.Tensor], device: torch.device, amp: bool = False, split: bool = False,
-                 split_key_encoder: bool = False):
+                 split_key_encoder: bool = False, winograd: bool = True):
         ops.require_hip(device, 'DEVA network')
         if amp and split:
             raise ValueError('amp (fp16 operands) and f16_split (fp32-accurate on the f16 pipes) are alternatives: pick one')
@@ -123,6 +127,7 @@ class CompiledGraph:
         self.sd = sd
         self.amp = bool(amp)
         self.f16_split = bool(split)
+        self.winograd = bool(winograd) and not amp and not split
         # second level of the opt-in: the key encoder (ResNet-50 stages + the two projections; 6 % of the flop at 5 objects,
         # 3.7 ms of a 1080p frame on the fp32 kernels) on the split kernels too.  Its outputs feed the key projection --
         # which stays on the fp32 kernels either way -- so the memory read's inputs then differ from the fp32 run's by
@@ -138,7 +143,7 @@ class CompiledGraph:
                 continue
             base = name[:-len('.weight')]
             self.convs[base] = ops.pack_conv(sd[name], sd.get(base + '.bias'), self._bn_after(base), device,
-                                             amp=self._amp_of(base), split=self._split_of(base))
+                                             amp=self._amp_of(base), split=self._split_of(base), wino=self._wino_of(base))
         for name, t in sd.items():
             if '.ChannelGate.mlp.' in name:
                 self.vecs[name] = t.detach().float().contiguous().to(device)
@@ -175,11 +180,15 @@ class CompiledGraph:
     def _split_of(self, base: str) -> bool:
         return self.f16_split and base.startswith(self.split_scopes)
 
+    def _wino_of(self, base: str) -> bool:
+        return self.winograd and base.startswith(self.WINO_SCOPES)
+
     def _split_pack(self, base: str, cx: int) -> Tuple[PackedConv, PackedConv]:
         """(image part without bias, per-object part with the bias) of convolution `base`, BatchNorm folded"""
         w, b = self._folded(base)
-        return (ops.pack_conv(w[:, :cx].contiguous(), None, None, self.device, amp=self._amp_of(base), split=self._split_of(base)),
-                ops.pack_conv(w[:, cx:].contiguous(), b, None, self.device, amp=self._amp_of(base), split=self._split_of(base)))
+        kw = dict(amp=self._amp_of(base), split=self._split_of(base), wino=self._wino_of(base))
+        return (ops.pack_conv(w[:, :cx].contiguous(), None, None, self.device, **kw),
+                ops.pack_conv(w[:, cx:].contiguous(), b, None, self.device, **kw))
 
     def _conv(self, base: str, *inputs, **kw):
         """convolution `base` of the value encoder / mask decoder: fp16 operands under --amp, the hi/lo split under

@@ -32,6 +32,9 @@ class DEVA(nn.Module):
         if self.amp and self.f16_split:
             raise ValueError('--amp and --f16_split are alternatives: pick one')
         # --f16_split_key_encoder: the key encoder on the split kernels as well (deva/model/_graph.py:split_scopes)
+        # fp32 path: Winograd F(2x2, 3x3) for the big 3x3 layers of the value encoder / mask decoder (csrc/conv_wino.hip); on by
+        # default, --no_winograd keeps every layer on the direct kernels (the arithmetic order of rounds 1-5)
+        self.winograd = not bool(config.get('no_winograd', False))
         self.f16_split_key_encoder = bool(config.get('f16_split_key_encoder', False))
         if self.f16_split_key_encoder and not self.f16_split:
             raise ValueError('--f16_split_key_encoder extends --f16_split: pass both')
@@ -59,7 +62,7 @@ class DEVA(nn.Module):
         if self._graph is None:
             device = next(self.parameters()).device
             self._graph = CompiledGraph(self.state_dict(), device, amp=self.amp, split=self.f16_split,
-                                        split_key_encoder=self.f16_split_key_encoder)
+                                        split_key_encoder=self.f16_split_key_encoder, winograd=self.winograd)
         return self._graph
 
     # ------------------------------------------------------------------ reference API
