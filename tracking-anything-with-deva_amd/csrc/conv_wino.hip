@@ -16,13 +16,15 @@
 //     four MFMAs of a position are one 16-byte read) go global -> LDS as they are;
 //   * activations: thread (tile, channel pair) loads the 4x4 patch of its tile for two channels (four unaligned 16-byte
 //     loads each from guard-banded inputs, zeroed outside the image), applies ReLU-on-load and B^T d B in registers
-//     (32 additions per channel) and writes the 16 transformed values into the same fragment layout;
+//     (32 additions per channel) and writes the 16 transformed values as [p][k parity][k/2][tile] (a wave = one channel pair
+//     of all 64 tiles: contiguous loads, conflict-free stores; the B fragment of a position is four 4-byte reads);
 //   * per position: two ds_read_b128 (A, B) + four MFMAs; both tiles are double-buffered, the loads of step s+1 are in flight
 //     under the MFMAs of step s.
 // Output stage: the 16 position sums of a (channel, tile) pair sit in ONE lane (same register index of the 16 accumulators):
 // A^T M A is 24 additions in registers, then bias / residual / activation and two 8-byte stores per output channel.
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "conv_args.h"
 
@@ -33,6 +35,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef f32x4 f32x4_u __attribute__((aligned(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+// f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}): loop bodies whose index is a compile-time
+// constant (register-set and buffer indices)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 constexpr int WM = 64, WN = 64;  // output channels x tiles of a workgroup
 constexpr int KC = 8;            // channels per K step
@@ -63,6 +83,7 @@ struct WinoArgs {
 #define WINO_ABL(bit) false
 #endif
 
+template <bool RELU>  // ReLU on the input elements (F.relu before the convolution)
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoArgs p) {
   __shared__ __attribute__((aligned(16))) float sA[2][TILE_FLOATS];
   __shared__ __attribute__((aligned(16))) float sB[2][TILE_FLOATS];
@@ -75,8 +96,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoArgs p) {
   const int block_m = blockIdx.x % p.blocks_m, block_n = blockIdx.x / p.blocks_m;
   const int m0 = block_m * WM, n0 = block_n * WN;
 
-  // ---- activation staging: thread = (tile st, channel pair sm): channels 8 s + 2 sm, 8 s + 2 sm + 1
-  const int sm = tid & 3, st = tid >> 2;
+  // ---- activation staging: thread = (channel pair sm = wave, tile st = lane): channels 8 s + 2 sm, 8 s + 2 sm + 1
+  const int sm = tid >> 6, st = tid & 63;  // a wave loads ONE channel pair for the 64 tiles: every load is one contiguous row segment
   int64_t s_off0, s_off1;  // element offsets of the patch's first row (clamped) and first column inside in0 / in1 (channel 0)
   unsigned rmask = 0;      // validity of the four patch rows
   bool lcol = true, rcol = true;  // patch columns 0 / 3 inside the image (columns 1, 2 always are)
@@ -102,13 +123,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoArgs p) {
   const int64_t HW = (int64_t)p.H * p.W;
   // thread-constant 32-bit element offsets of the eight patch loads (channel of the pair, patch row) and of the weight chunk:
   // a K step only moves the wave-uniform bases (no per-load address arithmetic in the loop)
+  // (BYTE offsets for buffer loads: wave-uniform base in the descriptor, thread offset in a register, no address arithmetic)
   int poff[2][4];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) poff[h][i] = (int)((int64_t)(2 * sm + h) * HW + (int64_t)min(max(y0 + i, 0), p.H - 1) * p.W);
-  const int aoff = ((tid >> 6) * p.cout_pad + (tid & 63)) * 4;  // chunk t; chunk t + 256 i is 4 i segments further
-  const int astride = 4 * p.cout_pad * 4;
+    for (int i = 0; i < 4; ++i) poff[h][i] = (int)(((int64_t)(2 * sm + h) * HW + (int64_t)min(max(y0 + i, 0), p.H - 1) * p.W) * 4);
+  const int aoff = ((tid >> 6) * p.cout_pad + (tid & 63)) * 16;  // chunk t; chunk t + 256 i is 4 i segments further
+  const int astride = 4 * p.cout_pad * 16;
+  const int poff_b0 = (int)(s_off0 * 4), poff_b1 = (int)(s_off1 * 4);  // batch item + first column (may be -4: the guard band)
 
   f32x16 acc[16];
 #pragma unroll
@@ -122,19 +145,26 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoArgs p) {
   f32x4 ra[2][8];      // weight tile: 8 x 16 bytes per thread
   f32x4 rb[2][2][4];   // activation patches: 2 channels x 4 rows
 
+  // load `idx` (0..7: weight chunk, 8..15: patch row (idx - 8) % 4 of channel (idx - 8) / 4) of step s into set SET
+  // (measured and dropped: one load behind every fourth MFMA instead of the burst at the top of a step -- 40 % slower)
+  auto load_one = [&](int s, auto setc, auto idxc) {
+    constexpr int SET = decltype(setc)::value, IDX = decltype(idxc)::value;
+    if (WINO_ABL(4) || (IDX < 8 && WINO_ABL(32)) || (IDX >= 8 && WINO_ABL(64))) return;  // 32: no weight loads, 64: no patch loads
+    if constexpr (IDX < 8) {
+      const float* ub = p.u + ((int64_t)s * 32 * p.cout_pad + m0) * 4;
+      ra[SET][IDX] = buf_load4(make_rsrc(ub, 0x7fffffff), aoff, IDX * astride);
+    } else {
+      constexpr int H = (IDX - 8) / 4, I = (IDX - 8) % 4;
+      const int c = s * KC;  // (a step never straddles the two sources: c0 % 8 == 0)
+      const bool first = c < p.c0;
+      // the descriptor starts 16 bytes BEFORE the step's first channel plane (offsets are unsigned: a tile at column 0 of the
+      // first row of the first image reads one element in front of the tensor, into the guard band)
+      const float* base = (first ? p.in0 + (int64_t)c * HW : p.in1 + (int64_t)(c - p.c0) * HW) - 4;
+      rb[SET][H][I] = buf_load4(make_rsrc(base, 0x7fffffff), (first ? poff_b0 : poff_b1) + poff[H][I] + 16, 0);
+    }
+  };
   auto load_step = [&](int s, auto setc) {
-    constexpr int SET = decltype(setc)::value;
-    if (WINO_ABL(4)) return;
-    // weights: 32 segments (p, k parity) of 64 channels x 16 bytes; thread t copies chunks t, t + 256, ...
-    const float* ub = p.u + ((int64_t)s * 32 * p.cout_pad + m0) * 4;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) ra[SET][i] = *reinterpret_cast<const f32x4*>(ub + aoff + i * astride);
-    const int c = s * KC;  // (a step never straddles the two sources: c0 % 8 == 0)
-    const float* src = (c < p.c0) ? p.in0 + s_off0 + (int64_t)c * HW : p.in1 + s_off1 + (int64_t)(c - p.c0) * HW;
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) rb[SET][h][i] = *reinterpret_cast<const f32x4_u*>(src + poff[h][i]);
+    static_for<16>([&](auto k) { load_one(s, setc, k); });
   };
   auto store_a = [&](int buf, auto setc) {
     constexpr int SET = decltype(setc)::value;
@@ -153,7 +183,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       f32x4 v = rb[SET][h][i];
-      if (edge) {
+      if (edge) {  // (wave-uniform)
         const bool rok = (rmask >> i) & 1u;
         v[0] = (rok && lcol) ? v[0] : 0.0f;
         v[1] = rok ? v[1] : 0.0f;
@@ -161,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoArgs p) {
         v[3] = (rok && rcol) ? v[3] : 0.0f;
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) d[i][j] = p.relu_in ? fmaxf(v[j], 0.0f) : v[j];
+      for (int j = 0; j < 4; ++j) d[i][j] = RELU ? fmaxf(v[j], 0.0f) : v[j];
     }
     // B^T d B on pairs of columns (v_pk_add_f32): rows first, then columns
     f32x2 w[4][2];
@@ -179,11 +209,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoArgs p) {
       const float w0 = w[i][0][0], w1 = w[i][0][1], w2 = w[i][1][0], w3 = w[i][1][1];
       const f32x2 lo = f32x2{w0, w1} + f32x2{-w2, w2};  // (w0 - w2, w1 + w2)
       const f32x2 hi = f32x2{w2, w1} - f32x2{w1, w3};   // (w2 - w1, w1 - w3)
-      // position q = 4 i + l at [(q*2 + h)*64 + tile][sm]
-      bdst[(((4 * i + 0) * 2 + h) * 64 + st) * 4 + sm] = lo[0];
-      bdst[(((4 * i + 1) * 2 + h) * 64 + st) * 4 + sm] = lo[1];
-      bdst[(((4 * i + 2) * 2 + h) * 64 + st) * 4 + sm] = hi[0];
-      bdst[(((4 * i + 3) * 2 + h) * 64 + st) * 4 + sm] = hi[1];
+      // position q = 4 i + l at [(q*2 + h)*4 + sm][tile]: consecutive lanes write consecutive floats
+      bdst[(((4 * i + 0) * 2 + h) * 4 + sm) * 64 + st] = lo[0];
+      bdst[(((4 * i + 1) * 2 + h) * 4 + sm) * 64 + st] = lo[1];
+      bdst[(((4 * i + 2) * 2 + h) * 4 + sm) * 64 + st] = hi[0];
+      bdst[(((4 * i + 3) * 2 + h) * 4 + sm) * 64 + st] = hi[1];
     }
   };
 
@@ -200,51 +230,73 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoArgs p) {
   // the set staged for step s + 1 (loaded during step s - 1) is transformed and written behind the first three groups; the
   // loads of step s + 2 go out at the top of step s into the other set.
   f32x4 fa[2][4], fb[2][4];
-  auto step = [&](int s, auto setc) {  // SET = the register set that holds step s + 1 (loaded during step s - 1)
+  auto step = [&](int s, auto setc, auto fullc) {  // SET = the register set that holds step s + 1 (loaded during step s - 1)
     constexpr int SET = decltype(setc)::value;
+    constexpr bool FULL = decltype(fullc)::value;  // steps s + 1 and s + 2 exist: no conditions, the step is ONE basic block
     using Sx = std::integral_constant<int, SET>;
     using Sy = std::integral_constant<int, SET ^ 1>;
     const int buf = s & 1;
-    const bool more = s + 1 < ksteps;
+    const bool more = FULL || s + 1 < ksteps;
     const float* a_rd = sA[buf] + (half * 64 + wm * 32 + l31) * 4;
-    const float* b_rd = sB[buf] + (half * 64 + wn * 32 + l31) * 4;
+    const float* b_rd = sB[buf] + half * 4 * 64 + wn * 32 + l31;  // [(q*2 + half)*4 + e][tile]
+    auto read_b = [&](int q) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = b_rd[(q * 2 * 4 + e) * 64];
+      return v;
+    };
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
       fa[0][qq] = *reinterpret_cast<const f32x4*>(a_rd + qq * 2 * 64 * 4);
-      fb[0][qq] = *reinterpret_cast<const f32x4*>(b_rd + qq * 2 * 64 * 4);
+      fb[0][qq] = read_b(qq);
     }
-    if (s + 2 < ksteps) load_step(s + 2, Sy{});  // (the other set: written to LDS during step s - 1)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    if (FULL || s + 2 < ksteps) load_step(s + 2, Sy{});  // the other set (written to LDS during step s - 1)
+    static_for<4>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
       if (g + 1 < 4 && !WINO_ABL(16)) {
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
           fa[(g + 1) & 1][qq] = *reinterpret_cast<const f32x4*>(a_rd + (4 * (g + 1) + qq) * 2 * 64 * 4);
-          fb[(g + 1) & 1][qq] = *reinterpret_cast<const f32x4*>(b_rd + (4 * (g + 1) + qq) * 2 * 64 * 4);
+          fb[(g + 1) & 1][qq] = read_b(4 * (g + 1) + qq);
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
+      static_for<4>([&](auto ec) {
+        constexpr int e = decltype(ec)::value;
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq)
           acc[4 * g + qq] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][qq][e], fb[g & 1][qq][e], acc[4 * g + qq], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+      });
       if (more) {
         if (g == 0) store_a(buf ^ 1, Sx{});
         if (g == 1) store_b(buf ^ 1, 0, Sx{});
         if (g == 2) store_b(buf ^ 1, 1, Sx{});
+      }
+    });
+    if (FULL) {
+      // the wave is alone on its SIMD: what it issues between two MFMAs is free only if it is spread evenly -- two LDS reads, a
+      // few VALU instructions, one LDS write behind every MFMA, a global load behind every fourth
+#pragma unroll
+      for (int j = 0; j < 64; ++j) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // VALU
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+        if ((j & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
       }
     }
     if (!WINO_ABL(8)) __syncthreads();
   };
   {
     int s = 0;
-    for (; s + 2 <= ksteps; s += 2) {
-      step(s, S1{});
-      step(s + 1, S0{});
+    for (; s + 4 <= ksteps; s += 2) {  // steps s + 2, s + 3 exist
+      step(s, S1{}, std::true_type{});
+      step(s + 1, S0{}, std::true_type{});
     }
-    if (s < ksteps) step(s, S1{});
+    for (; s + 2 <= ksteps; s += 2) {
+      step(s, S1{}, std::false_type{});
+      step(s + 1, S0{}, std::false_type{});
+    }
+    if (s < ksteps) step(s, S1{}, std::false_type{});
   }
 
   // ---- output stage: Y = A^T M A per (channel, tile), bias / residual / activation, two 8-byte stores per channel
@@ -303,7 +355,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoArgs p) {
 int launch_conv_wino(const ConvArgs& a, const float* u, hipStream_t st) {
   if (!u || !a.vec_ok || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || (a.H & 1) || (a.W & 1) || a.W < 4) return -1;
   if (a.c0 % KC || a.ctot % KC || a.cout < 32) return -1;
-  if (a.in0_span >= (1ll << 31) || a.in1_span >= (1ll << 31)) return -1;  // 32-bit element offsets inside a source
+  if (a.in0_span >= (1ll << 29) || a.in1_span >= (1ll << 29)) return -1;  // 32-bit byte offsets inside a source (buffer loads)
   WinoArgs p;
   p.in0 = a.in0;
   p.in1 = a.in1 ? a.in1 : a.in0;
@@ -339,7 +391,11 @@ int launch_conv_wino(const ConvArgs& a, const float* u, hipStream_t st) {
 #endif
   const int64_t blocks = (int64_t)p.blocks_m * ceil_div(p.n_tiles, WN);
   if (blocks < 192) return -1;  // one workgroup per CU at a time: fewer than that and the direct kernels' split-K wins
-  hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+  if (p.relu_in) {
+    hipLaunchKernelGGL(conv_wino_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+  } else {
+    hipLaunchKernelGGL(conv_wino_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+  }
   return check_launch("deva_conv2d (Winograd F(2x2, 3x3))");
 }
 
