@@ -82,7 +82,7 @@ def conv_source_sha1():
     import hashlib
     h = hashlib.sha1()
     d = os.path.join(ROOT, 'tracking-anything-with-deva_amd', 'csrc')
-    for name in ('conv_args.h', 'conv_epilogue.h', 'conv_igemm.hip', 'conv_mfma.hip', 'conv_cout1.hip', 'common.h'):
+    for name in ('conv_args.h', 'conv_epilogue.h', 'conv_igemm.hip', 'conv_mfma.hip', 'conv_wino.hip', 'conv_cout1.hip', 'common.h'):
         with open(os.path.join(d, name), 'rb') as f:
             h.update(f.read())
     return h.hexdigest()
@@ -204,6 +204,13 @@ class ConvTimer:
             f16 = bool(d.amp and d.weight_f16 and d.stride == 1 and d.cout >= 64 and ((d.c0 % gran == 0 and d.c1 % gran == 0) or tail_ok)
                        and ((d.kh == 1 and d.pad == 0) or (d.kh == 3 and d.pad == 1)) and (oh * ow) % 4 == 0 and ow >= 4)
             f16 = (d.amp if f16 else 0)
+            # fp32 Winograd F(2x2, 3x3) (csrc/conv_wino.hip: launch_conv_wino's rule): 16 instead of 36 multiply-adds per input
+            # channel and 2x2 outputs -- class 3; its ALGORITHMIC flops (the direct count) stay what `achieved` is made of
+            if (not d.amp and d.weight_wino and d.kh == 3 and d.kw == 3 and d.stride == 1 and d.pad == 1 and d.height % 2 == 0
+                    and d.width % 2 == 0 and d.width >= 4 and d.c0 % 8 == 0 and cin % 8 == 0 and d.cout >= 32
+                    and (d.height * d.width) % 4 == 0
+                    and ((d.cout + 63) // 64) * ((d.batch * (d.height // 2) * (d.width // 2) + 63) // 64) >= 192):
+                f16 = 3
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             self._space(stream)
             s.record()
@@ -245,9 +252,9 @@ class ConvTimer:
     def split_by_precision(self):
         """-> {'f16': (flops, ms, launches), 'split': (...), 'f32': (...)}: launches the fp16-operand kernels took, the
         hi/lo split kernels took (with their gated fp32 launch behind them), and the plain fp32 ones"""
-        out = {'f16': [0.0, 0.0, 0], 'split': [0.0, 0.0, 0], 'f32': [0.0, 0.0, 0]}
+        out = {'f16': [0.0, 0.0, 0], 'split': [0.0, 0.0, 0], 'f32': [0.0, 0.0, 0], 'wino': [0.0, 0.0, 0]}
         for r in self.records:
-            o = out[{0: 'f32', 1: 'f16', 2: 'split'}[int(r[5])]]
+            o = out[{0: 'f32', 1: 'f16', 2: 'split', 3: 'wino'}[int(r[5])]]
             o[0] += r[0]
             o[1] += r[1].elapsed_time(r[2])
             o[2] += 1
@@ -293,6 +300,11 @@ def conv_roofline_report(ct, frames):
             e['f16_mfma_tflops_issued (3 MFMAs per block)'] = 3 * tf
             e['frac_of_f16_mfma_peak'] = 3 * tf / PEAK_F16_MATRIX_TFLOPS
             e['vs_fp32_matrix_peak'] = tf / PEAK_FP32_MATRIX_TFLOPS
+        elif name == 'wino':
+            e['algorithmic_tflops'] = tf
+            e['mfma_tflops_executed (16 of 36 multiply-adds)'] = tf / 2.25
+            e['algorithmic_over_fp32_mfma_peak'] = tf / PEAK_FP32_MATRIX_TFLOPS
+            e['executed_frac_of_fp32_mfma_peak'] = tf / 2.25 / PEAK_FP32_MATRIX_TFLOPS
         else:
             e['frac_of_fp32_mfma_peak'] = tf / PEAK_FP32_MATRIX_TFLOPS
         out[name + '_kernels'] = e
@@ -993,7 +1005,8 @@ def extra_lines(net, device, cfg, args):
 LINE_LIMIT = 4096  # bytes of the final stdout line (a 27 KB line was not read back by the driver)
 CONTRACT_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
                  'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'rccl_ranks')
-ROOFLINE_KEYS = ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_over_algorithmic',
+ROOFLINE_KEYS = ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'mfma_executed_frac', 'winograd_share_of_algorithmic_flops',
+                 'traffic', 'traffic_over_algorithmic',
                  'gflop_per_frame', 'ms_in_kernel_per_frame', 'launches_per_frame', 'algorithmic_bytes_per_frame',
                  'frac_of_sustained_probe')
 CPU_KEYS = ('value', 'unit', 'cores', 'kind', 'range_fps', 'stage_ms_per_frame', 'sample')
@@ -1027,7 +1040,7 @@ def compact_line(result):
     if 'roofline' in result:
         r = result['roofline']
         out = {k: r[k] for k in ROOFLINE_KEYS if k in r}
-        out['kernel'] = 'conv_mfma_kernel / conv_igemm_kernel (fp32 MFMA implicit GEMM)'
+        out['kernel'] = 'conv_mfma_kernel (direct) + conv_wino_kernel (Winograd F(2x2,3x3)), fp32 MFMA; achieved = algorithmic flops / time'
         out.update({k: v for k, v in r.items() if k.startswith(('affinity_', 'f16_split_frac_of_f16_peak_', 'f16_split_traffic_'))
                     and not isinstance(v, (dict, list, str))})
         p = r.get('sustained_mfma_probe')
@@ -1198,9 +1211,18 @@ def main():
             with open(os.environ['DEVA_BENCH_LAYERS'], 'w') as f:
                 json.dump(ct.per_layer(n_replay), f, indent=1)
         ach = flops / (ms * 1e-3) / 1e12
+        by_class = ct.split_by_precision()
+        wf, wms, wn = by_class['wino']
         result['roofline'] = {
-            'kernel': 'conv_mfma_kernel / conv_igemm_kernel (+ splitk_reduce_kernel / conv_cout1 kernels of the same '
-                      'deva_conv2d call), fp32 MFMA implicit GEMM',
+            'kernel': 'conv_mfma_kernel (direct implicit GEMM) + conv_wino_kernel (Winograd F(2x2, 3x3) for the big 3x3 layers) '
+                      '(+ splitk_reduce_kernel / conv_cout1 kernels of the same deva_conv2d call), fp32 MFMA',
+            # `achieved` counts ALGORITHMIC flops (2 K cout pixels of every convolution, the direct count); the Winograd layers
+            # execute 1 / 2.25 of theirs on the matrix pipes -- the matrix pipes' own utilisation is `mfma_executed_frac`
+            'winograd_share_of_algorithmic_flops': wf / max(flops, 1.0),
+            'winograd_ms_per_frame': wms / args.steps,
+            'winograd_algorithmic_tflops': wf / max(wms, 1e-9) / 1e9,
+            'mfma_executed_tflops': (flops - wf * (1 - 1 / 2.25)) / (ms * 1e-3) / 1e12,
+            'mfma_executed_frac': (flops - wf * (1 - 1 / 2.25)) / (ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
             'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MATRIX_TFLOPS, 'unit': 'TFLOP/s',
             'frac': ach / PEAK_FP32_MATRIX_TFLOPS, 'traffic': None,
             'method': 'HIP events around every deva_conv2d launch on the launch stream, no synchronisation, '

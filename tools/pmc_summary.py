@@ -41,7 +41,7 @@ def _conv_sha1():
     import os
     h = hashlib.sha1()
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tracking-anything-with-deva_amd', 'csrc')
-    for name in ('conv_args.h', 'conv_epilogue.h', 'conv_igemm.hip', 'conv_mfma.hip', 'conv_cout1.hip', 'common.h'):
+    for name in ('conv_args.h', 'conv_epilogue.h', 'conv_igemm.hip', 'conv_mfma.hip', 'conv_wino.hip', 'conv_cout1.hip', 'common.h'):
         with open(os.path.join(d, name), 'rb') as f:
             h.update(f.read())
     return h.hexdigest()
