@@ -386,7 +386,7 @@ def test_conv_wino_matches_cpu(case):
 
 
 def test_conv_wino_small_layers_stay_on_the_direct_kernels():
-    """fewer than 192 workgroups of 64 channels x 64 tiles (the batch-1 layers of a 480p frame): the library ignores the
+    """fewer than 160 workgroups of 64 channels x 64 tiles (most batch-1 layers of a 480p frame): the library ignores the
     transformed weights -- bit-identical to the call without them; so do odd map sizes"""
     g = torch.Generator().manual_seed(8)
     w = rand(g, 64, 64, 3, 3, scale=0.05)

@@ -43,6 +43,18 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, int voff, i
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
+// packed fp32 additions, written out: on scalars the compiler prefers 2 x v_add_f32 (and builds shuffled pairs with moves)
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}): loop bodies whose index is a compile-time
 // constant (register-set and buffer indices)
 template <class F, int... I>
@@ -83,7 +95,10 @@ struct WinoArgs {
 #define WINO_ABL(bit) false
 #endif
 
-template <bool RELU>  // ReLU on the input elements (F.relu before the convolution)
+// RELU: ReLU on the input elements (F.relu before the convolution); RES: a residual is added.  The two choose between code
+// paths that compute the same thing: the kernel is ONE wave per SIMD at the register limit and its speed follows the exact
+// schedule -- each variant keeps the form that measured fastest for it (tools/convlab --wino).
+template <bool RELU, bool RES>
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoArgs p) {
   __shared__ __attribute__((aligned(16))) float sA[2][TILE_FLOATS];
   __shared__ __attribute__((aligned(16))) float sB[2][TILE_FLOATS];
@@ -118,8 +133,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoArgs p) {
     s_off0 = (int64_t)b * p.bs0 + x0;
     s_off1 = (int64_t)b * p.bs1 + x0;
   }
-  // interior waves (every tile of the wave has its whole patch inside the image) skip the edge selects
+  // (!RELU) interior waves (every tile of the wave has its whole patch inside the image) skip the edge selects
   const bool edge = __builtin_amdgcn_ballot_w64(rmask != 0xfu || !lcol || !rcol) != 0;
+  float pinf = __builtin_inff();
+  asm("" : "+v"(pinf));  // (a limit the compiler cannot see through: median(x, 0, +inf) folds to a max WITH the canonicalising max in front)
+  const float llim = lcol ? __builtin_inff() : 0.0f, rlim = rcol ? __builtin_inff() : 0.0f;  // (ReLU-on-load variant)
   const int64_t HW = (int64_t)p.H * p.W;
   // thread-constant 32-bit element offsets of the eight patch loads (channel of the pair, patch row) and of the weight chunk:
   // a K step only moves the wave-uniform bases (no per-load address arithmetic in the loop)
@@ -128,7 +146,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoArgs p) {
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) poff[h][i] = (int)(((int64_t)(2 * sm + h) * HW + (int64_t)min(max(y0 + i, 0), p.H - 1) * p.W) * 4);
+    for (int i = 0; i < 4; ++i) {
+      // RELU variant: a patch row outside the image gets an offset beyond the descriptor's range -- the load returns zeros;
+      // the other variant clamps the row and zeroes it with the column selects
+      const bool oob = RELU && !((rmask >> i) & 1u);
+      poff[h][i] = oob ? (int)0x80000000 : (int)(((int64_t)(2 * sm + h) * HW + (int64_t)min(max(y0 + i, 0), p.H - 1) * p.W) * 4);
+    }
   const int aoff = ((tid >> 6) * p.cout_pad + (tid & 63)) * 16;  // chunk t; chunk t + 256 i is 4 i segments further
   const int astride = 4 * p.cout_pad * 16;
   const int poff_b0 = (int)(s_off0 * 4), poff_b1 = (int)(s_off1 * 4);  // batch item + first column (may be -4: the guard band)
@@ -173,8 +196,55 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoArgs p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(a + (tid + 256 * i) * 4) = ra[SET][i];
   };
-  // channel h of the thread's pair: B^T d B of its patch -> the 16 positions of the activation tile
-  auto store_b = [&](int buf, int h, auto setc) {
+  // channel h of the thread's pair: B^T d B of its patch -> the 16 positions of the activation tile.  Two forms:
+  // (RELU) 16 medians + 16 packed additions per channel
+  auto store_b_pk = [&](int buf, int h, auto setc) {
+    constexpr int SET = decltype(setc)::value;
+    if (WINO_ABL(1)) return;
+    float* bdst = sB[buf];
+    // the patch rows as column pairs (0, 1) and (2, 3).  Rows outside the image came back as zeros (out-of-range offsets);
+    // columns 0 / 3 outside it (the neighbouring row's element, or the guard band) are zeroed here.  ReLU on load is ONE
+    // instruction per element (median of x, 0, limit: limit = +inf, or 0 for a masked column; no NaN canonicalisation in
+    // front of it as with v_max), the column mask alone a select.
+    f32x2 dl[4], dr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 v = rb[SET][h][i];
+      if (RELU) {
+        dl[i] = f32x2{__builtin_amdgcn_fmed3f(v[0], 0.0f, llim), __builtin_amdgcn_fmed3f(v[1], 0.0f, pinf)};
+        dr[i] = f32x2{__builtin_amdgcn_fmed3f(v[2], 0.0f, pinf), __builtin_amdgcn_fmed3f(v[3], 0.0f, rlim)};
+      } else {
+        dl[i] = f32x2{lcol ? v[0] : 0.0f, v[1]};
+        dr[i] = f32x2{v[2], rcol ? v[3] : 0.0f};
+      }
+    }
+    // B^T d B, 16 packed additions per channel: rows first (on the column pairs as they are), then columns -- the second
+    // pass combines elements ACROSS the two pairs of a row, which v_pk_add_f32 does in one instruction through its operand
+    // selectors (the compiler builds the shuffled pairs with moves instead: written out)
+    f32x2 wl[4], wr[4];
+    wl[0] = pk_sub(dl[0], dl[2]);
+    wl[1] = pk_add(dl[1], dl[2]);
+    wl[2] = pk_sub(dl[2], dl[1]);
+    wl[3] = pk_sub(dl[1], dl[3]);
+    wr[0] = pk_sub(dr[0], dr[2]);
+    wr[1] = pk_add(dr[1], dr[2]);
+    wr[2] = pk_sub(dr[2], dr[1]);
+    wr[3] = pk_sub(dr[1], dr[3]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x2 lo, hi;  // (w0 - w2, w1 + w2), (w2 - w1, w1 - w3) of the row (w0, w1 | w2, w3)
+      asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(lo) : "v"(wl[i]), "v"(wr[i]));
+      asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(hi) : "v"(wr[i]), "v"(wl[i]));
+      // position q = 4 i + l at [(q*2 + h)*4 + sm][tile]: consecutive lanes write consecutive floats
+      bdst[(((4 * i + 0) * 2 + h) * 4 + sm) * 64 + st] = lo[0];
+      bdst[(((4 * i + 1) * 2 + h) * 4 + sm) * 64 + st] = lo[1];
+      bdst[(((4 * i + 2) * 2 + h) * 4 + sm) * 64 + st] = hi[0];
+      bdst[(((4 * i + 3) * 2 + h) * 4 + sm) * 64 + st] = hi[1];
+    }
+  };
+
+  // (!RELU) selects on edge waves, additions as the compiler forms them
+  auto store_b_sel = [&](int buf, int h, auto setc) {
     constexpr int SET = decltype(setc)::value;
     if (WINO_ABL(1)) return;
     float* bdst = sB[buf];
@@ -191,7 +261,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoArgs p) {
         v[3] = (rok && rcol) ? v[3] : 0.0f;
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) d[i][j] = RELU ? fmaxf(v[j], 0.0f) : v[j];
+      for (int j = 0; j < 4; ++j) d[i][j] = v[j];
     }
     // B^T d B on pairs of columns (v_pk_add_f32): rows first, then columns
     f32x2 w[4][2];
@@ -217,6 +287,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoArgs p) {
     }
   };
 
+  auto store_b = [&](int buf, int h, auto setc) {
+    if constexpr (RELU) {
+      store_b_pk(buf, h, setc);
+    } else {
+      store_b_sel(buf, h, setc);
+    }
+  };
+  using MODE_TAIL = std::integral_constant<int, 0>;
+  using MODE_FULL = std::integral_constant<int, 1>;
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
   load_step(0, S0{});
@@ -232,7 +311,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoArgs p) {
   f32x4 fa[2][4], fb[2][4];
   auto step = [&](int s, auto setc, auto fullc) {  // SET = the register set that holds step s + 1 (loaded during step s - 1)
     constexpr int SET = decltype(setc)::value;
-    constexpr bool FULL = decltype(fullc)::value;  // steps s + 1 and s + 2 exist: no conditions, the step is ONE basic block
+    constexpr int MODE = decltype(fullc)::value;
+    constexpr bool FULL = MODE == 1;  // steps s + 1 and s + 2 exist: no conditions, the step is ONE basic block
     using Sx = std::integral_constant<int, SET>;
     using Sy = std::integral_constant<int, SET ^ 1>;
     const int buf = s & 1;
@@ -289,62 +369,134 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoArgs p) {
   {
     int s = 0;
     for (; s + 4 <= ksteps; s += 2) {  // steps s + 2, s + 3 exist
-      step(s, S1{}, std::true_type{});
-      step(s + 1, S0{}, std::true_type{});
+      step(s, S1{}, MODE_FULL{});
+      step(s + 1, S0{}, MODE_FULL{});
     }
     for (; s + 2 <= ksteps; s += 2) {
-      step(s, S1{}, std::false_type{});
-      step(s + 1, S0{}, std::false_type{});
+      step(s, S1{}, MODE_TAIL{});
+      step(s + 1, S0{}, MODE_TAIL{});
     }
-    if (s < ksteps) step(s, S1{}, std::false_type{});
+    if (s < ksteps) step(s, S1{}, MODE_TAIL{});
   }
-
-  // ---- output stage: Y = A^T M A per (channel, tile), bias / residual / activation, two 8-byte stores per channel
-  const int n = n0 + wn * 32 + l31;
-  if (n >= p.n_tiles) return;
-  const int b = n / p.tiles_per_img;
-  const int rr = n - b * p.tiles_per_img;
-  const int ty = rr / p.tiles_x, tx = rr - ty * p.tiles_x;
-  const int64_t pix = (int64_t)(2 * ty) * p.W + 2 * tx;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    if (m >= p.cout) continue;
-    float t0[4], t1[4];
-#pragma unroll
-    for (int l = 0; l < 4; ++l) {
-      t0[l] = acc[0 + l][r] + acc[4 + l][r] + acc[8 + l][r];
-      t1[l] = acc[4 + l][r] - acc[8 + l][r] - acc[12 + l][r];
+  if constexpr (RES) {
+    // ---- output stage with a residual: residual and bias of all 16 channels are fetched up front (the wave is alone on its
+    // SIMD: a load issued between the stores is waited for in full, and `out` may alias `res`, so the compiler keeps every
+    // load behind the stores in front of it -- 16 exposed round trips per workgroup, +20 % on a 32-step layer)
+    const int n = n0 + wn * 32 + l31;
+    const bool n_ok = n < p.n_tiles;
+    int64_t o_base;  // element offset of (batch item, channel 0, first pixel of the tile) in a [b][cout][H][W] tensor
+    int r_off;       // the same in the residual, as a byte offset (out of range for a tile past the end: loads return zeros)
+    {
+      const int nc = min(n, p.n_tiles - 1);
+      const int b = nc / p.tiles_per_img;
+      const int rr = nc - b * p.tiles_per_img;
+      const int ty = rr / p.tiles_x, tx = rr - ty * p.tiles_x;
+      const int64_t pix = (int64_t)(2 * ty) * p.W + 2 * tx;
+      o_base = (int64_t)b * p.cout * HW + pix;
+      r_off = n_ok ? (int)(((int64_t)b * p.res_bs + pix) * 4) : (int)0x80000000;
     }
-    float y[2][2];
-    y[0][0] = t0[0] + t0[1] + t0[2];
-    y[0][1] = t0[1] - t0[2] - t0[3];
-    y[1][0] = t1[0] + t1[1] + t1[2];
-    y[1][1] = t1[1] - t1[2] - t1[3];
-    const float bv = p.bias ? p.bias[m] : 0.0f;
-    const int64_t o = ((int64_t)b * p.cout + m) * HW + pix;
-    const int64_t ro = (int64_t)b * p.res_bs + (int64_t)m * HW + pix;
+    f32x2 rv[16][2];
+    float bv[16];
+    auto fetch_res = [&]() {
+      const __amdgpu_buffer_rsrc_t rres = make_rsrc(p.res ? p.res : p.out, p.res ? 0x7fffffff : 0);
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      f32x2 v = {y[a][0] + bv, y[a][1] + bv};
-      if (p.res) {
-        const f32x2 rv = *reinterpret_cast<const f32x2*>(p.res + ro + (int64_t)a * p.W);
-        v[0] += rv[0];
-        v[1] += rv[1];
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int mo = m < p.cout ? r_off + (int)((int64_t)m * HW * 4) : (int)0x80000000;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+          rv[r][a] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rres, mo + a * p.W * 4, 0, 0));
+        bv[r] = p.bias ? p.bias[min(m, p.cout - 1)] : 0.0f;
       }
+    };
+    fetch_res();
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- output stage: Y = A^T M A per (channel, tile), bias / residual / activation, two 8-byte stores per channel
+    if (!n_ok) return;
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        float x = v[e];
-        if (p.act == DEVA_ACT_RELU) {
-          x = fmaxf(x, 0.0f);
-        } else if (p.act == DEVA_ACT_SIGMOID) {
-          x = sigmoidf_(x);
-        } else if (p.act == DEVA_ACT_SQUARE_PLUS_ONE) {
-          x = x * x + 1.0f;
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (m >= p.cout) continue;
+      float t0[4], t1[4];
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        t0[l] = acc[0 + l][r] + acc[4 + l][r] + acc[8 + l][r];
+        t1[l] = acc[4 + l][r] - acc[8 + l][r] - acc[12 + l][r];
+      }
+      float y[2][2];
+      y[0][0] = t0[0] + t0[1] + t0[2];
+      y[0][1] = t0[1] - t0[2] - t0[3];
+      y[1][0] = t1[0] + t1[1] + t1[2];
+      y[1][1] = t1[1] - t1[2] - t1[3];
+      const int64_t o = o_base + (int64_t)m * HW;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        f32x2 v = {y[a][0] + bv[r] + rv[r][a][0], y[a][1] + bv[r] + rv[r][a][1]};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          float x = v[e];
+          if (p.act == DEVA_ACT_RELU) {
+            x = fmaxf(x, 0.0f);
+          } else if (p.act == DEVA_ACT_SIGMOID) {
+            x = sigmoidf_(x);
+          } else if (p.act == DEVA_ACT_SQUARE_PLUS_ONE) {
+            x = x * x + 1.0f;
+          }
+          v[e] = x;
         }
-        v[e] = x;
+        *reinterpret_cast<f32x2*>(p.out + o + (int64_t)a * p.W) = v;
       }
-      *reinterpret_cast<f32x2*>(p.out + o + (int64_t)a * p.W) = v;
+      __builtin_amdgcn_sched_barrier(0);  // one channel at a time: 16 accumulator reads each, not all 256 hoisted to the top
+    }
+  } else {
+    // ---- output stage: Y = A^T M A per (channel, tile), bias / residual / activation, two 8-byte stores per channel
+    const int n = n0 + wn * 32 + l31;
+    if (n >= p.n_tiles) return;
+    const int b = n / p.tiles_per_img;
+    const int rr = n - b * p.tiles_per_img;
+    const int ty = rr / p.tiles_x, tx = rr - ty * p.tiles_x;
+    const int64_t pix = (int64_t)(2 * ty) * p.W + 2 * tx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (m >= p.cout) continue;
+      float t0[4], t1[4];
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        t0[l] = acc[0 + l][r] + acc[4 + l][r] + acc[8 + l][r];
+        t1[l] = acc[4 + l][r] - acc[8 + l][r] - acc[12 + l][r];
+      }
+      float y[2][2];
+      y[0][0] = t0[0] + t0[1] + t0[2];
+      y[0][1] = t0[1] - t0[2] - t0[3];
+      y[1][0] = t1[0] + t1[1] + t1[2];
+      y[1][1] = t1[1] - t1[2] - t1[3];
+      const float bv = p.bias ? p.bias[m] : 0.0f;
+      const int64_t o = ((int64_t)b * p.cout + m) * HW + pix;
+      const int64_t ro = (int64_t)b * p.res_bs + (int64_t)m * HW + pix;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        f32x2 v = {y[a][0] + bv, y[a][1] + bv};
+        if (p.res) {
+          const f32x2 rv = *reinterpret_cast<const f32x2*>(p.res + ro + (int64_t)a * p.W);
+          v[0] += rv[0];
+          v[1] += rv[1];
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          float x = v[e];
+          if (p.act == DEVA_ACT_RELU) {
+            x = fmaxf(x, 0.0f);
+          } else if (p.act == DEVA_ACT_SIGMOID) {
+            x = sigmoidf_(x);
+          } else if (p.act == DEVA_ACT_SQUARE_PLUS_ONE) {
+            x = x * x + 1.0f;
+          }
+          v[e] = x;
+        }
+        *reinterpret_cast<f32x2*>(p.out + o + (int64_t)a * p.W) = v;
+      }
     }
   }
 }
@@ -356,6 +508,7 @@ int launch_conv_wino(const ConvArgs& a, const float* u, hipStream_t st) {
   if (!u || !a.vec_ok || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || (a.H & 1) || (a.W & 1) || a.W < 4) return -1;
   if (a.c0 % KC || a.ctot % KC || a.cout < 32) return -1;
   if (a.in0_span >= (1ll << 29) || a.in1_span >= (1ll << 29)) return -1;  // 32-bit byte offsets inside a source (buffer loads)
+  if (a.res && (int64_t)(a.n_total / a.OHW) * a.res_bs >= (1ll << 29)) return -1;  // ... and inside the residual
   WinoArgs p;
   p.in0 = a.in0;
   p.in1 = a.in1 ? a.in1 : a.in0;
@@ -389,12 +542,30 @@ int launch_conv_wino(const ConvArgs& a, const float* u, hipStream_t st) {
     p.ablate = abl;
   }
 #endif
+#if defined(DEVA_CONV_PROBES) || defined(DEVA_WINO_TUNE)  // (`make EXTRA=-DDEVA_WINO_TUNE`: the threshold alone, kernels as shipped)
+  static const int min_blocks_probe = [] {
+    const char* e = getenv("DEVA_WINO_MIN_BLOCKS");
+    return e ? atoi(e) : 160;
+  }();
+  const int min_blocks = min_blocks_probe;
+#else
+  const int min_blocks = 160;
+#endif
   const int64_t blocks = (int64_t)p.blocks_m * ceil_div(p.n_tiles, WN);
-  if (blocks < 192) return -1;  // one workgroup per CU at a time: fewer than that and the direct kernels' split-K wins
+  if (blocks < min_blocks) return -1;  // one workgroup per CU at a time: fewer than that and the direct kernels' split-K wins
+  const dim3 grid((unsigned)blocks), block(256);
   if (p.relu_in) {
-    hipLaunchKernelGGL(conv_wino_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    if (p.res) {
+      hipLaunchKernelGGL((conv_wino_kernel<true, true>), grid, block, 0, st, p);
+    } else {
+      hipLaunchKernelGGL((conv_wino_kernel<true, false>), grid, block, 0, st, p);
+    }
   } else {
-    hipLaunchKernelGGL(conv_wino_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    if (p.res) {
+      hipLaunchKernelGGL((conv_wino_kernel<false, true>), grid, block, 0, st, p);
+    } else {
+      hipLaunchKernelGGL((conv_wino_kernel<false, false>), grid, block, 0, st, p);
+    }
   }
   return check_launch("deva_conv2d (Winograd F(2x2, 3x3))");
 }
