@@ -20,7 +20,7 @@ run_test() {
   local dir=$1 f=$2 to=${3:-1500}
   mkdir -p $OUT/$dir
   local t0=$SECONDS
-  timeout -k 10 $to python -m pytest tests/$f.py -m gpu -q -s -p no:cacheprovider > $OUT/$dir/$f.log 2>&1
+  timeout -k 10 $to python -m pytest tests/$f.py -m gpu -q -s -p no:cacheprovider --durations=12 > $OUT/$dir/$f.log 2>&1
   local rc=$?
   echo "$dir/$f exit $rc in $((SECONDS-t0)) s : $(tail -1 $OUT/$dir/$f.log) [sources $(cat tracking-anything-with-deva_amd/csrc/*.hip tracking-anything-with-deva_amd/csrc/*.h include/*.h | sha1sum | cut -c1-12)]" | tee -a $OUT/$dir/summary.txt
   if [ $rc -ne 0 ]; then grep -E "^(FAILED|ERROR)|Error|assert" $OUT/$dir/$f.log | head -20; fi

@@ -46,15 +46,16 @@ def main():
     frames = agg.get('upsample4x_softmax_kernel', [0])[0] + 1  # one decoder pass per propagated frame + the annotated frame
     is_conv = lambda n: n.startswith(('conv_', 'splitk_reduce'))
     conv = sum(a[1] for n, a in agg.items() if is_conv(n))
-    mfma = sum(a[1] for n, a in agg.items() if n.startswith(('conv_mfma', 'conv_igemm')))
+    mfma = sum(a[1] for n, a in agg.items() if n.startswith(('conv_mfma', 'conv_igemm', 'conv_wino')))
+    wino = sum(a[1] for n, a in agg.items() if n.startswith('conv_wino'))
     aff = sum(a[1] for n, a in agg.items() if n.startswith('affinity') or n.startswith('readout'))
     print(f'# rocprofv3 --kernel-trace of `{cmd}`\n')
     print(f'One workload in the trace: the {label} ({frames} frames: annotated + warm-up + timed + event-timed '
           f'replay + the per-frame-synchronised replay).  {len(rows)} dispatches, {total / 1e3:.1f} ms of kernel time'
           + (f' (+ {probe[0]} launches = {probe[1] / 1e3:.1f} ms of the matrix-pipe probe, left out of every figure below)' if probe[0] else '') + '.\n')
-    print(f'* convolution kernels (conv_mfma / conv_igemm + splitk_reduce + conv_cout1 / conv3x3_cout1_rows): {conv / 1e3:.1f} ms = '
+    print(f'* convolution kernels (conv_wino / conv_mfma / conv_igemm + splitk_reduce + conv_cout1 / conv3x3_cout1_rows): {conv / 1e3:.1f} ms = '
           f'**{conv / 1e3 / frames:.3f} ms per frame** = {100 * conv / total:.1f} % of GPU time '
-          f'(MFMA kernels alone {mfma / 1e3 / frames:.3f} ms per frame)')
+          f'(MFMA kernels alone {mfma / 1e3 / frames:.3f} ms per frame, of which the Winograd kernels {wino / 1e3 / frames:.3f})')
     print(f'* memory read (affinity_* + readout_sparse): {aff / 1e3:.2f} ms = {aff / 1e3 / frames:.3f} ms per frame = {100 * aff / total:.2f} %')
     print(f'* {gflop:.2f} GF of convolution per frame (bench.py roofline.gflop_per_frame) / {conv / 1e3 / frames:.3f} ms = '
           f'{gflop / (conv / 1e3 / frames):.1f} TFLOP/s = {gflop / (conv / 1e3 / frames) / 157.3:.3f} of the fp32-MFMA peak, kernel time '

@@ -104,7 +104,7 @@ def conv(prefix, out):
         'hbm_read_bytes_per_frame (FETCH_SIZE KiB x 1024 x 2, gfx950 correction)': rd / frames,
         'hbm_write_bytes_per_frame (WRITE_SIZE KiB x 1024)': wr / frames,
         'hbm_bytes_per_frame': (rd + wr) / frames,
-        'kernels': 'conv_mfma_kernel*, conv_igemm_kernel*, splitk_reduce_kernel, conv_cout1 kernels (everything deva_conv2d launches)',
+        'kernels': 'conv_wino_kernel*, conv_mfma_kernel*, conv_igemm_kernel*, splitk_reduce_kernel, conv_cout1 kernels (everything deva_conv2d launches)',
         'per_dispatch_averages': per_kernel,
     }
     g = counters.get('conv_mfma_kernel', None) or next((c for n, c in counters.items() if n.startswith('conv_mfma')), {})
@@ -112,6 +112,10 @@ def conv(prefix, out):
         # busy cycles are summed over the SIMDs: 1024 SIMDs x active cycles = 100 %
         res['conv_mfma_mfma_util_frac'] = (g['SQ_VALU_MFMA_BUSY_CYCLES'][0] / g['SQ_VALU_MFMA_BUSY_CYCLES'][1]) / (
             g['GRBM_GUI_ACTIVE'][0] / g['GRBM_GUI_ACTIVE'][1] / 8.0 * 1024)
+    w = next((c for n, c in counters.items() if n.startswith('conv_wino')), {})
+    if 'SQ_VALU_MFMA_BUSY_CYCLES' in w and 'GRBM_GUI_ACTIVE' in w:
+        res['conv_wino_mfma_util_frac'] = (w['SQ_VALU_MFMA_BUSY_CYCLES'][0] / w['SQ_VALU_MFMA_BUSY_CYCLES'][1]) / (
+            w['GRBM_GUI_ACTIVE'][0] / w['GRBM_GUI_ACTIVE'][1] / 8.0 * 1024)
     with open(out, 'w') as f:
         json.dump(res, f, indent=1)
     print(json.dumps({k: v for k, v in res.items() if k != 'per_dispatch_averages'}, indent=1))
@@ -238,7 +242,7 @@ def clock(probe_prefix, bench_prefix, out):
         dur = defaultdict(lambda: [0.0, 0])
         for name, c in counters.items():
             key = ('mfma_probe_kernel' if 'probe' in name else 'conv_mfma_kernel' if name.startswith('conv_mfma') else
-                   'conv_f16_kernel' if name.startswith('conv_f16') else None)
+                   'conv_wino_kernel' if name.startswith('conv_wino') else 'conv_f16_kernel' if name.startswith('conv_f16') else None)
             if key is None or 'GRBM_GUI_ACTIVE' not in c:
                 continue
             for cn in ('GRBM_GUI_ACTIVE', 'SQ_VALU_MFMA_BUSY_CYCLES'):

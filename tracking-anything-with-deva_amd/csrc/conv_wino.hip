@@ -86,6 +86,7 @@ struct WinoArgs {
   int act;
   float* out;
   int blocks_m;
+  int by_tiles;  // grid numbered XCD-major (see the kernel)
   int ablate;  // `make PROBES=1` builds only (DEVA_WINO_ABLATE): timing runs with parts of the K loop switched off
 };
 
@@ -107,8 +108,17 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;  // 32 channels x 32 tiles of the wave
-  // cout blocks fastest: the workgroups that share an activation tile run side by side
-  const int block_m = blockIdx.x % p.blocks_m, block_n = blockIdx.x / p.blocks_m;
+  // cout blocks fastest: the workgroups that share an activation tile run side by side.  Workgroup b runs on XCD b % 8, each
+  // with its own L2: as it is, XCD x sees the cout blocks = x (mod 8) of EVERY tile block -- 1/8 of the weights, all the
+  // activations.  Right when the weights are the bigger operand (GRU: 100 MB of U against 33 MB); when the activations
+  // are (up_8_4: 132 MB against 4 MB) p.by_tiles renumbers the grid so that an XCD gets a contiguous range of TILE blocks
+  // with all their cout blocks, one after the other: an activation tile enters one L2, not blocks_m of them
+  int lb = blockIdx.x;
+  if (p.by_tiles) {
+    const int nb = gridDim.x, x = lb & 7, i = lb >> 3;
+    lb = x * (nb >> 3) + min(x, nb & 7) + i;
+  }
+  const int block_m = lb % p.blocks_m, block_n = lb / p.blocks_m;
   const int m0 = block_m * WM, n0 = block_n * WN;
 
   // ---- activation staging: thread = (channel pair sm = wave, tile st = lane): channels 8 s + 2 sm, 8 s + 2 sm + 1
@@ -532,6 +542,7 @@ int launch_conv_wino(const ConvArgs& a, const float* u, hipStream_t st) {
   p.act = a.act;
   p.out = a.out;
   p.blocks_m = p.cout_pad / WM;
+  p.by_tiles = (int64_t)batch * a.HW > 16ll * p.cout_pad;  // activation elements per channel > transformed weights per channel
   p.ablate = 0;
 #ifdef DEVA_CONV_PROBES
   {
@@ -548,6 +559,11 @@ int launch_conv_wino(const ConvArgs& a, const float* u, hipStream_t st) {
     return e ? atoi(e) : 160;
   }();
   const int min_blocks = min_blocks_probe;
+  static const int by_tiles_probe = [] {
+    const char* e = getenv("DEVA_WINO_BY_TILES");
+    return e ? atoi(e) : -1;
+  }();
+  if (by_tiles_probe >= 0) p.by_tiles = by_tiles_probe;
 #else
   const int min_blocks = 160;
 #endif
