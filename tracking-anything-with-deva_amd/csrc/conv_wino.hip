@@ -206,38 +206,47 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(const WinoArgs p) {
     }
   };
 
+  // fragments of position 8 ph + j: A = 16 bytes (the four k values of the lane's channel and k parity), B = four floats
+  f32x4 fa[2][2], fb[2][2];
+  auto read_frag = [&](int buf, int set, int g) {
+    const float* a_rd = sA[buf] + ((8 * ph) * 2 * 64 + half * 64 + wm * 32 + l31) * 4;
+    const float* b_rd = sB[buf] + ((8 * ph) * 2 + half) * 4 * 64 + wn * 32 + l31;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int q = 2 * g + j;
+      fa[set][j] = *reinterpret_cast<const f32x4*>(a_rd + q * 2 * 64 * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) fb[set][j][e] = b_rd[(q * 2 * 4 + e) * 64];
+    }
+  };
+  auto multiply = [&](int set, int g) {  // positions 2 g, 2 g + 1: consecutive MFMAs never share an accumulator
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[2 * g + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][j][e], fb[set][j][e], acc[2 * g + j], 0, 0, 0);
+  };
+  // A step runs ACROSS the workgroup barrier: the fragments of its last two positions are in registers before the barrier,
+  // their MFMAs are issued behind it and cover the LDS latency of the next step's first fragments (both waves of a SIMD
+  // arrive at the barrier together: without this the matrix pipe idles for a round trip at every step)
   load_step(0);
   store_step(0);
   __syncthreads();
+  read_frag(0, 0, 0);
   for (int s = 0; s < ksteps; ++s) {
     const int buf = s & 1;
     const bool more = s + 1 < ksteps;
-    // fragments of position 8 ph + j: A = 16 bytes (the four k values of the lane's channel and k parity), B = four floats
-    const float* a_rd = sA[buf] + ((8 * ph) * 2 * 64 + half * 64 + wm * 32 + l31) * 4;
-    const float* b_rd = sB[buf] + ((8 * ph) * 2 + half) * 4 * 64 + wn * 32 + l31;
-    f32x4 fa[2][2], fb[2][2];
-    auto read_frag = [&](int set, int g) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int q = 2 * g + j;
-        fa[set][j] = *reinterpret_cast<const f32x4*>(a_rd + q * 2 * 64 * 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) fb[set][j][e] = b_rd[(q * 2 * 4 + e) * 64];
-      }
-    };
-    read_frag(0, 0);
     if (more) load_step(s + 1);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      if (g + 1 < 4) read_frag((g + 1) & 1, g + 1);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[2 * g + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][j][e], fb[g & 1][j][e], acc[2 * g + j], 0, 0, 0);
-      if (g == (RELU ? 2 : 3) && more) store_step(buf ^ 1);
+    for (int g = 0; g < 3; ++g) {
+      read_frag(buf, (g + 1) & 1, g + 1);
+      multiply(g & 1, g);
+      if (RELU && g == 2 && more) store_step(buf ^ 1);
     }
+    if (!RELU && more) store_step(buf ^ 1);
     __syncthreads();
+    if (more) read_frag(buf ^ 1, 0, 0);
+    multiply(1, 3);
   }
 
   // ---- output stage.  Rows of M held by this half -> partial t0 = (A^T M)[0], t1 = (A^T M)[1], then the column pass:

@@ -114,9 +114,12 @@ class CompiledGraph:
     # whose FMA order the affinity tests pin, so the inputs of the memory read's top-k do not move by a bit
     SPLIT_SCOPES = AMP_SCOPES
     # modules whose 3x3 stride-1 convolutions carry Winograd-transformed weights on the plain fp32 path (csrc/conv_wino.hip:
-    # F(2x2, 3x3), 2.25x fewer MFMAs, ~2x the direct kernels' round-off; the library takes it for the big layers only): the same
-    # two scopes -- the key encoder and the key projection keep the direct kernels' arithmetic under the memory read's top-k
-    WINO_SCOPES = AMP_SCOPES
+    # F(2x2, 3x3), 2.25x fewer MFMAs, round-off BELOW the direct kernels' -- a quarter of the accumulated terms; the library
+    # takes it only for layers that fill the chip).  The key encoder's bottleneck 3x3s are among them from 1080p up (layer1 /
+    # layer2 at 1080p, layer3 too at 4K: 13 launches = 30 % of a 4K frame on the direct kernels); at 480p they stay below the
+    # threshold, so the keys of the headline configuration are the direct kernels' bit for bit.  The key projection (1x1 /
+    # 3x3 at 1/16 resolution, 64 + 64 + 64 channels) is never eligible.
+    WINO_SCOPES = AMP_SCOPES + ('pixel_encoder.',)
 
     def __init__(self, sd: Dict[str, torch.Tensor], device: torch.device, amp: bool = False, split: bool = False,
                  split_key_encoder: bool = False, winograd: bool = True):
