@@ -129,12 +129,13 @@ typedef struct deva_conv_desc {
   int32_t split_scale_log2;
   int32_t* split_flag;
   /* optional: the weights of a 3x3 / stride 1 / pad 1 layer transformed for Winograd F(2x2, 3x3) by deva_conv_pack_wino
-   * (NULL: the direct kernels).  With amp == 0, even height / width (>= 4), c0 and c1 multiples of 8 and enough 2x2 output
-   * tiles to fill the chip, the layer runs csrc/conv_wino.hip: 16 instead of 36 multiply-adds per input channel and 2x2
-   * outputs on the fp32 matrix pipes, transforms with constants 0, +-1, +-1/2 in fp32 -- the arithmetic of the reference's
-   * nn.Conv2d (big_modules.py:54-212, modules.py:81-169) to ~2x the direct kernels' round-off (5e-7 of the output range on
-   * the network's layer shapes; the same 2e-5 gate in tests/test_gpu_a_conv.py).  Everything else runs the direct kernels
-   * on `weight`. */
+   * (NULL: the direct kernels).  With amp == 0, even height / width (>= 4), c0 and c1 multiples of 8, cout >= 32,
+   * guard-banded inputs and enough 2x2 output tiles to fill the chip (>= 160 workgroups of 64 channels x 64 tiles), the
+   * layer runs csrc/conv_wino.hip: 16 instead of 36 multiply-adds per input channel and 2x2 outputs on the fp32 matrix
+   * pipes, transforms with constants 0, +-1, +-1/2 in fp32 -- the arithmetic of the reference's nn.Conv2d
+   * (big_modules.py:54-212, modules.py:81-169, resnet.py:78-152) with a quarter of the accumulated terms: measured
+   * round-off below the direct kernels' on the network's layer shapes (the same 2e-5 gate in tests/test_gpu_a_conv.py).
+   * Everything else runs the direct kernels on `weight`. */
   const float* weight_wino;
 } deva_conv_desc;
 

@@ -340,7 +340,7 @@ def test_api_surface_matches_reference(golden_dir):
                              switch=type(a).__name__ == '_StoreTrueAction')
                 for a in parser._actions if a.dest != 'help'}
     # flags this package adds on top of the reference's surface (the drivers never pass them)
-    for extension in ('f16_split', 'f16_split_key_encoder'):
+    for extension in ('f16_split', 'f16_split_key_encoder', 'no_winograd'):
         ext = got_args.pop(extension)
         assert ext['switch'] and ext['default'] is False
     assert got_args == ref.pop('eval_args')

@@ -20,8 +20,9 @@ _FLAGS = (
                                'operands, fp32 accumulation) in the value encoder and the mask decoder; held to the fp32 '
                                'parity bounds, 2.5-3x the fp32 rate of those layers.  Error per product: 2^-21 |x w| + 2^-25 |w| '
                                '(absolute floor: activations are not pre-scaled; layers whose inputs are all << 0.1 lose bits)'),
-    ('no_winograd', None, False, 'extension: keep the big 3x3 layers of the value encoder / mask decoder on the direct fp32 kernels '
-                                 '(default: Winograd F(2x2, 3x3) on the fp32 matrix pipes, 2.25x fewer multiply-adds, same parity gates)'),
+    ('no_winograd', None, False, 'extension: keep the big 3x3 layers (value encoder / mask decoder; key encoder from 1080p up) on the '
+                                 'direct fp32 kernels (default: Winograd F(2x2, 3x3) on the fp32 matrix pipes, 2.25x fewer '
+                                 'multiply-adds, same parity gates)'),
     ('f16_split_key_encoder', None, False, 'extension, with --f16_split: the key encoder on the split kernels too (the memory '
                                            "read's inputs then move by fp32 round-off, as under any change of accumulation order)"),
     # network widths (C^k, C^v, pixel feature)
