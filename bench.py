@@ -206,10 +206,10 @@ class ConvTimer:
             f16 = (d.amp if f16 else 0)
             # fp32 Winograd F(2x2, 3x3) (csrc/conv_wino.hip: launch_conv_wino's rule): 16 instead of 36 multiply-adds per input
             # channel and 2x2 outputs -- class 3; its ALGORITHMIC flops (the direct count) stay what `achieved` is made of
-            if (not d.amp and d.weight_wino and d.kh == 3 and d.kw == 3 and d.stride == 1 and d.pad == 1 and d.height % 2 == 0
+            if (not d.amp and d.weight_wino and d.kh == 3 and d.kw == 3 and d.stride == 1 and d.pad == 1
                     and d.width % 2 == 0 and d.width >= 4 and d.c0 % 8 == 0 and cin % 8 == 0 and d.cout >= 32
                     and (d.height * d.width) % 4 == 0
-                    and ((d.cout + 63) // 64) * ((d.batch * (d.height // 2) * (d.width // 2) + 63) // 64) >= 160):
+                    and ((d.cout + 63) // 64) * ((d.batch * ((d.height + 1) // 2) * (d.width // 2) + 63) // 64) >= 160):
                 f16 = 3
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             self._space(stream)

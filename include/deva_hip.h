@@ -129,7 +129,7 @@ typedef struct deva_conv_desc {
   int32_t split_scale_log2;
   int32_t* split_flag;
   /* optional: the weights of a 3x3 / stride 1 / pad 1 layer transformed for Winograd F(2x2, 3x3) by deva_conv_pack_wino
-   * (NULL: the direct kernels).  With amp == 0, even height / width (>= 4), c0 and c1 multiples of 8, cout >= 32,
+   * (NULL: the direct kernels).  With amp == 0, even width (>= 4), c0 and c1 multiples of 8, cout >= 32,
    * guard-banded inputs and enough 2x2 output tiles to fill the chip (>= 160 workgroups of 64 channels x 64 tiles), the
    * layer runs csrc/conv_wino.hip: 16 instead of 36 multiply-adds per input channel and 2x2 outputs on the fp32 matrix
    * pipes, transforms with constants 0, +-1, +-1/2 in fp32 -- the arithmetic of the reference's nn.Conv2d

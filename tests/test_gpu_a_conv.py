@@ -352,6 +352,9 @@ WINO_CASES = [
     ('wino_gru_shape', 512, 512, 1536, 2, 30, 54, False, False, 'none', ops.ACT_NONE, True),
     ('wino_narrow', 16, 0, 128, 200, 34, 4, False, False, 'full', ops.ACT_SQUARE_PLUS_ONE, True),
     ('wino_ragged_tiles', 64, 0, 192, 7, 46, 62, False, True, 'none', ops.ACT_RELU, True),
+    # odd heights (4K: 2160 / 16 = 135 rows): the last tile row holds one output row
+    ('wino_odd_height_res', 32, 0, 256, 4, 45, 64, False, False, 'full', ops.ACT_RELU, True),
+    ('wino_odd_height_relu', 32, 32, 200, 5, 27, 72, False, True, 'none', ops.ACT_NONE, False),
 ]
 
 
@@ -387,7 +390,7 @@ def test_conv_wino_matches_cpu(case):
 
 def test_conv_wino_small_layers_stay_on_the_direct_kernels():
     """fewer than 160 workgroups of 64 channels x 64 tiles (most batch-1 layers of a 480p frame): the library ignores the
-    transformed weights -- bit-identical to the call without them; so do odd map sizes"""
+    transformed weights -- bit-identical to the call without them; so do odd widths and maps of 4 k + 2 pixels"""
     g = torch.Generator().manual_seed(8)
     w = rand(g, 64, 64, 3, 3, scale=0.05)
     pc, pcd = to_dev(ops.pack_conv(w, None, None, wino=True)), to_dev(ops.pack_conv(w, None, None))

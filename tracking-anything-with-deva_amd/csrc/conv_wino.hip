@@ -276,6 +276,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(const WinoArgs p) {
   if (ph == 1 || !n_ok) return;
   int64_t o_base;
   int r_off;
+  bool row1;  // the tile's second output row exists (odd heights: the last tile row has one)
   {
     const int b = n / p.tiles_per_img;
     const int rr = n - b * p.tiles_per_img;
@@ -283,6 +284,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(const WinoArgs p) {
     const int64_t pix = (int64_t)(2 * ty) * p.W + 2 * tx;
     o_base = (int64_t)b * p.cout * HW + pix;
     r_off = (int)(((int64_t)b * p.res_bs + pix) * 4);
+    row1 = 2 * ty + 1 < p.H;
   }
   const __amdgpu_buffer_rsrc_t rres = make_rsrc(RES ? p.res : p.out, RES ? 0x7fffffff : 0);
 #pragma unroll
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(const WinoArgs p) {
         const int mo = m < p.cout ? r_off + (int)((int64_t)m * HW * 4) : (int)0x80000000;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
-          rv[k][a] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rres, mo + a * p.W * 4, 0, 0));
+          rv[k][a] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rres, (a == 0 || row1) ? mo + a * p.W * 4 : (int)0x80000000, 0, 0));
       } else {
         rv[k][0] = rv[k][1] = f32x2{0.0f, 0.0f};
       }
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(const WinoArgs p) {
           }
           v[j] = x;
         }
-        *reinterpret_cast<f32x2*>(p.out + o + (int64_t)a * p.W) = v;
+        if (a == 0 || row1) *reinterpret_cast<f32x2*>(p.out + o + (int64_t)a * p.W) = v;
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(const WinoArgs p) {
 
 // -> 0 launched, 1 launch error, -1 not eligible (the caller runs the direct kernels)
 int launch_conv_wino(const ConvArgs& a, const float* u, hipStream_t st) {
-  if (!u || !a.vec_ok || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || (a.H & 1) || (a.W & 1) || a.W < 4) return -1;
+  if (!u || !a.vec_ok || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || (a.W & 1) || a.W < 4) return -1;  // (odd heights: a last tile row of one output row)
   if (a.c0 % KC || a.ctot % KC || a.cout < 32) return -1;
   if (a.in0_span >= (1ll << 29) || a.in1_span >= (1ll << 29)) return -1;  // 32-bit byte offsets inside a source (buffer loads)
   if (a.res && (int64_t)(a.n_total / a.OHW) * a.res_bs >= (1ll << 29)) return -1;  // ... and inside the residual
@@ -359,7 +361,7 @@ int launch_conv_wino(const ConvArgs& a, const float* u, hipStream_t st) {
   p.H = a.H;
   p.W = a.W;
   p.tiles_x = a.W / 2;
-  p.tiles_per_img = (a.H / 2) * (a.W / 2);
+  p.tiles_per_img = ((a.H + 1) / 2) * (a.W / 2);
   const int batch = a.n_total / a.OHW;
   p.n_tiles = batch * p.tiles_per_img;
   p.u = u;
