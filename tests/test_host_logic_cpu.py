@@ -575,3 +575,30 @@ def test_memory_manager_keys_its_prepared_banks_on_the_versions(emu):
     mem.purge_except([7])
     mem._prep_of(1, False)
     assert 0 not in mem._bank_prep and 1 in mem._bank_prep
+
+
+def test_winograd_weights_follow_the_flags(emu, recipe_state_dict):
+    """which convolutions carry Winograd-transformed weights (deva/model/_graph.py:WINO_SCOPES): the 3x3 layers of the value
+    encoder, the mask decoder and the key encoder by default; none with --no_winograd, --f16_split or --amp (their kernels take
+    those layers); never the key projection or a 1x1 / 7x7 layer"""
+    from deva.model.network import DEVA
+    sd, _ = recipe_state_dict
+
+    def wino_layers(**flags):
+        net = DEVA(dict(synth.base_config(), **flags))
+        net.load_weights(sd)
+        g = net.graph()
+        return {name for name, pc in g.convs.items() if pc.weight_wino is not None}, g
+
+    on, g = wino_layers()
+    assert on, 'no layer carries Winograd weights by default'
+    for name in on:
+        w = sd[name + '.weight']
+        assert tuple(w.shape[2:]) == (3, 3) and w.shape[1] % 8 == 0, name
+        assert name.startswith(('mask_encoder.', 'mask_decoder.', 'pixel_encoder.')), name
+    eligible = {n[:-len('.weight')] for n, w in sd.items() if n.endswith('.weight') and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3)
+                and w.shape[1] % 8 == 0 and n.startswith(('mask_encoder.', 'mask_decoder.', 'pixel_encoder.'))}
+    assert on == {n for n in eligible if n in g.convs}
+    assert not any(n.startswith('key_proj') for n in on)
+    for flags in (dict(no_winograd=True), dict(f16_split=True), dict(f16_split=True, f16_split_key_encoder=True), dict(amp=True)):
+        assert wino_layers(**flags)[0] == set(), flags
